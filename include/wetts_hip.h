@@ -1,0 +1,234 @@
+/*
+ * wetts_hip.h -- C ABI of libwetts_hip.so: the MI355X (gfx950) native VITS inference path.
+ *
+ * This is the drop-in boundary for ONE hot path of wenet-e2e/wetts: SynthesizerTrn.infer()
+ * (text encoder -> duration -> length regulate -> flow^-1 -> HiFi-GAN) plus the standalone
+ * monotonic-alignment search.  The reference has no FFI seam on this path (it is nn.Modules all
+ * the way down), so every entry point below cites the reference Python / C++
+ * interface whose arithmetic it replaces.  Citations are relative to the reference repo root.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no torch / HIP types in any signature (`stream` is a
+ *     hipStream_t passed as void*; NULL = the default stream).
+ *   - every data pointer is a DEVICE pointer owned by the caller unless the name ends in `_host`.
+ *   - activations are contiguous float32, channel-first [B, C, T]; ids / lengths are int64;
+ *     masks are float 0/1 [B, T] (the reference's [B,1,T] with the unit dim dropped).
+ *   - all launches are stream-ordered and asynchronous; nothing allocates after wetts_create():
+ *     scratch comes from the caller's workspace (wetts_workspace_bytes()).
+ *   - return value: 0 = ok, negative = error (WETTS_E_*); wetts_last_error() gives the message
+ *     of the calling thread's last failure.  Kernels never fall back to a CPU path.
+ *   - thread-compatible: one handle may be used from one thread at a time (the reference's
+ *     VitsModel has the same contract, runtime/core/model/vits_model.h:30-66).
+ */
+#ifndef WETTS_HIP_H_
+#define WETTS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WETTS_ABI_VERSION 1
+
+#define WETTS_OK 0
+#define WETTS_E_INVALID (-1)   /* bad argument / unsupported configuration */
+#define WETTS_E_HIP (-2)       /* HIP runtime / launch error               */
+#define WETTS_E_WORKSPACE (-3) /* caller workspace too small               */
+#define WETTS_E_DOMAIN (-4)    /* reference would raise (spline domain...) */
+
+#define WETTS_MAX_STAGES 8
+#define WETTS_MAX_RB_KERNELS 8
+#define WETTS_MAX_RB_DILATIONS 8
+
+/* Hyper-parameters of one model.  Field meaning == ctor arguments of the reference
+ * SynthesizerTrn (wetts/vits/model/models.py:19-51) as splatted from `hps.model`
+ * (wetts/vits/inference.py:72-76). */
+typedef struct wetts_config {
+  int32_t n_vocab;
+  int32_t inter_channels;  /* 192 */
+  int32_t hidden_channels; /* 192 */
+  int32_t filter_channels; /* 768 */
+  int32_t n_heads;         /* 2   */
+  int32_t n_layers;        /* 6   */
+  int32_t kernel_size;     /* 3 (encoder FFN) */
+  int32_t window_size;     /* 4 (attentions.py:20) */
+  int32_t resblock;        /* 1 or 2 (decoders.py:35) */
+  int32_t n_resblock_kernels;
+  int32_t resblock_kernel_sizes[WETTS_MAX_RB_KERNELS];
+  int32_t n_resblock_dilations; /* per resblock: 3 for "1", 2 for "2" */
+  int32_t resblock_dilation_sizes[WETTS_MAX_RB_KERNELS][WETTS_MAX_RB_DILATIONS];
+  int32_t n_upsamples;
+  int32_t upsample_rates[WETTS_MAX_STAGES];
+  int32_t upsample_kernel_sizes[WETTS_MAX_STAGES];
+  int32_t upsample_initial_channel;
+  int32_t n_speakers;   /* 0 => no emb_g, g = None */
+  int32_t gin_channels; /* 256 */
+  int32_t use_sdp;      /* 1: StochasticDurationPredictor, 0: DurationPredictor */
+  int32_t flow_n_flows;     /* 4  (models.py:133-142) */
+  int32_t flow_wn_layers;   /* 4  */
+  int32_t flow_kernel_size; /* 5  */
+  int32_t sdp_n_flows;      /* 4  (models.py:145-150) */
+  int32_t dp_filter_channels; /* 256 (models.py:152-156) */
+  int32_t reserved[8];
+} wetts_config_t;
+
+typedef struct wetts_model wetts_model_t; /* opaque */
+
+/* ---- library / weight-blob layout (no GPU required) ------------------------------------- */
+
+int32_t wetts_abi_version(void);
+const char* wetts_last_error(void);
+
+/* The weight blob is one flat float32 array holding every inference tensor of the reference
+ * state_dict in its natural PyTorch layout, weight-norm pairs already folded
+ * (w = g * v / ||v||, norm over all dims but 0 -- torch.nn.utils.weight_norm dim=0, as used at
+ * decoders.py:41-48,96-153, modules.py:35,49,58).  Names are the reference's state_dict keys
+ * with `weight_g`/`weight_v` collapsed to `weight`.  The library is the single source of truth
+ * for the order: the host loader enumerates it with these three calls.
+ * Replaces: utils/task.py:31-56 load_checkpoint + decoders.py:84-88 remove_weight_norm. */
+int32_t wetts_blob_num_tensors(const wetts_config_t* cfg);
+/* name_buf gets a NUL-terminated key; shape gets up to 4 dims (unused = 0).
+ * offset / numel are in floats. */
+int32_t wetts_blob_tensor_info(const wetts_config_t* cfg, int32_t index, char* name_buf,
+                               size_t name_buf_len, int64_t* offset, int64_t* numel,
+                               int64_t shape[4]);
+int64_t wetts_blob_numel(const wetts_config_t* cfg);
+
+/* ---- model lifetime ---------------------------------------------------------------------- */
+
+/* Builds a model on the CURRENT HIP device from a device-resident blob (e.g. the buffer an
+ * RCCL broadcast just filled).  Repacks conv weights into MFMA fragment order on the device.
+ * The blob may be freed after the call returns.  Replaces SynthesizerTrn.__init__ + .to(device)
+ * + load_checkpoint (inference.py:72-80). */
+int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t blob_numel,
+                     void* stream, wetts_model_t** out);
+void wetts_destroy(wetts_model_t* m);
+
+/* total upsampling factor (prod upsample_rates) == hop length of the checkpoint. */
+int32_t wetts_hop_length(const wetts_model_t* m);
+
+/* Scratch needed by any of the stage calls below for a batch of B utterances, Tx phonemes
+ * (padded) and Ty frames (padded).  Pass Ty = 0 for the pre-length-regulation stages only. */
+int64_t wetts_workspace_bytes(const wetts_model_t* m, int32_t B, int32_t Tx, int32_t Ty);
+
+/* ---- stage entry points (stream-ordered) -------------------------------------------------- */
+
+/* a2 emb_g lookup (models.py:238-241).  g_out [B, gin].  sid may be NULL iff n_speakers==0
+ * (g_out is then zero-filled and ignored downstream, matching g=None). */
+int32_t wetts_speaker_embedding(const wetts_model_t* m, const int64_t* sid, int32_t B,
+                                float* g_out, void* stream);
+
+/* a3-a7 TextEncoder.forward (encoders.py:47-57; attentions.py:70-87,225-282,403-411;
+ * normalization.py:16-19; commons.py:113-117).
+ *   x [B,Tx] int64, x_lengths [B] int64
+ *   x_enc [B,H,Tx], stats [B,2*inter,Tx] (m_p = channels [0,inter), logs_p = the rest),
+ *   x_mask [B,Tx]. */
+int32_t wetts_text_encoder(const wetts_model_t* m, const int64_t* x, const int64_t* x_lengths,
+                           int32_t B, int32_t Tx, float* x_enc, float* stats, float* x_mask,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
+/* a8 StochasticDurationPredictor.forward(reverse=True) (duration_predictors.py:213-219,254-263;
+ * transforms.py:47-187).  eps_w [B,2,Tx] is the caller's standard-normal draw (the reference
+ * calls torch.randn at :257); it is scaled by noise_scale_w inside.  logw [B,Tx].
+ * status_dev (int32[1], may be NULL) is set non-zero on the device if the reference would have
+ * failed `assert (discriminant >= 0)` (transforms.py:171). */
+int32_t wetts_duration_sdp(const wetts_model_t* m, const float* x_enc, const float* x_mask,
+                           const float* g, const float* eps_w, float noise_scale_w, int32_t B,
+                           int32_t Tx, float* logw, int32_t* status_dev, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+
+/* a9 DurationPredictor.forward (duration_predictors.py:297-311). */
+int32_t wetts_duration_dp(const wetts_model_t* m, const float* x_enc, const float* x_mask,
+                          const float* g, int32_t B, int32_t Tx, float* logw, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
+/* a10 durations -> lengths (models.py:254-256): w = exp(logw)*mask*length_scale,
+ * w_ceil = ceil(w) [B,Tx], cum = inclusive cumsum(w_ceil) [B,Tx] (float, exact integers),
+ * y_lengths = clamp_min(sum,1) [B] int64.  The caller reads y_lengths back (the one host sync
+ * the reference also has: commons.py:114-115 `length.max()`). */
+int32_t wetts_durations_to_lengths(const float* logw, const float* x_mask, float length_scale,
+                                   int32_t B, int32_t Tx, float* w_ceil, float* cum,
+                                   int64_t* y_lengths, void* stream);
+
+/* a10-a12 sequence_mask + generate_path + prior expansion + sampling (models.py:257-267,
+ * commons.py:113-136).  Ty = max(y_lengths) chosen by the caller.
+ *   frame2phone [B,Ty] int32: the working form of the alignment (index of the phoneme each
+ *   frame copies, -1 = none); y_mask [B,Ty]; attn [B,Ty,Tx] (may be NULL to skip materialising
+ *   the dense 0/1 path of generate_path); m_p / logs_p come from `stats` [B,2*inter,Tx];
+ *   outputs m_p_exp, logs_p_exp (both may be NULL), z_p [B,inter,Ty];
+ *   eps_z[b,c,t] at eps_z + b*eps_batch_stride + c*eps_channel_stride + t is the caller's
+ *   standard-normal draw (torch.randn_like at models.py:267). */
+int32_t wetts_length_regulate(const wetts_model_t* m, const float* stats, const float* cum,
+                              const float* x_mask, const int64_t* y_lengths, const float* eps_z,
+                              int64_t eps_batch_stride, int64_t eps_channel_stride,
+                              float noise_scale, int32_t B, int32_t Tx, int32_t Ty,
+                              int32_t* frame2phone, float* y_mask, float* attn, float* m_p_exp,
+                              float* logs_p_exp, float* z_p, void* stream);
+
+/* a13 ResidualCouplingTransformersBlock.forward(reverse=True) (flows.py:442-449,494-513;
+ * modules.py:60-106; commons.py:98-105).  z_p, z_out [B,inter,Ty]; z_out is NOT masked
+ * (the reference returns z unmasked, models.py:280). */
+int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float* y_mask,
+                           const float* g, int32_t B, int32_t Ty, float* z_out, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+
+/* a14 Generator.forward (decoders.py:63-82,157-170,205-214).  z [B,inter,L] with arbitrary
+ * batch stride `z_batch_stride` (floats) so a time-slice (z*y_mask)[:,:,:max_len] or a
+ * streaming chunk (export_decoder_forward, models.py:360-363) needs no copy; y_mask may be
+ * NULL (no masking) or [B, >=L] with row stride mask_stride.  audio [B, L*hop]. */
+int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_stride,
+                      int64_t z_channel_stride, const float* y_mask, int64_t mask_stride,
+                      const float* g, int32_t B, int32_t L, float* audio, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+
+/* a15 monotonic_align.maximum_path (utils/monotonic_align.py:6-57).  Needs no model.
+ *   neg_cent [B,Ty,Tx] float32 (not modified), t_ys / t_xs int32[B] (the mask sums the
+ *   reference derives at :16-17), path [B,Ty,Tx] int32 (zero-filled then the 1s written),
+ *   workspace >= B*Ty*Tx*4 bytes (the in-place DP table the reference keeps in `values`). */
+int32_t wetts_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, int32_t B,
+                  int32_t Ty, int32_t Tx, int32_t* path, void* workspace, int64_t workspace_bytes,
+                  void* stream);
+
+/* a16 inference.py:100-110 output scaling: per utterance peak-normalise to 0.6 full scale,
+ * clip, convert to int16.  lengths_samples [B] int64 = valid samples per row (peak is taken
+ * over the valid part only when non-NULL, else over all L samples). */
+int32_t wetts_audio_to_int16(const float* audio, const int64_t* lengths_samples, int32_t B,
+                             int64_t L, int16_t* pcm, void* stream);
+
+/* a1 SynthesizerTrn.infer (models.py:228-280) composed for native hosts (the shape of
+ * runtime/core/model/vits_model.h:37 Forward()).  Synchronises the stream once internally to
+ * read y_lengths.  The caller provides capacity for max_frames frames; on return
+ * *frames_out = max(y_lengths) (<= max_frames, else WETTS_E_WORKSPACE), y_lengths_host[B].
+ * eps_w [B,2,Tx] and eps_z [B,inter,max_frames] (row stride max_frames) are standard-normal
+ * draws.  audio needs capacity B*max_frames*hop floats and is written PACKED as
+ * [B, (*frames_out)*hop].  workspace >= wetts_infer_workspace_bytes(). */
+int64_t wetts_infer_workspace_bytes(const wetts_model_t* m, int32_t B, int32_t Tx,
+                                    int32_t max_frames);
+int32_t wetts_infer(const wetts_model_t* m, const int64_t* x, const int64_t* x_lengths,
+                    const int64_t* sid, const float* eps_w, const float* eps_z,
+                    float noise_scale, float length_scale, float noise_scale_w, int32_t B,
+                    int32_t Tx, int32_t max_frames, float* audio, int64_t* y_lengths_host,
+                    int32_t* frames_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- measurement helpers ------------------------------------------------------------------ */
+
+/* Algorithmic FLOPs / bytes of wetts_hifigan for one frame (SURVEY.md §8d formulas), so
+ * bench.py prices the roofline from the same shapes the kernels run. */
+int32_t wetts_hifigan_cost(const wetts_config_t* cfg, double* flops_per_frame,
+                           double* bytes_per_frame_perconv, double* mrf_flops_per_frame,
+                           double* mrf_bytes_per_frame_perconv);
+
+/* Times `iters` launches of the dominant MRF conv kernel class (all ResBlock convs of the
+ * decoder) with HIP events on `stream`; returns total ms and the number of conv launches.
+ * Used by bench.py for roofline.achieved. */
+int32_t wetts_profile_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_stride,
+                              int64_t z_channel_stride, const float* g, int32_t B, int32_t L,
+                              float* audio, void* workspace, int64_t workspace_bytes, void* stream,
+                              double* mrf_ms, double* total_ms, int32_t* mrf_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WETTS_HIP_H_ */

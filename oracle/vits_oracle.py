@@ -1,0 +1,412 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  Never imported by the product path (wetts_amd/).
+
+A CPU float32 restatement of the reference's SynthesizerTrn.infer() hot path (wenet-e2e/wetts,
+wetts/vits/model/models.py:228-280) as plain functions over a dict of *folded* weights
+(name -> tensor, weight-norm already collapsed).  Because the kernels under test are floating
+point, the restatement is written with torch CPU tensor ops (the task's "torch fp32 reference for
+a floating-point kernel"), but it is a restatement, not the reference's nn.Modules: the
+relative-position attention is the direct banded form, generate_path is an index search, Flip is
+index arithmetic, and ConvTranspose1d is not special-cased anywhere else.
+
+Pinning: tests/test_oracle_golden.py checks every function here against golden vectors produced
+by the *real* reference run in the build container (tests/golden/make_golden.py, fixtures under
+tests/golden/*.npz) and, when /root/reference is present, against the live reference.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Each function cites the reference file:line it follows (paths relative to wetts/vits/).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LRELU_SLOPE = 0.1  # model/modules.py:7
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+def sequence_mask(length, max_length=None):
+    """utils/commons.py:113-117."""
+    if max_length is None:
+        max_length = int(length.max())
+    ar = torch.arange(max_length, dtype=length.dtype)
+    return ar.unsqueeze(0) < length.unsqueeze(1)
+
+
+def layer_norm_c(x, gamma, beta, eps=1e-5):
+    """model/normalization.py:16-19: LayerNorm over the channel dim of [B,C,T]."""
+    xt = x.transpose(1, -1)
+    xt = F.layer_norm(xt, (x.shape[1],), gamma, beta, eps)
+    return xt.transpose(1, -1)
+
+
+def conv1d(W, name, x, dilation=1, padding=0, groups=1):
+    return F.conv1d(x, W[name + ".weight"], W.get(name + ".bias"), dilation=dilation,
+                    padding=padding, groups=groups)
+
+
+# ------------------------------------------------------------------------------------------------
+# text encoder  (model/encoders.py:47-57, model/attentions.py:70-87,225-282,403-411)
+# ------------------------------------------------------------------------------------------------
+def rel_attention(W, pre, x, attn_mask, n_heads, window):
+    """MultiHeadAttention.forward/attention (attentions.py:225-282) in banded form:
+    scores[i,j] = (q_i/sqrt(dk)).k_j + [|j-i|<=w] (q_i/sqrt(dk)).E_k[j-i+w];
+    out_i = sum_j P[i,j] v_j + sum_{|r|<=w} P[i,i+r] E_v[r+w]   (the pad/reshape skew of
+    attentions.py:284-358 computes exactly these terms)."""
+    q = conv1d(W, pre + ".conv_q", x)
+    k = conv1d(W, pre + ".conv_k", x)
+    v = conv1d(W, pre + ".conv_v", x)
+    b, d, t = q.shape
+    dk = d // n_heads
+    q = q.view(b, n_heads, dk, t).transpose(2, 3)  # [b,h,t,dk]
+    k = k.view(b, n_heads, dk, t).transpose(2, 3)
+    v = v.view(b, n_heads, dk, t).transpose(2, 3)
+    qs = q / math.sqrt(dk)
+    scores = torch.matmul(qs, k.transpose(-2, -1))  # [b,h,t,t]
+    Ek = W[pre + ".emb_rel_k"][0]  # [2w+1, dk] shared across heads
+    Ev = W[pre + ".emb_rel_v"][0]
+    rel = torch.matmul(qs, Ek.t())  # [b,h,t,2w+1]
+    idx = torch.arange(t)
+    for r in range(-window, window + 1):
+        i = idx[(idx + r >= 0) & (idx + r < t)]
+        if i.numel():
+            scores[:, :, i, i + r] += rel[:, :, i, r + window]
+    scores = scores.masked_fill(attn_mask == 0, -1e4)
+    p = F.softmax(scores, dim=-1)
+    out = torch.matmul(p, v)  # [b,h,t,dk]
+    for r in range(-window, window + 1):
+        i = idx[(idx + r >= 0) & (idx + r < t)]
+        if i.numel():
+            out[:, :, i, :] += p[:, :, i, i + r].unsqueeze(-1) * Ev[r + window]
+    out = out.transpose(2, 3).contiguous().view(b, d, t)
+    return conv1d(W, pre + ".conv_o", out)
+
+
+def ffn(W, pre, x, x_mask, k):
+    """FFN.forward with _same_padding (attentions.py:403-429)."""
+    pl, pr = (k - 1) // 2, k // 2
+    h = conv1d(W, pre + ".conv_1", F.pad(x * x_mask, (pl, pr)))
+    h = torch.relu(h)
+    h = conv1d(W, pre + ".conv_2", F.pad(h * x_mask, (pl, pr)))
+    return h * x_mask
+
+
+def text_encoder(W, cfg, x_ids, x_lengths):
+    """TextEncoder.forward (encoders.py:47-57) + Encoder.forward (attentions.py:70-87)."""
+    H = cfg["hidden_channels"]
+    x = F.embedding(x_ids, W["enc_p.emb.weight"]) * math.sqrt(H)
+    x = x.transpose(1, -1)
+    x_mask = sequence_mask(x_lengths, x.shape[2]).unsqueeze(1).to(x.dtype)
+    x = x * x_mask
+    attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
+    x = x * x_mask
+    for l in range(cfg["n_layers"]):
+        y = rel_attention(W, f"enc_p.encoder.attn_layers.{l}", x, attn_mask, cfg["n_heads"],
+                          cfg["window_size"])
+        x = layer_norm_c(x + y, W[f"enc_p.encoder.norm_layers_1.{l}.gamma"],
+                         W[f"enc_p.encoder.norm_layers_1.{l}.beta"])
+        y = ffn(W, f"enc_p.encoder.ffn_layers.{l}", x, x_mask, cfg["kernel_size"])
+        x = layer_norm_c(x + y, W[f"enc_p.encoder.norm_layers_2.{l}.gamma"],
+                         W[f"enc_p.encoder.norm_layers_2.{l}.beta"])
+    x = x * x_mask
+    stats = conv1d(W, "enc_p.proj", x) * x_mask
+    m, logs = torch.split(stats, cfg["inter_channels"], dim=1)
+    return x, m, logs, x_mask
+
+
+# ------------------------------------------------------------------------------------------------
+# duration predictors
+# ------------------------------------------------------------------------------------------------
+def dds_conv(W, pre, x, x_mask, g=None, n_layers=3, k=3):
+    """DDSConv.forward (duration_predictors.py:45-57)."""
+    if g is not None:
+        x = x + g
+    C = x.shape[1]
+    for i in range(n_layers):
+        dil = k ** i
+        pad = (k * dil - dil) // 2
+        y = conv1d(W, f"{pre}.convs_sep.{i}", x * x_mask, dilation=dil, padding=pad, groups=C)
+        y = layer_norm_c(y, W[f"{pre}.norms_1.{i}.gamma"], W[f"{pre}.norms_1.{i}.beta"])
+        y = F.gelu(y)
+        y = conv1d(W, f"{pre}.convs_1x1.{i}", y)
+        y = layer_norm_c(y, W[f"{pre}.norms_2.{i}.gamma"], W[f"{pre}.norms_2.{i}.beta"])
+        y = F.gelu(y)
+        x = x + y
+    return x * x_mask
+
+
+def rq_spline_inverse(x, uw, uh, ud, tail_bound=5.0, min_w=1e-3, min_h=1e-3, min_d=1e-3):
+    """unconstrained_rational_quadratic_spline(inverse=True, tails='linear') +
+    rational_quadratic_spline inverse branch (utils/transforms.py:47-97,100-187), written
+    per-element over all positions (inside-interval positions take the spline, the rest are the
+    identity) instead of boolean-mask scatter."""
+    nb = uw.shape[-1]
+    inside = (x >= -tail_bound) & (x <= tail_bound)
+    cst = float(np.log(np.exp(1 - min_d) - 1))
+    ud = F.pad(ud, (1, 1))
+    ud[..., 0] = cst
+    ud[..., -1] = cst
+
+    def cum(un, mn):
+        p = F.softmax(un, dim=-1)
+        p = mn + (1 - mn * nb) * p
+        c = torch.cumsum(p, dim=-1)
+        c = F.pad(c, (1, 0), value=0.0)
+        c = (2 * tail_bound) * c + (-tail_bound)
+        c[..., 0] = -tail_bound
+        c[..., -1] = tail_bound
+        return c, c[..., 1:] - c[..., :-1]
+
+    cw, widths = cum(uw, min_w)
+    ch, heights = cum(uh, min_h)
+    deriv = min_d + F.softplus(ud)
+    # searchsorted (transforms.py:42-44): last edge += eps, count(x >= edge) - 1
+    edges = ch.clone()
+    edges[..., -1] += 1e-6
+    xc = torch.where(inside, x, torch.zeros_like(x))
+    b = (torch.sum(xc[..., None] >= edges, dim=-1) - 1).clamp(0, nb - 1)[..., None]
+    in_cw = cw.gather(-1, b)[..., 0]
+    in_bw = widths.gather(-1, b)[..., 0]
+    in_ch = ch.gather(-1, b)[..., 0]
+    delta = heights / widths
+    in_delta = delta.gather(-1, b)[..., 0]
+    d0 = deriv.gather(-1, b)[..., 0]
+    d1 = deriv[..., 1:].gather(-1, b)[..., 0]
+    in_h = heights.gather(-1, b)[..., 0]
+    a_ = (xc - in_ch) * (d0 + d1 - 2 * in_delta) + in_h * (in_delta - d0)
+    b_ = in_h * d0 - (xc - in_ch) * (d0 + d1 - 2 * in_delta)
+    c_ = -in_delta * (xc - in_ch)
+    disc = b_.pow(2) - 4 * a_ * c_
+    assert bool((disc[inside] >= 0).all()), "transforms.py:171"
+    root = (2 * c_) / (-b_ - torch.sqrt(disc))
+    y = root * in_bw + in_cw
+    return torch.where(inside, y, x)
+
+
+def conv_flow_reverse(W, pre, z, x_mask, g, filter_channels, num_bins=10, tail_bound=5.0):
+    """ConvFlow.forward(reverse=True) (duration_predictors.py:90-122)."""
+    x0, x1 = z[:, :1], z[:, 1:]
+    h = conv1d(W, pre + ".pre", x0)
+    h = dds_conv(W, pre + ".convs", h, x_mask, g=g)
+    h = conv1d(W, pre + ".proj", h) * x_mask
+    b, c, t = x0.shape
+    h = h.reshape(b, c, -1, t).permute(0, 1, 3, 2)
+    uw = h[..., :num_bins] / math.sqrt(filter_channels)
+    uh = h[..., num_bins:2 * num_bins] / math.sqrt(filter_channels)
+    ud = h[..., 2 * num_bins:]
+    x1 = rq_spline_inverse(x1, uw, uh, ud, tail_bound=tail_bound)
+    return torch.cat([x0, x1], 1) * x_mask
+
+
+def sdp_reverse(W, cfg, x, x_mask, g, eps_w, noise_scale_w):
+    """StochasticDurationPredictor.forward(reverse=True) (duration_predictors.py:213-219,254-263).
+    eps_w replaces the torch.randn draw at :257."""
+    H = cfg["hidden_channels"]
+    x = conv1d(W, "dp.pre", x)
+    if g is not None:
+        x = x + conv1d(W, "dp.cond", g)
+    x = dds_conv(W, "dp.convs", x, x_mask)
+    x = conv1d(W, "dp.proj", x) * x_mask
+    z = eps_w * noise_scale_w
+    # reversed(flows) minus the "useless vflow": [Flip, CF_n, ..., Flip, CF_2, Flip, EA]
+    for f in range(cfg["sdp_n_flows"] - 1, 0, -1):
+        z = torch.flip(z, [1])
+        z = conv_flow_reverse(W, f"dp.flows.{2 * f + 1}", z, x_mask, x, H)
+    z = torch.flip(z, [1])
+    z = (z - W["dp.flows.0.m"]) * torch.exp(-W["dp.flows.0.logs"]) * x_mask  # :139-141
+    return z[:, :1]
+
+
+def dp_forward(W, cfg, x, x_mask, g):
+    """DurationPredictor.forward (duration_predictors.py:297-311)."""
+    if g is not None:
+        x = x + conv1d(W, "dp.cond", g)
+    x = conv1d(W, "dp.conv_1", x * x_mask, padding=1)
+    x = torch.relu(x)
+    x = layer_norm_c(x, W["dp.norm_1.gamma"], W["dp.norm_1.beta"])
+    x = conv1d(W, "dp.conv_2", x * x_mask, padding=1)
+    x = torch.relu(x)
+    x = layer_norm_c(x, W["dp.norm_2.gamma"], W["dp.norm_2.beta"])
+    x = conv1d(W, "dp.proj", x * x_mask)
+    return x * x_mask
+
+
+# ------------------------------------------------------------------------------------------------
+# length regulation  (models.py:254-267, commons.py:120-136)
+# ------------------------------------------------------------------------------------------------
+def durations_to_lengths(logw, x_mask, length_scale):
+    w = torch.exp(logw) * x_mask * length_scale
+    w_ceil = torch.ceil(w)
+    y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+    return w_ceil, y_lengths
+
+
+def generate_path(w_ceil, x_mask, y_mask):
+    """commons.generate_path (commons.py:120-136) as an index search: frame ty belongs to the first
+    phoneme whose cumulative duration exceeds ty.  Returns attn [B,1,Ty,Tx] and the index map."""
+    b, _, tx = w_ceil.shape
+    ty = y_mask.shape[-1]
+    cum = torch.cumsum(w_ceil[:, 0], -1)  # [b,tx]
+    frames = torch.arange(ty, dtype=cum.dtype).view(1, ty, 1)
+    below = (cum.unsqueeze(1) > frames)  # [b,ty,tx]
+    first = below.to(torch.int64).argmax(-1)
+    has = below.any(-1)
+    f2p = torch.where(has & (y_mask[:, 0] > 0), first, torch.full_like(first, -1))
+    attn = torch.zeros(b, ty, tx)
+    bi, ti = torch.nonzero(f2p >= 0, as_tuple=True)
+    attn[bi, ti, f2p[bi, ti]] = 1.0
+    attn = attn * x_mask[:, 0].unsqueeze(1) * y_mask[:, 0].unsqueeze(2)
+    return attn.unsqueeze(1), f2p
+
+
+# ------------------------------------------------------------------------------------------------
+# flow^-1  (model/flows.py:442-449,494-513; model/modules.py:60-106; commons.py:98-105)
+# ------------------------------------------------------------------------------------------------
+def wn(W, pre, x, x_mask, g, hidden, n_layers, k):
+    """WN.forward (modules.py:60-87) with dilation_rate 1."""
+    out = torch.zeros_like(x)
+    gc = conv1d(W, pre + ".cond_layer", g) if g is not None else None
+    for i in range(n_layers):
+        x_in = conv1d(W, f"{pre}.in_layers.{i}", x, padding=(k - 1) // 2)
+        if gc is not None:
+            x_in = x_in + gc[:, i * 2 * hidden:(i + 1) * 2 * hidden]
+        acts = torch.tanh(x_in[:, :hidden]) * torch.sigmoid(x_in[:, hidden:])
+        rs = conv1d(W, f"{pre}.res_skip_layers.{i}", acts)
+        if i < n_layers - 1:
+            x = (x + rs[:, :hidden]) * x_mask
+            out = out + rs[:, hidden:]
+        else:
+            out = out + rs
+    return out * x_mask
+
+
+def flow_reverse(W, cfg, z_p, y_mask, g):
+    """ResidualCouplingTransformersBlock.forward(reverse=True): reversed [(RCL, Flip) x n]
+    (flows.py:442-449); RCL reverse with mean_only (flows.py:494-513)."""
+    H, I = cfg["hidden_channels"], cfg["inter_channels"]
+    half = I // 2
+    x = z_p
+    for f in range(cfg["flow_n_flows"] - 1, -1, -1):
+        x = torch.flip(x, [1])
+        pre = f"flow.flows.{2 * f}"
+        x0, x1 = x[:, :half], x[:, half:]
+        h = conv1d(W, pre + ".pre", x0) * y_mask
+        h = wn(W, pre + ".enc", h, y_mask, g, H, cfg["flow_wn_layers"], cfg["flow_kernel_size"])
+        m = conv1d(W, pre + ".post", h) * y_mask
+        x1 = (x1 - m) * y_mask
+        x = torch.cat([x0, x1], 1)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# HiFi-GAN generator  (model/decoders.py:63-82,157-170,205-214)
+# ------------------------------------------------------------------------------------------------
+def hifigan(W, cfg, z, g):
+    x = conv1d(W, "dec.conv_pre", z, padding=3)
+    if g is not None:
+        x = x + conv1d(W, "dec.cond", g)
+    nk = len(cfg["resblock_kernel_sizes"])
+    for i, (u, uk) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
+        x = F.leaky_relu(x, LRELU_SLOPE)
+        x = F.conv_transpose1d(x, W[f"dec.ups.{i}.weight"], W[f"dec.ups.{i}.bias"], stride=u,
+                               padding=(uk - u) // 2)
+        xs = None
+        for j, (k, dils) in enumerate(zip(cfg["resblock_kernel_sizes"],
+                                          cfg["resblock_dilation_sizes"])):
+            n = i * nk + j
+            r = x
+            if cfg["resblock"] == 1:
+                for d, dil in enumerate(dils[:3]):
+                    t = F.leaky_relu(r, LRELU_SLOPE)
+                    t = conv1d(W, f"dec.resblocks.{n}.convs1.{d}", t, dilation=dil,
+                               padding=(k * dil - dil) // 2)
+                    t = F.leaky_relu(t, LRELU_SLOPE)
+                    t = conv1d(W, f"dec.resblocks.{n}.convs2.{d}", t, padding=(k - 1) // 2)
+                    r = t + r
+            else:
+                for d, dil in enumerate(dils[:2]):
+                    t = F.leaky_relu(r, LRELU_SLOPE)
+                    t = conv1d(W, f"dec.resblocks.{n}.convs.{d}", t, dilation=dil,
+                               padding=(k * dil - dil) // 2)
+                    r = t + r
+            xs = r if xs is None else xs + r
+        x = xs / nk
+    x = F.leaky_relu(x)  # default slope 0.01 (decoders.py:78)
+    x = F.conv1d(x, W["dec.conv_post.weight"], None, padding=3)
+    return torch.tanh(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# infer  (model/models.py:228-280)
+# ------------------------------------------------------------------------------------------------
+def infer(W, cfg, x_ids, x_lengths, sid=None, noise_scale=1.0, length_scale=1.0,
+          noise_scale_w=1.0, max_len=None, eps_w=None, eps_z=None, return_stages=False):
+    """eps_w [B,2,Tx] / eps_z [B,inter,Ty] replace the two torch.randn draws
+    (duration_predictors.py:257, models.py:267); when None they are drawn here in the reference's
+    order from the global CPU generator."""
+    with torch.no_grad():
+        g = None
+        if cfg["n_speakers"] > 0:
+            g = F.embedding(sid, W["emb_g.weight"]).unsqueeze(-1)
+        x, m_p, logs_p, x_mask = text_encoder(W, cfg, x_ids, x_lengths)
+        if cfg["use_sdp"]:
+            if eps_w is None:
+                eps_w = torch.randn(x.size(0), 2, x.size(2))
+            logw = sdp_reverse(W, cfg, x, x_mask, g, eps_w, noise_scale_w)
+        else:
+            logw = dp_forward(W, cfg, x, x_mask, g)
+        w_ceil, y_lengths = durations_to_lengths(logw, x_mask, length_scale)
+        y_mask = sequence_mask(y_lengths, None).unsqueeze(1).to(x_mask.dtype)
+        attn, f2p = generate_path(w_ceil, x_mask, y_mask)
+        m_e = torch.matmul(attn.squeeze(1), m_p.transpose(1, 2)).transpose(1, 2)
+        logs_e = torch.matmul(attn.squeeze(1), logs_p.transpose(1, 2)).transpose(1, 2)
+        if eps_z is None:
+            eps_z = torch.randn_like(m_e)
+        z_p = m_e + eps_z * torch.exp(logs_e) * noise_scale
+        z = flow_reverse(W, cfg, z_p, y_mask, g)
+        o = hifigan(W, cfg, (z * y_mask)[:, :, :max_len], g)
+    if return_stages:
+        return dict(x=x, m_p=m_p, logs_p=logs_p, x_mask=x_mask, logw=logw, w_ceil=w_ceil,
+                    y_lengths=y_lengths, y_mask=y_mask, attn=attn, f2p=f2p, m_p_exp=m_e,
+                    logs_p_exp=logs_e, z_p=z_p, z=z, o=o, g=g)
+    return o, attn, y_mask, (z, z_p, m_e, logs_e)
+
+
+def audio_to_int16(audio):
+    """inference.py:100-110 output scaling (float32 arithmetic, numpy >= 2 scalar rules)."""
+    a = np.asarray(audio, dtype=np.float32).copy()
+    a *= np.float32(32767.0) / max(np.float32(0.01), np.max(np.abs(a))) * np.float32(0.6)
+    return np.clip(a, -32767.0, 32767.0).astype(np.int16)
+
+
+# ------------------------------------------------------------------------------------------------
+# MAS  (utils/monotonic_align.py:22-57), numpy restatement; the C twin is oracle/mas_oracle.c
+# ------------------------------------------------------------------------------------------------
+def maximum_path_numpy(neg_cent, t_ys, t_xs):
+    values = np.array(neg_cent, dtype=np.float32, copy=True)
+    paths = np.zeros(values.shape, dtype=np.int32)
+    neg = np.float32(-1e9)
+    for i in range(values.shape[0]):
+        value, path = values[i], paths[i]
+        t_y, t_x = int(t_ys[i]), int(t_xs[i])
+        index = t_x - 1
+        for y in range(t_y):
+            lo, hi = max(0, t_x + y - t_y), min(t_x, y + 1)
+            if hi <= lo:
+                continue
+            xs = np.arange(lo, hi)
+            if y == 0:
+                v_cur = np.full(xs.shape, neg, np.float32)
+                v_prev = np.where(xs == 0, np.float32(0.0), neg).astype(np.float32)
+            else:
+                prev = value[y - 1]
+                v_cur = np.where(xs == y, neg, prev[xs]).astype(np.float32)
+                v_prev = np.where(xs == 0, neg, prev[np.maximum(xs - 1, 0)]).astype(np.float32)
+            value[y, lo:hi] = value[y, lo:hi] + np.maximum(v_prev, v_cur)
+        for y in range(t_y - 1, -1, -1):
+            path[y, index] = 1
+            if index != 0 and (index == y or value[y - 1, index] < value[y - 1, index - 1]):
+                index -= 1
+    return paths

@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors by running the REAL reference (wenet-e2e/wetts,
+/root/reference, imported unmodified through oracle/ref_import.py) on seeded synthetic
+checkpoints.  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+Fixtures (tests/golden/*.npz) hold inputs, injected noise and the reference's outputs at every
+stage boundary of SynthesizerTrn.infer(); weights are NOT stored -- they are regenerated from
+(config name, seed) by wetts_amd.synth.make_state_dict, and a checksum of the packed blob is
+stored so RNG drift is detected instead of silently mis-pinning.
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import  # noqa: E402
+from wetts_amd import checkpoint, config, synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# name -> (model config, n_vocab, n_speakers, B, Tx, lengths, weight seed, noise seed, scales)
+CASES = {
+    "tiny_sdp_b3": ("tiny", 40, 3, 3, 12, [12, 7, 9], 11, 101, (0.667, 1.0, 0.8)),
+    "tiny_dp_b2": ("tiny_dp", 40, 2, 2, 10, [10, 6], 12, 102, (0.667, 1.1, 0.8)),
+    "tiny_sdp_nonoise": ("tiny", 40, 3, 2, 9, [9, 4], 13, 103, (0.0, 1.0, 0.0)),
+    "tiny_sdp_single": ("tiny", 40, 1, 1, 1, [1], 14, 104, (0.667, 1.0, 0.8)),
+    "v1_b2": ("v1", 64, 1, 2, 8, [8, 5], 21, 201, (0.667, 1.0, 0.8)),
+    "v3_b2": ("v3", 64, 2, 2, 8, [8, 6], 22, 202, (0.667, 1.0, 0.8)),
+}
+
+
+def build_reference(model_name, n_vocab, n_speakers, sd):
+    SynthesizerTrn, _, _, _ = ref_import.import_reference()
+    model = dict(config.MODEL_CONFIGS[model_name])
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = SynthesizerTrn(n_vocab, 513, 32, n_speakers=n_speakers, **model).eval()
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    # everything the synthetic checkpoint does not carry must be outside the infer() path
+    bad = [k for k in missing if not (k.startswith("enc_q.") or k.startswith("dp.post_")
+                                      or k.startswith("dp.flows.1."))]
+    assert not bad, bad
+    return net
+
+
+def run_reference(net, x, x_len, sid, scales, noise_seed):
+    """Reference infer() with its two torch.randn draws reproduced from `noise_seed`."""
+    ns, ls, nsw = scales
+    torch.manual_seed(noise_seed)
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        o, attn, y_mask, (z, z_p, m_p, logs_p) = net.infer(
+            x, x_len, sid=sid, noise_scale=ns, length_scale=ls, noise_scale_w=nsw)
+    return o, attn, y_mask, z, z_p, m_p, logs_p
+
+
+def stage_probe(net, x, x_len, sid, scales, noise_seed):
+    """Re-runs the reference's sub-modules to capture stage boundaries infer() does not return."""
+    ns, ls, nsw = scales
+    torch.manual_seed(noise_seed)
+    with torch.no_grad():
+        g = net.emb_g(sid).unsqueeze(-1) if net.n_speakers > 0 else None
+        xe, m_p, logs_p, x_mask = net.enc_p(x, x_len, g=g)
+        if net.use_sdp:
+            logw = net.dp(xe, x_mask, g=g, reverse=True, noise_scale=nsw)
+        else:
+            logw = net.dp(xe, x_mask, g=g)
+    return xe, m_p, logs_p, x_mask, logw
+
+
+def main():
+    if not ref_import.available():
+        raise SystemExit("reference not present; golden vectors can only be generated in the "
+                         "build container")
+    torch.set_num_threads(1)
+    for name, (mname, n_vocab, n_spk, B, Tx, lens, wseed, nseed, scales) in CASES.items():
+        cfg = config.make_config(config.MODEL_CONFIGS[mname], n_vocab, n_spk)
+        sd = synth.make_state_dict(cfg, wseed)
+        blob = checkpoint.pack_blob(cfg, sd)
+        net = build_reference(mname, n_vocab, n_spk, sd)
+        gi = torch.Generator().manual_seed(nseed + 7)
+        x = torch.randint(0, n_vocab, (B, Tx), generator=gi)
+        x_len = torch.tensor(lens, dtype=torch.long)
+        sid = torch.randint(0, n_spk, (B,), generator=gi)
+        # the noise the reference will draw: randn(B,2,Tx) then randn_like(m_p) [B,192,Ty]
+        torch.manual_seed(nseed)
+        eps_w = torch.randn(B, 2, Tx) if cfg.use_sdp else torch.zeros(B, 2, Tx)
+        o, attn, y_mask, z, z_p, m_pe, logs_pe = run_reference(net, x, x_len, sid, scales, nseed)
+        Ty = z.shape[2]
+        torch.manual_seed(nseed)
+        if cfg.use_sdp:
+            torch.randn(B, 2, Tx)
+        # randn_like(m_p): m_p is a transposed VIEW of a [B,Ty,C] matmul result (models.py:262-267)
+        # and torch's CPU normal_ consumes the generator differently for strided tensors, so the
+        # draw must be reproduced on a tensor with the same strides.
+        eps_z = torch.randn_like(torch.empty(B, Ty, cfg.inter_channels).transpose(1, 2)).contiguous()
+        xe, m_p, logs_p, x_mask, logw = stage_probe(net, x, x_len, sid, scales, nseed)
+        # margin of ceil(): distance of w to the nearest integer from below
+        w = torch.exp(logw) * x_mask * scales[1]
+        frac = (torch.ceil(w) - w)[x_mask > 0]
+        margin = float(torch.minimum(frac, 1 - frac).min()) if frac.numel() else 1.0
+        # folded weight-norm check against the reference's own remove_weight_norm
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"),
+            model=mname, n_vocab=n_vocab, n_speakers=n_spk, weight_seed=wseed, noise_seed=nseed,
+            scales=np.array(scales, np.float64), blob_checksum=synth.blob_checksum(blob),
+            x=x.numpy(), x_lengths=x_len.numpy(), sid=sid.numpy(),
+            eps_w=eps_w.numpy(), eps_z=eps_z.numpy(),
+            x_enc=xe.numpy(), m_p=m_p.numpy(), logs_p=logs_p.numpy(), x_mask=x_mask.numpy(),
+            logw=logw.numpy(), ceil_margin=margin,
+            attn=attn.numpy().astype(np.uint8), y_mask=y_mask.numpy(), z=z.numpy(),
+            z_p=z_p.numpy(), m_p_exp=m_pe.numpy(), logs_p_exp=logs_pe.numpy(),
+            audio=o.numpy())
+        rms = float(o.pow(2).mean().sqrt())
+        print(f"{name}: Ty={Ty} audio={tuple(o.shape)} rms={rms:.4f} ceil_margin={margin:.2e} "
+              f"frames/phone={float(y_mask.sum() / x_mask.sum()):.2f}")
+
+    # MAS known-answer vectors from the reference's maximum_path (numba stub => plain Python)
+    _, _, _, mas = ref_import.import_reference()
+    g = torch.Generator().manual_seed(5)
+    cases = []
+    for (b, ty, tx) in [(3, 9, 5), (2, 16, 16), (4, 23, 7), (1, 1, 1), (2, 12, 1)]:
+        neg = torch.randn(b, ty, tx, generator=g)
+        t_y = torch.randint(max(1, ty // 2), ty + 1, (b,), generator=g)
+        t_x = torch.minimum(torch.randint(1, tx + 1, (b,), generator=g), t_y)
+        mask = (torch.arange(ty).view(1, ty, 1) < t_y.view(b, 1, 1)) & \
+               (torch.arange(tx).view(1, 1, tx) < t_x.view(b, 1, 1))
+        path = mas.maximum_path(neg, mask.float())
+        cases.append((neg.numpy(), t_y.numpy().astype(np.int32), t_x.numpy().astype(np.int32),
+                      path.numpy().astype(np.int8)))
+    # tie case: constant scores exercise the strict `<` in the backtrack
+    neg = torch.zeros(1, 6, 3)
+    mask = torch.ones(1, 6, 3)
+    cases.append((neg.numpy(), np.array([6], np.int32), np.array([3], np.int32),
+                  mas.maximum_path(neg, mask).numpy().astype(np.int8)))
+    np.savez_compressed(os.path.join(OUT, "mas_kat.npz"), n=len(cases),
+                        **{f"neg{i}": c[0] for i, c in enumerate(cases)},
+                        **{f"ty{i}": c[1] for i, c in enumerate(cases)},
+                        **{f"tx{i}": c[2] for i, c in enumerate(cases)},
+                        **{f"path{i}": c[3] for i, c in enumerate(cases)})
+    print("mas_kat:", len(cases), "cases")
+
+    # generate_path edge cases (commons.py:120-136), incl. zero durations and single phoneme
+    _, _, commons, _ = ref_import.import_reference()
+    durs = [[2, 0, 3, 1], [0, 0, 0, 0], [1, 1, 1, 1], [5, 0, 0, 0]]
+    d = torch.tensor(durs, dtype=torch.float32).unsqueeze(1)
+    ylen = torch.clamp_min(d.sum([1, 2]), 1).long()
+    y_mask = commons.sequence_mask(ylen, None).unsqueeze(1).float()
+    x_mask = torch.ones(4, 1, 4)
+    attn = commons.generate_path(d, x_mask.unsqueeze(2) * y_mask.unsqueeze(-1))
+    np.savez_compressed(os.path.join(OUT, "generate_path_kat.npz"), durations=d.numpy(),
+                        y_lengths=ylen.numpy(), attn=attn.numpy())
+    print("generate_path_kat: ok")
+
+
+if __name__ == "__main__":
+    main()

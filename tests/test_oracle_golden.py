@@ -1,0 +1,67 @@
+"""Pins oracle/vits_oracle.py against the golden vectors the REAL reference produced
+(tests/golden/make_golden.py) -- CPU tier.  Tolerances are float32 round-off: both sides run the
+same ATen CPU kernels, only the relative-attention / generate_path / spline formulations differ."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vits_oracle as vo
+from tests import util
+
+
+@pytest.mark.parametrize("name", util.INFER_CASES)
+def test_infer_matches_reference(name):
+    case = util.load_case(name)
+    cfg, _, W, _ = util.case_model(case)
+    cd = util.cfg_dict(cfg)
+    ns, ls, nsw = [float(v) for v in case["scales"]]
+    st = vo.infer(W, cd, util.t(case["x"]), util.t(case["x_lengths"]), util.t(case["sid"]),
+                  noise_scale=ns, length_scale=ls, noise_scale_w=nsw,
+                  eps_w=util.t(case["eps_w"]), eps_z=util.t(case["eps_z"]), return_stages=True)
+    assert util.rel_rms(st["x"].numpy(), case["x_enc"]) < 2e-5
+    assert util.rel_rms(st["m_p"].numpy(), case["m_p"]) < 2e-5
+    assert np.abs(st["logw"].numpy() - case["logw"]).max() < 2e-4
+    assert np.array_equal(st["y_mask"].numpy(), case["y_mask"])
+    assert np.array_equal(st["attn"].numpy().astype(np.uint8), case["attn"])
+    assert util.rel_rms(st["z_p"].numpy(), case["z_p"]) < 2e-5
+    assert util.rel_rms(st["z"].numpy(), case["z"]) < 5e-5
+    # the north-star gate is 1e-3 absolute RMS; the oracle sits ~100x inside it
+    assert util.rms(st["o"].numpy() - case["audio"]) < 2e-5
+    assert util.rel_rms(st["o"].numpy(), case["audio"]) < 2e-4
+
+
+def test_mas_known_answers():
+    d = np.load(util.GOLDEN + "/mas_kat.npz")
+    for i in range(int(d["n"])):
+        p = vo.maximum_path_numpy(d[f"neg{i}"], d[f"ty{i}"], d[f"tx{i}"])
+        assert np.array_equal(p.astype(np.int8), d[f"path{i}"]), f"case {i}"
+        # exactly one 1 per valid frame row, monotone non-decreasing column
+        for b in range(p.shape[0]):
+            ty = int(d[f"ty{i}"][b])
+            assert (p[b, :ty].sum(1) == 1).all() and p[b, ty:].sum() == 0
+            cols = p[b, :ty].argmax(1)
+            assert (np.diff(cols) >= 0).all() and (np.diff(cols) <= 1).all()
+
+
+def test_generate_path_known_answers():
+    d = np.load(util.GOLDEN + "/generate_path_kat.npz")
+    dur = torch.from_numpy(d["durations"])
+    ylen = torch.from_numpy(d["y_lengths"])
+    y_mask = vo.sequence_mask(ylen, None).unsqueeze(1).float()
+    x_mask = torch.ones(dur.shape[0], 1, dur.shape[2])
+    attn, f2p = vo.generate_path(dur, x_mask, y_mask)
+    assert np.array_equal(attn.numpy(), d["attn"])
+    # SURVEY §8 a11 example: durations [2,0,3,1] -> rows 110000 / 000000 / 001110 / 000001
+    assert attn[0, 0, :, 0].tolist() == [1, 1, 0, 0, 0, 0]
+    assert attn[0, 0, :, 2].tolist() == [0, 0, 1, 1, 1, 0]
+    assert f2p[1, 0].item() == -1  # all-zero durations: y_length clamps to 1, no phoneme
+
+
+def test_audio_to_int16_matches_cli_formula():
+    rng = np.random.default_rng(0)
+    a = (rng.standard_normal(1000) * 0.1).astype(np.float32)
+    ref = a.copy()
+    ref *= 32767 / max(0.01, np.max(np.abs(ref))) * 0.6  # inference.py:101
+    ref = np.clip(ref, -32767.0, 32767.0).astype(np.int16)
+    got = vo.audio_to_int16(a)
+    assert np.abs(got.astype(np.int32) - ref.astype(np.int32)).max() <= 1

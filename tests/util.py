@@ -1,0 +1,61 @@
+"""Shared helpers for the test-suite (test infrastructure; may import oracle/)."""
+import os
+
+import numpy as np
+import torch
+
+from wetts_amd import checkpoint, config, synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+INFER_CASES = ["tiny_sdp_b3", "tiny_dp_b2", "tiny_sdp_nonoise", "tiny_sdp_single", "v1_b2", "v3_b2"]
+
+
+def load_case(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: d[k] for k in d.files}
+
+
+def case_model(case):
+    """(cfg struct, reference-keyed state_dict, folded weights dict, blob) of a golden case."""
+    mname = str(case["model"])
+    cfg = config.make_config(config.MODEL_CONFIGS[mname], int(case["n_vocab"]),
+                             int(case["n_speakers"]))
+    sd = synth.make_state_dict(cfg, int(case["weight_seed"]))
+    blob = checkpoint.pack_blob(cfg, sd)
+    assert abs(synth.blob_checksum(blob) - float(case["blob_checksum"])) <= \
+        1e-6 * max(1.0, abs(float(case["blob_checksum"]))), \
+        "synthetic weights differ from the ones the golden vectors were generated with"
+    W = checkpoint.fold_weight_norm(sd)
+    return cfg, sd, W, blob
+
+
+def cfg_dict(cfg):
+    """Plain-dict view of wetts_config_t in the shape oracle/vits_oracle.py expects."""
+    nk, nd = cfg.n_resblock_kernels, cfg.n_resblock_dilations
+    return dict(
+        hidden_channels=cfg.hidden_channels, inter_channels=cfg.inter_channels,
+        n_heads=cfg.n_heads, n_layers=cfg.n_layers, kernel_size=cfg.kernel_size,
+        window_size=cfg.window_size, n_speakers=cfg.n_speakers, use_sdp=bool(cfg.use_sdp),
+        sdp_n_flows=cfg.sdp_n_flows, flow_n_flows=cfg.flow_n_flows,
+        flow_wn_layers=cfg.flow_wn_layers, flow_kernel_size=cfg.flow_kernel_size,
+        resblock=cfg.resblock,
+        resblock_kernel_sizes=[cfg.resblock_kernel_sizes[j] for j in range(nk)],
+        resblock_dilation_sizes=[[cfg.resblock_dilation_sizes[j][i] for i in range(nd)]
+                                 for j in range(nk)],
+        upsample_rates=[cfg.upsample_rates[i] for i in range(cfg.n_upsamples)],
+        upsample_kernel_sizes=[cfg.upsample_kernel_sizes[i] for i in range(cfg.n_upsamples)],
+    )
+
+
+def rms(a):
+    a = np.asarray(a, dtype=np.float64)
+    return float(np.sqrt(np.mean(a * a))) if a.size else 0.0
+
+
+def rel_rms(a, ref):
+    return rms(np.asarray(a, np.float64) - np.asarray(ref, np.float64)) / max(rms(ref), 1e-30)
+
+
+def t(a, dtype=None):
+    x = torch.from_numpy(np.ascontiguousarray(a))
+    return x.to(dtype) if dtype is not None else x

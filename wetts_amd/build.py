@@ -1,0 +1,71 @@
+"""Builds libwetts_hip.so (gfx950) in-tree with hipcc.  No torch, no JIT cache: the .so lands in
+wetts_amd/lib/ so it travels with the repo snapshot to the GPU box."""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libwetts_hip.so")
+SOURCES = ["conv_mfma.hip", "kernels.hip", "attention.hip", "mas.hip", "model.hip"]
+HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "wetts_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "build.sha256")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp):
+        if open(stamp).read().strip() == dig:
+            return LIB
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[wetts_amd.build]", " ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if out and verbose:
+            sys.stdout.write(out.decode(errors="replace"))
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(out.decode(errors="replace") if not verbose else "")
+    if failed:
+        raise RuntimeError("hipcc failed")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print("[wetts_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,167 @@
+"""Config handling for the MI355X VITS path.
+
+Mirrors the reference's JSON -> recursive HParams loader (wetts/vits/utils/task.py:250-303) so
+`hps.data.sampling_rate`, `**hps.model` etc. read the same, and converts the `model` section into
+the C-ABI `wetts_config_t` (include/wetts_hip.h).
+"""
+import json
+
+from . import _lib
+
+
+class HParams:
+    """Attribute/dict hybrid, same surface as the reference HParams (task.py:273-303)."""
+
+    def __init__(self, **kwargs):
+        for k, v in kwargs.items():
+            self[k] = HParams(**v) if isinstance(v, dict) else v
+
+    def keys(self):
+        return self.__dict__.keys()
+
+    def items(self):
+        return self.__dict__.items()
+
+    def values(self):
+        return self.__dict__.values()
+
+    def get(self, key, default=None):
+        return self.__dict__.get(key, default)
+
+    def __len__(self):
+        return len(self.__dict__)
+
+    def __getitem__(self, key):
+        return getattr(self, key)
+
+    def __setitem__(self, key, value):
+        setattr(self, key, value)
+
+    def __contains__(self, key):
+        return key in self.__dict__
+
+    def __repr__(self):
+        return self.__dict__.__repr__()
+
+
+def get_hparams_from_file(config_path):
+    """task.get_hparams_from_file (task.py:250-255)."""
+    with open(config_path, "r") as f:
+        return HParams(**json.load(f))
+
+
+# Shapes of the checked-in reference recipes (examples/*/configs/{v1,v2,v3}.json "model" sections),
+# restated here so tests / bench need no file from /root/reference.
+_COMMON = dict(inter_channels=192, hidden_channels=192, filter_channels=768, n_heads=2, n_layers=6,
+               kernel_size=3, p_dropout=0.1, gin_channels=256)
+MODEL_CONFIGS = {
+    # examples/baker/configs/v1.json:29-43 (also aishell-3 / ljspeech / multilingual v1)
+    "v1": dict(_COMMON, resblock="1", upsample_rates=[8, 8, 2, 2],
+               upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=512,
+               resblock_kernel_sizes=[3, 7, 11],
+               resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]]),
+    # examples/baker/configs/v2.json:38-43
+    "v2": dict(_COMMON, resblock="1", upsample_rates=[8, 8, 2, 2],
+               upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=128,
+               resblock_kernel_sizes=[3, 7, 11],
+               resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]]),
+    # examples/multilingual/configs/v3.json:38-45
+    "v3": dict(_COMMON, resblock="2", upsample_rates=[8, 8, 4], upsample_kernel_sizes=[16, 16, 8],
+               upsample_initial_channel=256, resblock_kernel_sizes=[3, 5, 7],
+               resblock_dilation_sizes=[[1, 2], [2, 6], [3, 12]], use_sdp=False),
+    # BASELINE.json configs[4]: builder-defined 48 kHz stress shape (not a reference recipe)
+    "stress48k": dict(_COMMON, resblock="1", upsample_rates=[8, 8, 4, 2],
+                      upsample_kernel_sizes=[16, 16, 8, 4], upsample_initial_channel=512,
+                      resblock_kernel_sizes=[3, 7, 11],
+                      resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]]),
+    # small shapes for fast CPU-oracle parity (same topology, narrower / shallower)
+    "tiny": dict(inter_channels=192, hidden_channels=192, filter_channels=256, n_heads=2,
+                 n_layers=2, kernel_size=3, p_dropout=0.1, gin_channels=64, resblock="1",
+                 upsample_rates=[4, 2], upsample_kernel_sizes=[8, 4], upsample_initial_channel=64,
+                 resblock_kernel_sizes=[3, 7], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5]]),
+    "tiny_dp": dict(inter_channels=192, hidden_channels=192, filter_channels=256, n_heads=2,
+                    n_layers=2, kernel_size=3, p_dropout=0.1, gin_channels=64, resblock="2",
+                    upsample_rates=[4, 4], upsample_kernel_sizes=[8, 8],
+                    upsample_initial_channel=96, resblock_kernel_sizes=[3, 5],
+                    resblock_dilation_sizes=[[1, 2], [2, 6]], use_sdp=False),
+}
+SAMPLING_RATES = {"v1": 22050, "v2": 22050, "v3": 16000, "stress48k": 48000, "tiny": 22050,
+                  "tiny_dp": 16000}
+
+
+def _get(model, key, default=None):
+    if isinstance(model, dict):
+        return model.get(key, default)
+    return model[key] if key in model else default
+
+
+_UNSUPPORTED = {
+    "use_transformer_flows": "VITS2 transformer flows (flows.py:16-324) are SURVEY §8(f) 'next'",
+    "use_spk_conditioned_encoder": "speaker-conditioned encoder (attentions.py:39-48) is 'next'",
+}
+
+
+def make_config(model, n_vocab, n_speakers):
+    """`hps.model` (dict or HParams) + vocabulary / speaker counts -> wetts_config_t.
+
+    Argument meaning follows SynthesizerTrn.__init__ (models.py:19-51); unknown keys are ignored
+    exactly like the reference's **kwargs; options that switch to code paths outside the scoped hot
+    path raise instead of silently computing something else.
+    """
+    for k, why in _UNSUPPORTED.items():
+        if _get(model, k, False):
+            raise NotImplementedError(f"model.{k}=true is not supported: {why}")
+    if _get(model, "vocoder_type", "hifigan") != "hifigan":
+        raise NotImplementedError("only vocoder_type='hifigan' (decoders.py:15-88) is in scope")
+    c = _lib.Config()
+    c.n_vocab = int(n_vocab)
+    c.inter_channels = int(_get(model, "inter_channels"))
+    c.hidden_channels = int(_get(model, "hidden_channels"))
+    c.filter_channels = int(_get(model, "filter_channels"))
+    c.n_heads = int(_get(model, "n_heads"))
+    c.n_layers = int(_get(model, "n_layers"))
+    c.kernel_size = int(_get(model, "kernel_size"))
+    c.window_size = 4  # attentions.Encoder default window_size (attentions.py:20)
+    c.resblock = 1 if str(_get(model, "resblock")) == "1" else 2
+    ks = list(_get(model, "resblock_kernel_sizes"))
+    ds = [list(d) for d in _get(model, "resblock_dilation_sizes")]
+    if len(ks) != len(ds) or len(ks) > _lib.MAX_RB_KERNELS:
+        raise ValueError("bad resblock_kernel_sizes / resblock_dilation_sizes")
+    # ResBlock1 uses dilation[0..2], ResBlock2 dilation[0..1] (decoders.py:91-218)
+    nd = 3 if c.resblock == 1 else 2
+    c.n_resblock_kernels = len(ks)
+    c.n_resblock_dilations = nd
+    for j, (k, d) in enumerate(zip(ks, ds)):
+        if len(d) < nd:
+            raise ValueError(f"resblock {j}: need {nd} dilations, got {d}")
+        c.resblock_kernel_sizes[j] = int(k)
+        for i in range(nd):
+            c.resblock_dilation_sizes[j][i] = int(d[i])
+    ur = list(_get(model, "upsample_rates"))
+    uk = list(_get(model, "upsample_kernel_sizes"))
+    if len(ur) != len(uk) or len(ur) > _lib.MAX_STAGES:
+        raise ValueError("bad upsample_rates / upsample_kernel_sizes")
+    c.n_upsamples = len(ur)
+    for i, (u, k) in enumerate(zip(ur, uk)):
+        c.upsample_rates[i] = int(u)
+        c.upsample_kernel_sizes[i] = int(k)
+    c.upsample_initial_channel = int(_get(model, "upsample_initial_channel"))
+    c.n_speakers = int(n_speakers)
+    c.gin_channels = int(_get(model, "gin_channels", 0))
+    c.use_sdp = 1 if _get(model, "use_sdp", True) else 0
+    c.flow_n_flows = 4       # models.py:133-142 ResidualCouplingTransformersBlock(.., 5, 1, 4)
+    c.flow_wn_layers = 4
+    c.flow_kernel_size = 5
+    c.sdp_n_flows = 4        # models.py:145-150
+    c.dp_filter_channels = 256  # models.py:152-156
+    return c
+
+
+def config_to_dict(c):
+    out = {}
+    for name, _ in c._fields_:
+        v = getattr(c, name)
+        if hasattr(v, "__len__"):
+            v = [list(x) if hasattr(x, "__len__") else x for x in v]
+        out[name] = v
+    return out

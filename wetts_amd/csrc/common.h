@@ -1,0 +1,120 @@
+// Internal shared declarations for libwetts_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/wetts_hip.h"
+
+namespace wetts {
+
+void set_error(const char* fmt, ...);
+
+#define WETTS_HIP_CHECK(expr)                                                        \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      ::wetts::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                         __FILE__, __LINE__);                                        \
+      return WETTS_E_HIP;                                                            \
+    }                                                                                \
+  } while (0)
+
+#define WETTS_LAUNCH_CHECK()                                                         \
+  do {                                                                               \
+    hipError_t _e = hipGetLastError();                                               \
+    if (_e != hipSuccess) {                                                          \
+      ::wetts::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),  \
+                         __FILE__, __LINE__);                                        \
+      return WETTS_E_HIP;                                                            \
+    }                                                                                \
+  } while (0)
+
+#define WETTS_REQUIRE(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::wetts::set_error(__VA_ARGS__);  \
+      return WETTS_E_INVALID;           \
+    }                                   \
+  } while (0)
+
+#define WETTS_TRY(expr)          \
+  do {                           \
+    int32_t _r = (expr);         \
+    if (_r != WETTS_OK) return _r; \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
+// Implicit-GEMM Conv1d / ConvTranspose1d on the f32 matrix cores (v_mfma_f32_32x32x2_f32).
+// GEMM view (per batch item):  D[M x N] = A[M x K] * B[K x N]
+//   rows  M : output channels (Conv1d) or (co, phase) pairs (ConvTranspose1d, polyphase)
+//   cols  N : output time (Conv1d) or input time q (ConvTranspose1d)
+//   K       : (ci, tap);  B[(ci,tap)][n] = act(x[ci][n + tap*dil - pad]) (0 outside [0,Tin))
+// ---------------------------------------------------------------------------------------
+constexpr int kConvCK = 16;  // input channels staged per LDS chunk (fixed by the packed layout)
+
+enum InAct { IN_NONE = 0, IN_LRELU = 1 };
+enum OutAct { OUT_NONE = 0, OUT_RELU = 1 };
+
+struct ConvParams {
+  // input
+  const float* x;
+  int64_t x_bs, x_cs;  // batch / channel strides (floats); time stride is 1
+  int Cin, Tin;
+  int in_rev_base;       // >=0: physical channel = in_rev_base - ci (Flip folded into indexing)
+  int in_act;            // InAct
+  float in_slope;
+  const float* in_mask;  // [B][>=Tin] multiply after activation, or null
+  int64_t in_mask_stride;
+  // weights (packed by pack_conv_weight) + biases
+  const float* wpk;
+  const float* bias;     // [Cout] or null
+  const float* bias_b;   // [B][bias_b_stride] per-utterance bias (speaker conditioning) or null
+  int64_t bias_b_stride;
+  // GEMM geometry
+  int M, N;
+  int ktaps, dil, pad;   // x index = n + tap*dil - pad
+  int off_lo, span;      // min tap offset, max-min tap offset (host precomputed)
+  int nchunks;           // ceil(Cin / kConvCK)
+  // output
+  float* out;
+  int64_t o_bs, o_cs;
+  int Tout;
+  int up, up_pad;        // up>0: ConvTranspose store  out[row/up][n*up + row%up - up_pad]
+  int out_act;           // OutAct
+  const float* out_mask; // [B][>=Tout] or null
+  int64_t out_mask_stride;
+  const float* res;      // residual, indexed like out, or null
+  int64_t r_bs, r_cs;
+  int accum;             // 1: add the previous contents of out
+  float out_div;         // final true division (MRF mean: xs / num_kernels), 1 = none
+  int B;
+};
+
+// Packed weight descriptor held by the model.
+struct PackedConv {
+  float* wpk = nullptr;   // device, [ceil(M/128)*4][G][64][4]
+  const float* bias = nullptr;
+  int M = 0, Cin = 0, ktaps = 0, dil = 1, pad = 0;
+  int up = 0, up_pad = 0;  // transposed conv
+  int Cout = 0;            // logical output channels (M/up for transposed)
+  int k_orig = 0;
+  int off_lo = 0, span = 0, nchunks = 0;
+};
+
+// Packs a natural-layout weight into MFMA fragment order on the device.
+//  transposed == 0: w is Conv1d [Cout][Cin][k]
+//  transposed == 1: w is ConvTranspose1d [Cin][Cout][k] with stride `up`
+int32_t pack_conv_weight(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
+                         int dil, int pad, int transposed, int up, hipStream_t stream,
+                         PackedConv* out);
+void free_packed(PackedConv* pc);
+
+// Launches the conv.  Fills geometry fields of `p` from `pc`; caller fills the I/O fields.
+int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream);
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace wetts

@@ -1,0 +1,327 @@
+// Implicit-GEMM Conv1d / ConvTranspose1d on the gfx950 f32 matrix cores.
+//
+// Replaces every dense Conv1d / ConvTranspose1d the reference runs through ATen on the
+// infer() path: HiFi-GAN conv_pre / ups / ResBlock convs (decoders.py:63-82,157-170,205-214),
+// WN in/res_skip layers (modules.py:66-85), coupling pre/post (flows.py:496-498), the encoder's
+// 1x1 q/k/v/o, FFN and proj convs (attentions.py:225-233,403-411; encoders.py:54) and the
+// duration predictors' convs (duration_predictors.py:50-54,297-310).
+//
+// Why f32 MFMA: the Baker config is quoted at fp32 with a 1e-3 waveform tolerance; per-conv
+// arithmetic intensity is 28-113 flop/B, above the f32 ridge (157 TF / 8 TB/s ~ 20 flop/B), so the
+// stack is compute-bound and v_mfma_f32_32x32x2_f32 (exact f32 fma chain, 157 TF peak, ~2.4x a
+// VALU kernel) is the binding unit.  Data movement follows the HBM rules: each activation tile
+// is read once per (m-tile) into LDS with the pre-activation (leaky-relu / mask) applied while
+// staging, weights stream from L2 in pre-packed fragment order (one dwordx4 per lane = 4 k-steps).
+//
+// Tile: 256 threads = 4 waves arranged WM x WN; each wave owns MB x NB 32x32 accumulators.
+// K loop: chunks of kConvCK=16 input channels; per chunk all taps re-use the same LDS tile
+// (columns shifted by tap*dil), so a k-tap conv reads its input once, not k times.
+#include "common.h"
+
+namespace wetts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+// layout: [mt32][g][lane][4]  with kstep = g*4+s, chunk = kstep / (ktaps*8),
+//         tap = (kstep % (ktaps*8)) / 8, pair = kstep % 8,
+//         lane -> row = mt32*32 + (lane&31), ci = chunk*16 + pair*2 + (lane>>5)
+// ------------------------------------------------------------------------------------------
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                        int M, int Cin, int Cout, int k, int ktaps, int up,
+                                        int transposed, int G, int64_t total) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int s = (int)(idx & 3);
+  int lane = (int)((idx >> 2) & 63);
+  int64_t rest = idx >> 8;
+  int g = (int)(rest % G);
+  int mt32 = (int)(rest / G);
+  int kstep = g * 4 + s;
+  int per_chunk = ktaps * 8;
+  int chunk = kstep / per_chunk;
+  int within = kstep % per_chunk;
+  int tap = within / 8;
+  int pair = within % 8;
+  int ci = chunk * kConvCK + pair * 2 + (lane >> 5);
+  int row = mt32 * 32 + (lane & 31);
+  float v = 0.f;
+  if (row < M && ci < Cin) {
+    if (!transposed) {
+      v = w[((int64_t)row * Cin + ci) * k + tap];
+    } else {
+      int co = row / up, ph = row % up;
+      int kk = ph + tap * up;
+      if (kk < k) v = w[((int64_t)ci * Cout + co) * k + kk];
+    }
+  }
+  out[idx] = v;
+}
+
+int32_t pack_conv_weight(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
+                         int dil, int pad, int transposed, int up, hipStream_t stream,
+                         PackedConv* pc) {
+  pc->Cin = Cin;
+  pc->Cout = Cout;
+  pc->k_orig = k;
+  pc->bias = bias_dev;
+  if (!transposed) {
+    pc->M = Cout;
+    pc->ktaps = k;
+    pc->dil = dil;
+    pc->pad = pad;
+    pc->up = 0;
+    pc->up_pad = 0;
+  } else {
+    pc->M = Cout * up;
+    pc->ktaps = cdiv(k, up);
+    pc->dil = -1;
+    pc->pad = 0;
+    pc->up = up;
+    pc->up_pad = pad;
+  }
+  int o0 = -pc->pad, o1 = (pc->ktaps - 1) * pc->dil - pc->pad;
+  pc->off_lo = o0 < o1 ? o0 : o1;
+  pc->span = (o0 < o1 ? o1 : o0) - pc->off_lo;
+  pc->nchunks = cdiv(Cin, kConvCK);
+  int G = pc->nchunks * pc->ktaps * 2;
+  int mt32 = cdiv(pc->M, 128) * 4;
+  int64_t total = (int64_t)mt32 * G * 256;
+  WETTS_HIP_CHECK(hipMalloc((void**)&pc->wpk, total * sizeof(float)));
+  int threads = 256;
+  int64_t blocks = (total + threads - 1) / threads;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream,
+                     w_dev, pc->wpk, pc->M, Cin, Cout, k, pc->ktaps, up > 0 ? up : 1, transposed,
+                     G, total);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+void free_packed(PackedConv* pc) {
+  if (pc->wpk) (void)hipFree(pc->wpk);
+  pc->wpk = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// the conv kernel
+// ------------------------------------------------------------------------------------------
+template <int MB, int NB, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int CK = kConvCK;
+  constexpr int MT = 32 * MB * WM;
+  constexpr int NT = 32 * NB * WN;
+  constexpr int MAXCI = (NT + 128 + 63) / 64;  // span <= 128 enforced on the host
+  constexpr int RPW = CK / 4;                  // staged rows per wave
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // block -> (b, mtile, ntile); ntile fastest so neighbouring blocks share halos in L2
+  const int ntiles = (p.N + NT - 1) / NT;
+  const int mtiles = (p.M + MT - 1) / MT;
+  int bid = blockIdx.x;
+  const int ntile = bid % ntiles;
+  bid /= ntiles;
+  const int mtile = bid % mtiles;
+  const int b = bid / mtiles;
+
+  const int n0 = ntile * NT;
+  const int W = NT + p.span;
+  float* buf0 = smem;
+  float* buf1 = smem + CK * W;
+
+  const float* xb = p.x + (int64_t)b * p.x_bs;
+  const float* mrow = p.in_mask ? p.in_mask + (int64_t)b * p.in_mask_stride : nullptr;
+
+  // per-column staging info is chunk independent
+  int tcol[MAXCI];
+  float mcol[MAXCI];
+#pragma unroll
+  for (int i = 0; i < MAXCI; ++i) {
+    int col = lane + 64 * i;
+    int t = n0 + p.off_lo + col;
+    bool ok = (col < W) && (t >= 0) && (t < p.Tin);
+    tcol[i] = ok ? t : -1;
+    mcol[i] = (ok && mrow) ? mrow[t] : 1.f;
+  }
+
+  float stage[RPW][MAXCI];
+  auto load_chunk = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      int ci = c * CK + wave + 4 * r;
+      bool cok = ci < p.Cin;
+      int ch = p.in_rev_base >= 0 ? (p.in_rev_base - ci) : ci;
+      const float* xr = xb + (int64_t)ch * p.x_cs;
+#pragma unroll
+      for (int i = 0; i < MAXCI; ++i) {
+        float v = 0.f;
+        if (cok && tcol[i] >= 0) v = xr[tcol[i]];
+        if (p.in_act == IN_LRELU) v = v > 0.f ? v : v * p.in_slope;
+        stage[r][i] = v * mcol[i];
+      }
+    }
+  };
+  auto store_chunk = [&](float* buf) {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      float* row = buf + (wave + 4 * r) * W;
+#pragma unroll
+      for (int i = 0; i < MAXCI; ++i) {
+        int col = lane + 64 * i;
+        if (col < W) row[col] = stage[r][i];
+      }
+    }
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // packed A stream for this wave's m-blocks
+  const int G = p.nchunks * p.ktaps * 2;  // groups of 4 k-steps
+  const float4* abase[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    int mt32 = mtile * (MB * WM) + wm * MB + i;
+    abase[i] = reinterpret_cast<const float4*>(p.wpk) + ((int64_t)mt32 * G) * 64 + lane;
+  }
+
+  float4 a_nxt[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][0];
+
+  load_chunk(0);
+  store_chunk(buf0);
+  __syncthreads();
+
+  const int half = lane >> 5;
+  const int bcol0 = wn * (32 * NB) + (lane & 31) - p.pad - p.off_lo;
+  int g = 0;
+  for (int c = 0; c < p.nchunks; ++c) {
+    const float* cur = (c & 1) ? buf1 : buf0;
+    const bool more = (c + 1) < p.nchunks;
+    if (more) load_chunk(c + 1);
+    for (int tap = 0; tap < p.ktaps; ++tap) {
+      const int coff = bcol0 + tap * p.dil;
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp) {
+        float4 a_cur[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) a_cur[i] = a_nxt[i];
+        ++g;
+        if (g < G) {
+#pragma unroll
+          for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][(int64_t)g * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int row = (hp * 4 + s) * 2 + half;
+          const float* brow = cur + row * W + coff;
+          float bv[NB];
+#pragma unroll
+          for (int j = 0; j < NB; ++j) bv[j] = brow[32 * j];
+#pragma unroll
+          for (int i = 0; i < MB; ++i) {
+            const float av = s == 0 ? a_cur[i].x : s == 1 ? a_cur[i].y : s == 2 ? a_cur[i].z
+                                                                                 : a_cur[i].w;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (more) store_chunk((c & 1) ? buf0 : buf1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------
+  const int64_t ob = (int64_t)b * p.o_bs;
+  const int64_t rb = (int64_t)b * p.r_bs;
+  const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
+  const float* omask = p.out_mask ? p.out_mask + (int64_t)b * p.out_mask_stride : nullptr;
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int mrow0 = mtile * MT + (wm * MB + i) * 32 + 4 * half;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int col = n0 + wn * (32 * NB) + j * 32 + (lane & 31);
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mrow0 + (r & 3) + 8 * (r >> 2);
+        if (row >= p.M) continue;
+        int co = row, t = col;
+        if (p.up > 0) {
+          co = row / p.up;
+          t = col * p.up + (row - co * p.up) - p.up_pad;
+          if (t < 0 || t >= p.Tout) continue;
+        }
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[co];
+        if (bb) v += bb[co];
+        if (p.out_act == OUT_RELU) v = v > 0.f ? v : 0.f;
+        if (omask) v *= omask[t];
+        if (p.res) v += p.res[rb + (int64_t)co * p.r_cs + t];
+        float* dst = p.out + ob + (int64_t)co * p.o_cs + t;
+        if (p.accum) v += *dst;
+        if (p.out_div != 1.f) v = v / p.out_div;
+        *dst = v;
+      }
+    }
+  }
+}
+
+template <int MB, int NB, int WM, int WN>
+static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
+  constexpr int MT = 32 * MB * WM, NT = 32 * NB * WN;
+  int ntiles = cdiv(p.N, NT), mtiles = cdiv(p.M, MT);
+  int64_t blocks = (int64_t)ntiles * mtiles * p.B;
+  if (blocks <= 0) return WETTS_OK;
+  WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
+  size_t lds = (size_t)2 * kConvCK * (NT + p.span) * sizeof(float);
+  hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN>), dim3((unsigned)blocks), dim3(256), lds,
+                     stream, p);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
+  p.wpk = pc.wpk;
+  p.bias = pc.bias;
+  p.M = pc.M;
+  p.Cin = pc.Cin;
+  p.ktaps = pc.ktaps;
+  p.dil = pc.dil;
+  p.pad = pc.pad;
+  p.off_lo = pc.off_lo;
+  p.span = pc.span;
+  p.nchunks = pc.nchunks;
+  p.up = pc.up;
+  p.up_pad = pc.up_pad;
+  WETTS_REQUIRE(pc.wpk != nullptr, "conv weight not packed");
+  WETTS_REQUIRE(p.span <= 128, "conv receptive field too wide (span %d > 128)", p.span);
+  if (p.up > 0) {
+    p.N = p.Tin + p.ktaps - 1;
+  } else {
+    p.N = p.Tout;
+  }
+  // tile selection: fill the chip first, then maximise per-wave register reuse
+  if (p.M >= 128 && (int64_t)p.N * p.B >= 4096) return launch_cfg<2, 2, 2, 2>(p, stream);
+  if (p.M > 32 && (int64_t)p.N * p.B >= 8192) return launch_cfg<2, 2, 1, 4>(p, stream);
+  if (p.M <= 32 && (int64_t)p.N * p.B >= 8192) return launch_cfg<1, 2, 1, 4>(p, stream);
+  return launch_cfg<1, 1, 2, 2>(p, stream);
+}
+
+}  // namespace wetts

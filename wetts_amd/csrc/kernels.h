@@ -1,0 +1,93 @@
+// Launchers for the non-GEMM kernels of the VITS infer() path (kernels.hip, attention.hip,
+// mas.hip).  All tensors float32 channel-first [B,C,T] contiguous unless noted.
+#pragma once
+#include "common.h"
+
+namespace wetts {
+
+// a3 emb lookup * sqrt(H) * mask + sequence_mask  (encoders.py:48-53, commons.py:113-117)
+int32_t k_embed_mask(const int64_t* ids, const int64_t* lengths, const float* emb, int n_vocab,
+                     int B, int H, int T, float* x_out, float* mask_out, hipStream_t s);
+
+// a7 channel LayerNorm (normalization.py:16-19), fused with the surrounding elementwise ops:
+//   v = a (+ add);  y = LN(v)*gamma+beta;  if gelu: y = gelu_erf(y);  if res: y += res;
+//   if mask: y *= mask[b,t]
+int32_t k_layernorm(const float* a, const float* add, const float* gamma, const float* beta,
+                    const float* res, const float* mask, int gelu, int B, int C, int T, float* out,
+                    hipStream_t s);
+
+// DDSConv depthwise dilated conv on (x*mask)  (duration_predictors.py:49-50)
+int32_t k_dwconv(const float* x, const float* mask, const float* w, const float* bias, int k,
+                 int dil, int B, int C, int T, float* out, hipStream_t s);
+
+// out[b,c] = bias[c] + sum_k W[c,k] * g[b,k]   (every `cond`/`cond_layer` 1x1 conv on g[B,gin,1])
+int32_t k_cond_linear(const float* g, const float* W, const float* bias, int B, int Cout, int K,
+                      float* out, hipStream_t s);
+
+int32_t k_gather_rows(const int64_t* idx, const float* table, int n_rows, int B, int C, float* out,
+                      hipStream_t s);
+
+// x[b,c,t] += v[b,c]
+int32_t k_add_bias_b(float* x, const float* v, int B, int C, int T, hipStream_t s);
+// out = a * scale
+int32_t k_scale(const float* a, float scale, int64_t n, float* out, hipStream_t s);
+
+// ConvFlow.pre (1 -> C 1x1 conv) + DDSConv's `x + g`   (duration_predictors.py:92-93,46-47)
+int32_t k_convflow_pre(const float* z, int ch0, const float* w, const float* bias, const float* g,
+                       int B, int C, int T, float* out, hipStream_t s);
+
+// Rational-quadratic spline inverse with linear tails + cat + mask  (transforms.py:47-187,
+// duration_predictors.py:96-118).  z [B,2,T] updated in place: channel ch0 *= mask,
+// channel ch1 = spline^-1(z[ch1]) * mask.  h [B, 3*bins-1, T].
+int32_t k_spline_inverse(float* z, int ch0, int ch1, const float* h, const float* mask,
+                         int num_bins, float tail_bound, float inv_sqrt_div, int B, int T,
+                         int32_t* status, hipStream_t s);
+
+// ElementwiseAffine reverse on channel ch -> logw  (duration_predictors.py:139-141,259-262)
+int32_t k_affine_reverse(const float* z, int ch, const float* m, const float* logs, int param_idx,
+                         const float* mask, int B, int T, float* logw, hipStream_t s);
+
+// commons.fused_add_tanh_sigmoid_multiply (commons.py:98-105): a [B,2H,T] -> out [B,H,T]
+int32_t k_gate(const float* a, int B, int H, int T, float* out, hipStream_t s);
+
+// WN residual/skip update (modules.py:79-86)
+int32_t k_wn_update(const float* rs, float* h, float* skip, const float* mask, int last, int first,
+                    int B, int H, int T, hipStream_t s);
+
+// Flip + coupling reverse (flows.py:494-513, modules.py:100-106):
+//   out[c] = c < half ? xin[C-1-c] : (xin[C-1-c] - m[c-half]) * mask
+int32_t k_coupling_flip(const float* xin, const float* m, const float* mask, int B, int C, int T,
+                        float* out, hipStream_t s);
+
+// conv_post: lrelu(0.01) -> Conv1d(C,1,7,pad 3, no bias) -> tanh  (decoders.py:78-80)
+int32_t k_conv_post_tanh(const float* x, const float* w, int k, int B, int C, int T, float* out,
+                         hipStream_t s);
+
+// a10 (models.py:254-256)
+int32_t k_durations_to_lengths(const float* logw, const float* mask, float length_scale, int B,
+                               int T, float* w_ceil, float* cum, int64_t* y_lengths,
+                               hipStream_t s);
+
+// a10-a12 (models.py:257-267; commons.py:113-136)
+int32_t k_frame_index(const float* cum, const int64_t* y_lengths, int B, int Tx, int Ty,
+                      int32_t* frame2phone, float* y_mask, hipStream_t s);
+int32_t k_expand_prior(const float* stats, const int32_t* frame2phone, const float* eps,
+                       int64_t eps_bs, int64_t eps_cs, float noise_scale, int B, int C, int Tx, int Ty, float* m_exp,
+                       float* logs_exp, float* z_p, hipStream_t s);
+int32_t k_attn_path(const int32_t* frame2phone, int B, int Tx, int Ty, float* attn, hipStream_t s);
+
+// a16 (inference.py:100-110)
+int32_t k_audio_to_int16(const float* audio, const int64_t* lengths, int B, int64_t L, int16_t* pcm,
+                         hipStream_t s);
+
+// a5 windowed relative-position attention (attentions.py:235-282), banded form.
+//   qkv: q,k,v [B,H*dk,T];  scores workspace [B,H,T,T];  out [B,H*dk,T]
+int32_t k_rel_attention(const float* q, const float* k, const float* v, const float* mask,
+                        const float* emb_rel_k, const float* emb_rel_v, int window, int B,
+                        int n_heads, int dk, int T, float* scores, float* out, hipStream_t s);
+
+// a15 MAS
+int32_t k_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, int B, int Ty,
+              int Tx, int32_t* path, float* values, hipStream_t s);
+
+}  // namespace wetts

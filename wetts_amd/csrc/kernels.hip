@@ -1,0 +1,672 @@
+// Non-GEMM kernels of the VITS infer() path for gfx950.  All are HBM/latency-bound byte movers:
+// lanes run along the time axis (stride-1 in [B,C,T]) so every global access is coalesced; small
+// reductions over channels use LDS or wave shuffles.  No kernel here is reshaped into a GEMM.
+#include "kernels.h"
+
+namespace wetts {
+
+static inline dim3 grid1d(int64_t n, int threads) {
+  return dim3((unsigned)((n + threads - 1) / threads));
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void embed_mask_kernel(const int64_t* __restrict__ ids,
+                                  const int64_t* __restrict__ lengths,
+                                  const float* __restrict__ emb, int n_vocab, int B, int H, int T,
+                                  float scale, float* __restrict__ x_out,
+                                  float* __restrict__ mask_out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)B * H * T;
+  if (idx >= total) return;
+  int t = (int)(idx % T);
+  int c = (int)((idx / T) % H);
+  int b = (int)(idx / ((int64_t)T * H));
+  bool valid = (int64_t)t < lengths[b];
+  float v = 0.f;
+  if (valid) {
+    int64_t id = ids[(int64_t)b * T + t];
+    if (id < 0) id = 0;
+    if (id >= n_vocab) id = n_vocab - 1;
+    v = emb[id * H + c] * scale;
+  }
+  x_out[idx] = v;
+  if (c == 0) mask_out[(int64_t)b * T + t] = valid ? 1.f : 0.f;
+}
+
+int32_t k_embed_mask(const int64_t* ids, const int64_t* lengths, const float* emb, int n_vocab,
+                     int B, int H, int T, float* x_out, float* mask_out, hipStream_t s) {
+  int64_t n = (int64_t)B * H * T;
+  if (n == 0) return WETTS_OK;
+  float scale = (float)sqrt((double)H);  // math.sqrt(hidden_channels), encoders.py:48
+  hipLaunchKernelGGL(embed_mask_kernel, grid1d(n, 256), dim3(256), 0, s, ids, lengths, emb,
+                     n_vocab, B, H, T, scale, x_out, mask_out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over channels.  Block = 64 time lanes x 4 channel groups; each thread owns C/4
+// channels of one (b,t) column; partial moments are combined through LDS.
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(
+    const float* __restrict__ a, const float* __restrict__ add, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ res, const float* __restrict__ mask,
+    int gelu, int B, int C, int T, float eps, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int tblocks = (T + 63) / 64;
+  const int b = blockIdx.x / tblocks;
+  const int t = (blockIdx.x % tblocks) * 64 + tl;
+  const bool ok = t < T;
+  const int64_t base = (int64_t)b * C * T + t;
+  const int c0 = (C * cg) / 4, c1 = (C * (cg + 1)) / 4;
+
+  float sum = 0.f;
+  if (ok) {
+    for (int c = c0; c < c1; ++c) {
+      float v = a[base + (int64_t)c * T];
+      if (add) v += add[base + (int64_t)c * T];
+      sum += v;
+    }
+  }
+  red[cg][tl] = sum;
+  __syncthreads();
+  const float mean = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / (float)C;
+  __syncthreads();
+  float sq = 0.f;
+  if (ok) {
+    for (int c = c0; c < c1; ++c) {
+      float v = a[base + (int64_t)c * T];
+      if (add) v += add[base + (int64_t)c * T];
+      float d = v - mean;
+      sq += d * d;
+    }
+  }
+  red[cg][tl] = sq;
+  __syncthreads();
+  const float var = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / (float)C;
+  const float rstd = 1.f / sqrtf(var + eps);
+  if (!ok) return;
+  const float mk = mask ? mask[(int64_t)b * T + t] : 1.f;
+  for (int c = c0; c < c1; ++c) {
+    float v = a[base + (int64_t)c * T];
+    if (add) v += add[base + (int64_t)c * T];
+    float y = (v - mean) * rstd * gamma[c] + beta[c];
+    if (gelu) y = gelu_erf(y);
+    if (res) y += res[base + (int64_t)c * T];
+    out[base + (int64_t)c * T] = y * mk;
+  }
+}
+
+int32_t k_layernorm(const float* a, const float* add, const float* gamma, const float* beta,
+                    const float* res, const float* mask, int gelu, int B, int C, int T, float* out,
+                    hipStream_t s) {
+  if (B * T == 0) return WETTS_OK;
+  int blocks = B * cdiv(T, 64);
+  hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, s, a, add, gamma, beta, res,
+                     mask, gelu, B, C, T, 1e-5f, out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                              const float* __restrict__ w, const float* __restrict__ bias, int k,
+                              int dil, int B, int C, int T, float* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)B * C * T;
+  if (idx >= total) return;
+  int t = (int)(idx % T);
+  int c = (int)((idx / T) % C);
+  int b = (int)(idx / ((int64_t)T * C));
+  const float* xr = x + ((int64_t)b * C + c) * T;
+  const float* mr = mask + (int64_t)b * T;
+  int pad = (k * dil - dil) / 2;
+  float acc = bias[c];
+  for (int j = 0; j < k; ++j) {
+    int tt = t + j * dil - pad;
+    if (tt >= 0 && tt < T) acc += w[c * k + j] * (xr[tt] * mr[tt]);
+  }
+  out[idx] = acc;
+}
+
+int32_t k_dwconv(const float* x, const float* mask, const float* w, const float* bias, int k,
+                 int dil, int B, int C, int T, float* out, hipStream_t s) {
+  int64_t n = (int64_t)B * C * T;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(dwconv_kernel, grid1d(n, 256), dim3(256), 0, s, x, mask, w, bias, k, dil, B,
+                     C, T, out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one wave per (b, c): lanes stride over K, shuffle-reduce
+__global__ __launch_bounds__(256) void cond_linear_kernel(const float* __restrict__ g,
+                                                          const float* __restrict__ W,
+                                                          const float* __restrict__ bias, int B,
+                                                          int Cout, int K,
+                                                          float* __restrict__ out) {
+  int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (wave >= B * Cout) return;
+  int c = wave % Cout, b = wave / Cout;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += W[(int64_t)c * K + k] * g[(int64_t)b * K + k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) out[(int64_t)b * Cout + c] = acc + (bias ? bias[c] : 0.f);
+}
+
+int32_t k_cond_linear(const float* g, const float* W, const float* bias, int B, int Cout, int K,
+                      float* out, hipStream_t s) {
+  int64_t n = (int64_t)B * Cout * 64;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(cond_linear_kernel, grid1d(n, 256), dim3(256), 0, s, g, W, bias, B, Cout, K,
+                     out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+__global__ void gather_rows_kernel(const int64_t* __restrict__ idx, const float* __restrict__ table,
+                                   int n_rows, int B, int C, float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  int b = i / C, c = i % C;
+  int64_t r = idx[b];
+  if (r < 0) r = 0;
+  if (r >= n_rows) r = n_rows - 1;
+  out[i] = table[r * C + c];
+}
+
+int32_t k_gather_rows(const int64_t* idx, const float* table, int n_rows, int B, int C, float* out,
+                      hipStream_t s) {
+  if (B * C == 0) return WETTS_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, grid1d((int64_t)B * C, 256), dim3(256), 0, s, idx, table,
+                     n_rows, B, C, out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+__global__ void add_bias_b_kernel(float* __restrict__ x, const float* __restrict__ v, int64_t total,
+                                  int T) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  x[idx] += v[idx / T];
+}
+
+int32_t k_add_bias_b(float* x, const float* v, int B, int C, int T, hipStream_t s) {
+  int64_t n = (int64_t)B * C * T;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(add_bias_b_kernel, grid1d(n, 256), dim3(256), 0, s, x, v, n, T);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+__global__ void scale_kernel(const float* __restrict__ a, float scale, int64_t n,
+                             float* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) out[idx] = a[idx] * scale;
+}
+
+int32_t k_scale(const float* a, float scale, int64_t n, float* out, hipStream_t s) {
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(scale_kernel, grid1d(n, 256), dim3(256), 0, s, a, scale, n, out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void convflow_pre_kernel(const float* __restrict__ z, int ch0,
+                                    const float* __restrict__ w, const float* __restrict__ bias,
+                                    const float* __restrict__ g, int B, int C, int T,
+                                    float* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)B * C * T;
+  if (idx >= total) return;
+  int t = (int)(idx % T);
+  int c = (int)((idx / T) % C);
+  int b = (int)(idx / ((int64_t)T * C));
+  float x0 = z[((int64_t)b * 2 + ch0) * T + t];
+  out[idx] = (w[c] * x0 + bias[c]) + g[idx];
+}
+
+int32_t k_convflow_pre(const float* z, int ch0, const float* w, const float* bias, const float* g,
+                       int B, int C, int T, float* out, hipStream_t s) {
+  int64_t n = (int64_t)B * C * T;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(convflow_pre_kernel, grid1d(n, 256), dim3(256), 0, s, z, ch0, w, bias, g, B,
+                     C, T, out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rational-quadratic spline, inverse direction, linear tails.  One thread per (b,t).
+// Mirrors transforms.py:47-97 (tails) and :100-187 (inverse branch) operation by operation.
+constexpr int kMaxBins = 16;
+
+__device__ __forceinline__ float softplus_f(float x) {
+  return x > 20.f ? x : log1pf(expf(x));  // F.softplus(beta=1, threshold=20)
+}
+
+__global__ void spline_inverse_kernel(float* __restrict__ z, int ch0, int ch1,
+                                      const float* __restrict__ h, const float* __restrict__ mask,
+                                      int nb, float tail, float div, int B, int T,
+                                      int32_t* __restrict__ status) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * T) return;
+  const int t = idx % T, b = idx / T;
+  const float mk = mask[idx];
+  float* z0 = z + ((int64_t)b * 2 + ch0) * T + t;
+  float* z1 = z + ((int64_t)b * 2 + ch1) * T + t;
+  const float x = *z1;
+  const float* hp = h + (int64_t)b * (3 * nb - 1) * T + t;
+  float outv = x;
+  if (x >= -tail && x <= tail) {
+    const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
+    const float one_minus = (float)(1.0 - 1e-3 * (double)nb);  // python double, then f32 (transforms.py:126)
+    float cw[kMaxBins + 1], chh[kMaxBins + 1];
+    // widths: softmax -> min + (1-min*nb)*p -> cumsum -> affine -> pin ends
+    {
+      float u[kMaxBins];
+      float mx = -INFINITY;
+      for (int i = 0; i < nb; ++i) {
+        u[i] = hp[(int64_t)i * T] / div;
+        mx = fmaxf(mx, u[i]);
+      }
+      float sm = 0.f;
+      for (int i = 0; i < nb; ++i) {
+        u[i] = expf(u[i] - mx);
+        sm += u[i];
+      }
+      float cum = 0.f;
+      cw[0] = -tail;
+      for (int i = 0; i < nb; ++i) {
+        float wdt = min_w + one_minus * (u[i] / sm);
+        cum += wdt;
+        cw[i + 1] = (2.f * tail) * cum + (-tail);
+      }
+      cw[0] = -tail;
+      cw[nb] = tail;
+    }
+    {
+      float u[kMaxBins];
+      float mx = -INFINITY;
+      for (int i = 0; i < nb; ++i) {
+        u[i] = hp[(int64_t)(nb + i) * T] / div;
+        mx = fmaxf(mx, u[i]);
+      }
+      float sm = 0.f;
+      for (int i = 0; i < nb; ++i) {
+        u[i] = expf(u[i] - mx);
+        sm += u[i];
+      }
+      float cum = 0.f;
+      chh[0] = -tail;
+      for (int i = 0; i < nb; ++i) {
+        float hgt = min_h + one_minus * (u[i] / sm);
+        cum += hgt;
+        chh[i + 1] = (2.f * tail) * cum + (-tail);
+      }
+      chh[0] = -tail;
+      chh[nb] = tail;
+    }
+    // searchsorted(cumheights, x): last edge += 1e-6; count(x >= edge) - 1
+    int bin = -1;
+    for (int i = 0; i <= nb; ++i) {
+      float e = chh[i];
+      if (i == nb) e += 1e-6f;
+      bin += (x >= e) ? 1 : 0;
+    }
+    if (bin < 0) bin = 0;
+    if (bin > nb - 1) bin = nb - 1;
+    const float in_cw = cw[bin];
+    const float in_bw = cw[bin + 1] - cw[bin];
+    const float in_ch = chh[bin];
+    const float in_h = chh[bin + 1] - chh[bin];
+    const float in_delta = in_h / in_bw;
+    // derivatives: pad both ends with log(exp(1-min_d)-1)
+    const float cst = (float)0.5408847652626036;  // np.log(np.exp(1 - 1e-3) - 1)
+    float ud0 = (bin == 0) ? cst : hp[(int64_t)(2 * nb + bin - 1) * T];
+    float ud1 = (bin == nb - 1) ? cst : hp[(int64_t)(2 * nb + bin) * T];
+    const float d0 = min_d + softplus_f(ud0);
+    const float d1 = min_d + softplus_f(ud1);
+
+    const float dx = x - in_ch;
+    const float s2 = d0 + d1 - 2.f * in_delta;
+    const float qa = dx * s2 + in_h * (in_delta - d0);
+    const float qb = in_h * d0 - dx * s2;
+    const float qc = -in_delta * dx;
+    const float disc = qb * qb - 4.f * qa * qc;
+    if (!(disc >= 0.f)) {
+      if (status) atomicOr(status, 1);
+    }
+    const float root = (2.f * qc) / (-qb - sqrtf(disc));
+    outv = root * in_bw + in_cw;
+  }
+  *z1 = outv * mk;
+  *z0 = (*z0) * mk;
+}
+
+int32_t k_spline_inverse(float* z, int ch0, int ch1, const float* h, const float* mask,
+                         int num_bins, float tail_bound, float div, int B, int T, int32_t* status,
+                         hipStream_t s) {
+  WETTS_REQUIRE(num_bins <= kMaxBins, "num_bins %d > %d", num_bins, kMaxBins);
+  if (B * T == 0) return WETTS_OK;
+  hipLaunchKernelGGL(spline_inverse_kernel, grid1d((int64_t)B * T, 128), dim3(128), 0, s, z, ch0,
+                     ch1, h, mask, num_bins, tail_bound, div, B, T, status);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+__global__ void affine_reverse_kernel(const float* __restrict__ z, int ch,
+                                      const float* __restrict__ m, const float* __restrict__ logs,
+                                      int pidx, const float* __restrict__ mask, int B, int T,
+                                      float* __restrict__ logw) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * T) return;
+  int t = idx % T, b = idx / T;
+  float x = z[((int64_t)b * 2 + ch) * T + t];
+  logw[idx] = (x - m[pidx]) * expf(-logs[pidx]) * mask[idx];
+}
+
+int32_t k_affine_reverse(const float* z, int ch, const float* m, const float* logs, int param_idx,
+                         const float* mask, int B, int T, float* logw, hipStream_t s) {
+  if (B * T == 0) return WETTS_OK;
+  hipLaunchKernelGGL(affine_reverse_kernel, grid1d((int64_t)B * T, 256), dim3(256), 0, s, z, ch, m,
+                     logs, param_idx, mask, B, T, logw);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void gate_kernel(const float* __restrict__ a, int B, int H, int T,
+                            float* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)B * H * T;
+  if (idx >= total) return;
+  int64_t ht = (int64_t)H * T;
+  int64_t b = idx / ht, r = idx % ht;
+  float ta = a[b * 2 * ht + r];
+  float sa = a[b * 2 * ht + ht + r];
+  out[idx] = tanhf(ta) * (1.f / (1.f + expf(-sa)));
+}
+
+int32_t k_gate(const float* a, int B, int H, int T, float* out, hipStream_t s) {
+  int64_t n = (int64_t)B * H * T;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(gate_kernel, grid1d(n, 256), dim3(256), 0, s, a, B, H, T, out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+__global__ void wn_update_kernel(const float* __restrict__ rs, float* __restrict__ h,
+                                 float* __restrict__ skip, const float* __restrict__ mask, int last,
+                                 int first, int B, int H, int T) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)B * H * T;
+  if (idx >= total) return;
+  int64_t ht = (int64_t)H * T;
+  int64_t b = idx / ht, r = idx % ht;
+  int t = (int)(r % T);
+  float sk;
+  if (!last) {
+    float res = rs[b * 2 * ht + r];
+    sk = rs[b * 2 * ht + ht + r];
+    h[idx] = (h[idx] + res) * mask[b * T + t];
+  } else {
+    sk = rs[idx];
+  }
+  skip[idx] = first ? sk : skip[idx] + sk;
+}
+
+int32_t k_wn_update(const float* rs, float* h, float* skip, const float* mask, int last, int first,
+                    int B, int H, int T, hipStream_t s) {
+  int64_t n = (int64_t)B * H * T;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(wn_update_kernel, grid1d(n, 256), dim3(256), 0, s, rs, h, skip, mask, last,
+                     first, B, H, T);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+__global__ void coupling_flip_kernel(const float* __restrict__ xin, const float* __restrict__ m,
+                                     const float* __restrict__ mask, int B, int C, int T,
+                                     float* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)B * C * T;
+  if (idx >= total) return;
+  int t = (int)(idx % T);
+  int c = (int)((idx / T) % C);
+  int b = (int)(idx / ((int64_t)T * C));
+  const int half = C / 2;
+  float v = xin[((int64_t)b * C + (C - 1 - c)) * T + t];
+  if (c >= half) v = (v - m[((int64_t)b * half + (c - half)) * T + t]) * mask[(int64_t)b * T + t];
+  out[idx] = v;
+}
+
+int32_t k_coupling_flip(const float* xin, const float* m, const float* mask, int B, int C, int T,
+                        float* out, hipStream_t s) {
+  int64_t n = (int64_t)B * C * T;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(coupling_flip_kernel, grid1d(n, 256), dim3(256), 0, s, xin, m, mask, B, C, T,
+                     out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_post: each thread produces 4 consecutive samples; weights (C*k floats) sit in LDS.
+__global__ __launch_bounds__(256) void conv_post_tanh_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ w, int k,
+                                                             int B, int C, int T,
+                                                             float* __restrict__ out) {
+  extern __shared__ float wsh[];
+  for (int i = threadIdx.x; i < C * k; i += blockDim.x) wsh[i] = w[i];
+  __syncthreads();
+  const int per_b = (T + 3) / 4;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * per_b) return;
+  const int b = (int)(idx / per_b);
+  const int t0 = (int)(idx % per_b) * 4;
+  const int pad = (k - 1) / 2;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* xb = x + (int64_t)b * C * T;
+  for (int c = 0; c < C; ++c) {
+    const float* xr = xb + (int64_t)c * T;
+    float win[4 + 15];
+    for (int i = 0; i < 3 + k; ++i) {
+      int tt = t0 - pad + i;
+      float v = (tt >= 0 && tt < T) ? xr[tt] : 0.f;
+      win[i] = v > 0.f ? v : v * 0.01f;  // F.leaky_relu default slope, decoders.py:78
+    }
+    for (int j = 0; j < k; ++j) {
+      float wv = wsh[c * k + j];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc[o] += wv * win[o + j];
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+    if (t0 + o < T) out[(int64_t)b * T + t0 + o] = tanhf(acc[o]);
+}
+
+int32_t k_conv_post_tanh(const float* x, const float* w, int k, int B, int C, int T, float* out,
+                         hipStream_t s) {
+  WETTS_REQUIRE(k <= 15, "conv_post kernel size %d unsupported", k);
+  int64_t n = (int64_t)B * ((T + 3) / 4);
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(conv_post_tanh_kernel, grid1d(n, 256), dim3(256), (size_t)C * k * 4, s, x, w,
+                     k, B, C, T, out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// durations -> lengths: one wave per utterance; inclusive scan with wave shuffles.
+__global__ __launch_bounds__(64) void durations_kernel(const float* __restrict__ logw,
+                                                       const float* __restrict__ mask,
+                                                       float length_scale, int B, int T,
+                                                       float* __restrict__ w_ceil,
+                                                       float* __restrict__ cum,
+                                                       int64_t* __restrict__ y_lengths) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float carry = 0.f;
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    int t = t0 + lane;
+    float wc = 0.f;
+    if (t < T) {
+      float w = expf(logw[(int64_t)b * T + t]) * mask[(int64_t)b * T + t] * length_scale;
+      wc = ceilf(w);
+      w_ceil[(int64_t)b * T + t] = wc;
+    }
+    float v = wc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      float n = __shfl_up(v, off, 64);
+      if (lane >= off) v += n;
+    }
+    v += carry;
+    if (t < T) cum[(int64_t)b * T + t] = v;
+    carry = __shfl(v, 63, 64);
+  }
+  if (lane == 0) {
+    float tot = carry < 1.f ? 1.f : carry;  // clamp_min(sum, 1)
+    y_lengths[b] = (int64_t)tot;
+  }
+}
+
+int32_t k_durations_to_lengths(const float* logw, const float* mask, float length_scale, int B,
+                               int T, float* w_ceil, float* cum, int64_t* y_lengths,
+                               hipStream_t s) {
+  if (B == 0) return WETTS_OK;
+  hipLaunchKernelGGL(durations_kernel, dim3(B), dim3(64), 0, s, logw, mask, length_scale, B, T,
+                     w_ceil, cum, y_lengths);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// frame -> phoneme index map (replaces generate_path's dense 0/1 tensor as the working form)
+__global__ void frame_index_kernel(const float* __restrict__ cum,
+                                   const int64_t* __restrict__ y_lengths, int B, int Tx, int Ty,
+                                   int32_t* __restrict__ f2p, float* __restrict__ y_mask) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * Ty) return;
+  int ty = idx % Ty, b = idx / Ty;
+  bool valid = (int64_t)ty < y_lengths[b];
+  int res = -1;
+  if (valid) {
+    // first tx with cum[tx] > ty  (path[tx] = (ty < cum[tx]) - (ty < cum[tx-1]), commons.py:128-134)
+    const float* cr = cum + (int64_t)b * Tx;
+    int lo = 0, hi = Tx;
+    float fy = (float)ty;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (cr[mid] > fy) hi = mid; else lo = mid + 1;
+    }
+    if (lo < Tx) res = lo;
+  }
+  f2p[idx] = res;
+  y_mask[idx] = valid ? 1.f : 0.f;
+}
+
+int32_t k_frame_index(const float* cum, const int64_t* y_lengths, int B, int Tx, int Ty,
+                      int32_t* frame2phone, float* y_mask, hipStream_t s) {
+  if (B * Ty == 0) return WETTS_OK;
+  hipLaunchKernelGGL(frame_index_kernel, grid1d((int64_t)B * Ty, 256), dim3(256), 0, s, cum,
+                     y_lengths, B, Tx, Ty, frame2phone, y_mask);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+__global__ void expand_prior_kernel(const float* __restrict__ stats,
+                                    const int32_t* __restrict__ f2p, const float* __restrict__ eps,
+                                    int64_t eps_bs, int64_t eps_cs, float noise_scale, int B, int C, int Tx, int Ty,
+                                    float* __restrict__ m_exp, float* __restrict__ logs_exp,
+                                    float* __restrict__ z_p) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)B * C * Ty;
+  if (idx >= total) return;
+  int ty = (int)(idx % Ty);
+  int c = (int)((idx / Ty) % C);
+  int b = (int)(idx / ((int64_t)Ty * C));
+  int tx = f2p[(int64_t)b * Ty + ty];
+  float m = 0.f, ls = 0.f;
+  if (tx >= 0) {
+    m = stats[((int64_t)b * 2 * C + c) * Tx + tx];
+    ls = stats[((int64_t)b * 2 * C + C + c) * Tx + tx];
+  }
+  if (m_exp) m_exp[idx] = m;
+  if (logs_exp) logs_exp[idx] = ls;
+  const float e = eps[(int64_t)b * eps_bs + (int64_t)c * eps_cs + ty];
+  z_p[idx] = m + e * expf(ls) * noise_scale;  // models.py:267
+}
+
+int32_t k_expand_prior(const float* stats, const int32_t* frame2phone, const float* eps,
+                       int64_t eps_bs, int64_t eps_cs, float noise_scale, int B, int C, int Tx, int Ty, float* m_exp,
+                       float* logs_exp, float* z_p, hipStream_t s) {
+  int64_t n = (int64_t)B * C * Ty;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(expand_prior_kernel, grid1d(n, 256), dim3(256), 0, s, stats, frame2phone, eps,
+                     eps_bs, eps_cs, noise_scale, B, C, Tx, Ty, m_exp, logs_exp, z_p);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+__global__ void attn_path_kernel(const int32_t* __restrict__ f2p, int B, int Tx, int Ty,
+                                 float* __restrict__ attn) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)B * Ty * Tx;
+  if (idx >= total) return;
+  int tx = (int)(idx % Tx);
+  int64_t bty = idx / Tx;
+  attn[idx] = (f2p[bty] == tx) ? 1.f : 0.f;
+}
+
+int32_t k_attn_path(const int32_t* frame2phone, int B, int Tx, int Ty, float* attn, hipStream_t s) {
+  int64_t n = (int64_t)B * Ty * Tx;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(attn_path_kernel, grid1d(n, 256), dim3(256), 0, s, frame2phone, B, Tx, Ty,
+                     attn);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void audio_to_int16_kernel(const float* __restrict__ audio,
+                                                             const int64_t* __restrict__ lengths,
+                                                             int64_t L, int16_t* __restrict__ pcm) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float* a = audio + (int64_t)b * L;
+  int64_t n = lengths ? lengths[b] : L;
+  if (n > L) n = L;
+  float mx = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, fabsf(a[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  // audio *= 32767 / max(0.01, max|audio|) * 0.6   (inference.py:101)
+  const float scale = (32767.f / fmaxf(0.01f, mx)) * 0.6f;
+  for (int64_t i = threadIdx.x; i < L; i += blockDim.x) {
+    float v = a[i] * scale;
+    v = fminf(fmaxf(v, -32767.f), 32767.f);
+    pcm[(int64_t)b * L + i] = (int16_t)v;  // numpy astype(int16) truncates toward zero
+  }
+}
+
+int32_t k_audio_to_int16(const float* audio, const int64_t* lengths, int B, int64_t L, int16_t* pcm,
+                         hipStream_t s) {
+  if (B == 0 || L == 0) return WETTS_OK;
+  hipLaunchKernelGGL(audio_to_int16_kernel, dim3(B), dim3(256), 0, s, audio, lengths, L, pcm);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+}  // namespace wetts

@@ -1,0 +1,1246 @@
+// libwetts_hip.so -- C-ABI implementation: blob layout, model creation (weight packing) and the
+// stream-ordered stage entry points that compose the reference's SynthesizerTrn.infer()
+// (wetts/vits/model/models.py:228-280).  See include/wetts_hip.h for the contract.
+#include <stdarg.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace wetts {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// blob layout
+// ---------------------------------------------------------------------------------------------
+struct TensorSpec {
+  std::string name;
+  int64_t shape[4];
+  int64_t offset, numel;
+};
+
+struct Layout {
+  std::vector<TensorSpec> specs;
+  std::map<std::string, int> index;
+  int64_t total = 0;
+  void add(const std::string& name, int64_t d0, int64_t d1 = 0, int64_t d2 = 0, int64_t d3 = 0) {
+    TensorSpec t;
+    t.name = name;
+    t.shape[0] = d0; t.shape[1] = d1; t.shape[2] = d2; t.shape[3] = d3;
+    t.numel = d0 * (d1 ? d1 : 1) * (d2 ? d2 : 1) * (d3 ? d3 : 1);
+    t.offset = total;
+    total += (t.numel + 63) / 64 * 64;  // keep every tensor 256-byte aligned
+    index[name] = (int)specs.size();
+    specs.push_back(t);
+  }
+};
+
+static std::string S(const char* fmt, ...) {
+  char buf[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return std::string(buf);
+}
+
+static int validate_config(const wetts_config_t* c) {
+  WETTS_REQUIRE(c != nullptr, "null config");
+  WETTS_REQUIRE(c->n_vocab > 0 && c->inter_channels > 0 && c->hidden_channels > 0, "bad channels");
+  WETTS_REQUIRE(c->inter_channels % 2 == 0, "inter_channels must be even (flows.py:469)");
+  WETTS_REQUIRE(c->n_heads > 0 && c->hidden_channels % c->n_heads == 0, "bad n_heads");
+  WETTS_REQUIRE(c->n_layers >= 0 && c->n_layers <= 64, "bad n_layers");
+  WETTS_REQUIRE(c->kernel_size >= 1 && c->kernel_size <= 15, "bad kernel_size");
+  WETTS_REQUIRE(c->resblock == 1 || c->resblock == 2, "resblock must be 1 or 2");
+  WETTS_REQUIRE(c->n_resblock_kernels >= 1 && c->n_resblock_kernels <= WETTS_MAX_RB_KERNELS,
+                "bad n_resblock_kernels");
+  WETTS_REQUIRE(c->n_resblock_dilations >= 1 && c->n_resblock_dilations <= WETTS_MAX_RB_DILATIONS,
+                "bad n_resblock_dilations");
+  WETTS_REQUIRE(c->n_upsamples >= 1 && c->n_upsamples <= WETTS_MAX_STAGES, "bad n_upsamples");
+  WETTS_REQUIRE(c->upsample_initial_channel >> c->n_upsamples >= 1, "too many upsample stages");
+  for (int i = 0; i < c->n_upsamples; ++i) {
+    WETTS_REQUIRE(c->upsample_rates[i] >= 1 && c->upsample_kernel_sizes[i] >= c->upsample_rates[i],
+                  "bad upsample stage %d", i);
+    WETTS_REQUIRE((c->upsample_kernel_sizes[i] - c->upsample_rates[i]) % 2 == 0,
+                  "upsample kernel-stride must be even (decoders.py:47)");
+  }
+  for (int j = 0; j < c->n_resblock_kernels; ++j)
+    WETTS_REQUIRE(c->resblock_kernel_sizes[j] % 2 == 1, "resblock kernel sizes must be odd");
+  WETTS_REQUIRE(c->n_speakers >= 0 && c->gin_channels >= 0, "bad speaker config");
+  WETTS_REQUIRE(c->n_speakers == 0 || c->gin_channels > 0, "n_speakers>0 needs gin_channels");
+  WETTS_REQUIRE(c->window_size >= 0 && c->window_size <= 16, "bad window_size");
+  WETTS_REQUIRE(c->flow_n_flows >= 1 && c->flow_wn_layers >= 1 && c->flow_kernel_size % 2 == 1,
+                "bad flow config");
+  WETTS_REQUIRE(c->sdp_n_flows >= 2, "bad sdp_n_flows");
+  return WETTS_OK;
+}
+
+static bool has_g(const wetts_config_t* c) { return c->n_speakers > 0 && c->gin_channels > 0; }
+
+static void add_dds(Layout& L, const std::string& p, int C, int k, int n) {
+  for (int i = 0; i < n; ++i) {
+    L.add(p + S(".convs_sep.%d.weight", i), C, 1, k);
+    L.add(p + S(".convs_sep.%d.bias", i), C);
+    L.add(p + S(".convs_1x1.%d.weight", i), C, C, 1);
+    L.add(p + S(".convs_1x1.%d.bias", i), C);
+    L.add(p + S(".norms_1.%d.gamma", i), C);
+    L.add(p + S(".norms_1.%d.beta", i), C);
+    L.add(p + S(".norms_2.%d.gamma", i), C);
+    L.add(p + S(".norms_2.%d.beta", i), C);
+  }
+}
+
+static void build_layout(const wetts_config_t* c, Layout& L) {
+  const int H = c->hidden_channels, I = c->inter_channels, F = c->filter_channels;
+  const int dk = H / c->n_heads, W = 2 * c->window_size + 1, gin = c->gin_channels;
+  L.add("enc_p.emb.weight", c->n_vocab, H);
+  for (int l = 0; l < c->n_layers; ++l) {
+    std::string a = S("enc_p.encoder.attn_layers.%d", l);
+    L.add(a + ".emb_rel_k", 1, W, dk);
+    L.add(a + ".emb_rel_v", 1, W, dk);
+    for (const char* n : {"conv_q", "conv_k", "conv_v", "conv_o"}) {
+      L.add(a + "." + n + ".weight", H, H, 1);
+      L.add(a + "." + n + ".bias", H);
+    }
+    L.add(S("enc_p.encoder.norm_layers_1.%d.gamma", l), H);
+    L.add(S("enc_p.encoder.norm_layers_1.%d.beta", l), H);
+    std::string f = S("enc_p.encoder.ffn_layers.%d", l);
+    L.add(f + ".conv_1.weight", F, H, c->kernel_size);
+    L.add(f + ".conv_1.bias", F);
+    L.add(f + ".conv_2.weight", H, F, c->kernel_size);
+    L.add(f + ".conv_2.bias", H);
+    L.add(S("enc_p.encoder.norm_layers_2.%d.gamma", l), H);
+    L.add(S("enc_p.encoder.norm_layers_2.%d.beta", l), H);
+  }
+  L.add("enc_p.proj.weight", 2 * I, H, 1);
+  L.add("enc_p.proj.bias", 2 * I);
+  if (has_g(c)) L.add("emb_g.weight", c->n_speakers, gin);
+
+  if (c->use_sdp) {
+    // StochasticDurationPredictor(hidden, 192, 3, 0.5, 4): filter_channels := in_channels
+    // (duration_predictors.py:166); only the tensors the reverse branch touches.
+    const int C = H;
+    L.add("dp.pre.weight", C, H, 1);
+    L.add("dp.pre.bias", C);
+    L.add("dp.proj.weight", C, C, 1);
+    L.add("dp.proj.bias", C);
+    add_dds(L, "dp.convs", C, 3, 3);
+    if (has_g(c)) {
+      L.add("dp.cond.weight", C, gin, 1);
+      L.add("dp.cond.bias", C);
+    }
+    L.add("dp.flows.0.m", 2, 1);
+    L.add("dp.flows.0.logs", 2, 1);
+    // flows = [EA, CF1, Flip, CF2, Flip, ...]; reverse drops CF1 (duration_predictors.py:255-256)
+    for (int f = 1; f < c->sdp_n_flows; ++f) {
+      std::string p = S("dp.flows.%d", 2 * f + 1);
+      L.add(p + ".pre.weight", C, 1, 1);
+      L.add(p + ".pre.bias", C);
+      add_dds(L, p + ".convs", C, 3, 3);
+      L.add(p + ".proj.weight", 29, C, 1);
+      L.add(p + ".proj.bias", 29);
+    }
+  } else {
+    const int Fd = c->dp_filter_channels;
+    L.add("dp.conv_1.weight", Fd, H, 3);
+    L.add("dp.conv_1.bias", Fd);
+    L.add("dp.norm_1.gamma", Fd);
+    L.add("dp.norm_1.beta", Fd);
+    L.add("dp.conv_2.weight", Fd, Fd, 3);
+    L.add("dp.conv_2.bias", Fd);
+    L.add("dp.norm_2.gamma", Fd);
+    L.add("dp.norm_2.beta", Fd);
+    L.add("dp.proj.weight", 1, Fd, 1);
+    L.add("dp.proj.bias", 1);
+    if (has_g(c)) {
+      L.add("dp.cond.weight", H, gin, 1);
+      L.add("dp.cond.bias", H);
+    }
+  }
+
+  for (int f = 0; f < c->flow_n_flows; ++f) {
+    std::string p = S("flow.flows.%d", 2 * f);
+    L.add(p + ".pre.weight", H, I / 2, 1);
+    L.add(p + ".pre.bias", H);
+    for (int i = 0; i < c->flow_wn_layers; ++i) {
+      L.add(p + S(".enc.in_layers.%d.weight", i), 2 * H, H, c->flow_kernel_size);
+      L.add(p + S(".enc.in_layers.%d.bias", i), 2 * H);
+      int rs = (i < c->flow_wn_layers - 1) ? 2 * H : H;
+      L.add(p + S(".enc.res_skip_layers.%d.weight", i), rs, H, 1);
+      L.add(p + S(".enc.res_skip_layers.%d.bias", i), rs);
+    }
+    if (has_g(c)) {
+      L.add(p + ".enc.cond_layer.weight", 2 * H * c->flow_wn_layers, gin, 1);
+      L.add(p + ".enc.cond_layer.bias", 2 * H * c->flow_wn_layers);
+    }
+    L.add(p + ".post.weight", I / 2, H, 1);
+    L.add(p + ".post.bias", I / 2);
+  }
+
+  const int C0 = c->upsample_initial_channel;
+  L.add("dec.conv_pre.weight", C0, I, 7);
+  L.add("dec.conv_pre.bias", C0);
+  int ch = C0;
+  for (int i = 0; i < c->n_upsamples; ++i) {
+    L.add(S("dec.ups.%d.weight", i), ch, ch / 2, c->upsample_kernel_sizes[i]);
+    L.add(S("dec.ups.%d.bias", i), ch / 2);
+    ch /= 2;
+    for (int j = 0; j < c->n_resblock_kernels; ++j) {
+      int n = i * c->n_resblock_kernels + j;
+      int k = c->resblock_kernel_sizes[j];
+      for (int d = 0; d < c->n_resblock_dilations; ++d) {
+        if (c->resblock == 1) {
+          L.add(S("dec.resblocks.%d.convs1.%d.weight", n, d), ch, ch, k);
+          L.add(S("dec.resblocks.%d.convs1.%d.bias", n, d), ch);
+          L.add(S("dec.resblocks.%d.convs2.%d.weight", n, d), ch, ch, k);
+          L.add(S("dec.resblocks.%d.convs2.%d.bias", n, d), ch);
+        } else {
+          L.add(S("dec.resblocks.%d.convs.%d.weight", n, d), ch, ch, k);
+          L.add(S("dec.resblocks.%d.convs.%d.bias", n, d), ch);
+        }
+      }
+    }
+  }
+  L.add("dec.conv_post.weight", 1, ch, 7);
+  if (has_g(c)) {
+    L.add("dec.cond.weight", C0, gin, 1);
+    L.add("dec.cond.bias", C0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------------------
+struct DDS {
+  const float *sep_w[3], *sep_b[3], *n1g[3], *n1b[3], *n2g[3], *n2b[3];
+  PackedConv c1x1[3];
+};
+
+struct EncLayer {
+  const float *rel_k, *rel_v, *n1g, *n1b, *n2g, *n2b;
+  PackedConv q, k, v, o, f1, f2;
+};
+
+struct ConvFlowW {
+  const float *pre_w, *pre_b;
+  DDS dds;
+  PackedConv proj;
+};
+
+struct FlowW {
+  PackedConv pre, post;
+  std::vector<PackedConv> in_layers, res_skip;
+  const float *cond_w = nullptr, *cond_b = nullptr;
+};
+
+struct RB {
+  std::vector<PackedConv> c1, c2;  // c2 empty for ResBlock2
+};
+
+}  // namespace wetts
+
+using namespace wetts;
+
+struct wetts_model {
+  wetts_config_t cfg;
+  Layout layout;
+  float* blob = nullptr;
+  std::vector<PackedConv*> all_packed;
+  // encoder
+  const float* emb = nullptr;
+  std::vector<EncLayer> enc;
+  PackedConv enc_proj;
+  const float* emb_g = nullptr;
+  // sdp
+  PackedConv sdp_pre, sdp_proj;
+  DDS sdp_dds;
+  const float *dp_cond_w = nullptr, *dp_cond_b = nullptr;
+  const float *ea_m = nullptr, *ea_logs = nullptr;
+  std::vector<ConvFlowW> cflows;  // CF2..CFn in module order
+  // dp
+  PackedConv dp_c1, dp_c2, dp_proj;
+  const float *dp_n1g = nullptr, *dp_n1b = nullptr, *dp_n2g = nullptr, *dp_n2b = nullptr;
+  // flow
+  std::vector<FlowW> flows;
+  // decoder
+  PackedConv conv_pre;
+  std::vector<PackedConv> ups;
+  std::vector<RB> rbs;
+  const float* conv_post_w = nullptr;
+  const float *dec_cond_w = nullptr, *dec_cond_b = nullptr;
+  int hop = 1;
+
+  const float* T(const std::string& name) const {
+    auto it = layout.index.find(name);
+    if (it == layout.index.end()) return nullptr;
+    return blob + layout.specs[it->second].offset;
+  }
+};
+
+namespace wetts {
+
+struct Bump {
+  char* base;
+  int64_t cap, off = 0;
+  bool ok = true;
+  Bump(void* p, int64_t c) : base((char*)p), cap(c) {}
+  template <typename T>
+  T* take(int64_t n) {
+    int64_t bytes = align_up(n * (int64_t)sizeof(T), 256);
+    if (off + bytes > cap) {
+      ok = false;
+      return nullptr;
+    }
+    T* r = (T*)(base + off);
+    off += bytes;
+    return r;
+  }
+};
+
+static int32_t pack(wetts_model* m, const std::string& wname, const std::string& bname, int Cout,
+                    int Cin, int k, int dil, int pad, int transposed, int up, hipStream_t s,
+                    PackedConv* pc) {
+  const float* w = m->T(wname);
+  WETTS_REQUIRE(w != nullptr, "tensor %s missing from layout", wname.c_str());
+  const float* b = bname.empty() ? nullptr : m->T(bname);
+  WETTS_TRY(pack_conv_weight(w, b, Cout, Cin, k, dil, pad, transposed, up, s, pc));
+  m->all_packed.push_back(pc);
+  return WETTS_OK;
+}
+
+static int32_t load_dds(wetts_model* m, const std::string& p, int C, hipStream_t s, DDS* d) {
+  for (int i = 0; i < 3; ++i) {
+    d->sep_w[i] = m->T(p + S(".convs_sep.%d.weight", i));
+    d->sep_b[i] = m->T(p + S(".convs_sep.%d.bias", i));
+    d->n1g[i] = m->T(p + S(".norms_1.%d.gamma", i));
+    d->n1b[i] = m->T(p + S(".norms_1.%d.beta", i));
+    d->n2g[i] = m->T(p + S(".norms_2.%d.gamma", i));
+    d->n2b[i] = m->T(p + S(".norms_2.%d.beta", i));
+    WETTS_TRY(pack(m, p + S(".convs_1x1.%d.weight", i), p + S(".convs_1x1.%d.bias", i), C, C, 1, 1,
+                   0, 0, 0, s, &d->c1x1[i]));
+  }
+  return WETTS_OK;
+}
+
+static int32_t build_model(wetts_model* m, hipStream_t s) {
+  const wetts_config_t* c = &m->cfg;
+  const int H = c->hidden_channels, I = c->inter_channels, F = c->filter_channels;
+  const int ks = c->kernel_size;
+  m->emb = m->T("enc_p.emb.weight");
+  m->enc.resize(c->n_layers);
+  for (int l = 0; l < c->n_layers; ++l) {
+    EncLayer& e = m->enc[l];
+    std::string a = S("enc_p.encoder.attn_layers.%d", l);
+    e.rel_k = m->T(a + ".emb_rel_k");
+    e.rel_v = m->T(a + ".emb_rel_v");
+    WETTS_TRY(pack(m, a + ".conv_q.weight", a + ".conv_q.bias", H, H, 1, 1, 0, 0, 0, s, &e.q));
+    WETTS_TRY(pack(m, a + ".conv_k.weight", a + ".conv_k.bias", H, H, 1, 1, 0, 0, 0, s, &e.k));
+    WETTS_TRY(pack(m, a + ".conv_v.weight", a + ".conv_v.bias", H, H, 1, 1, 0, 0, 0, s, &e.v));
+    WETTS_TRY(pack(m, a + ".conv_o.weight", a + ".conv_o.bias", H, H, 1, 1, 0, 0, 0, s, &e.o));
+    e.n1g = m->T(S("enc_p.encoder.norm_layers_1.%d.gamma", l));
+    e.n1b = m->T(S("enc_p.encoder.norm_layers_1.%d.beta", l));
+    e.n2g = m->T(S("enc_p.encoder.norm_layers_2.%d.gamma", l));
+    e.n2b = m->T(S("enc_p.encoder.norm_layers_2.%d.beta", l));
+    std::string f = S("enc_p.encoder.ffn_layers.%d", l);
+    // FFN _same_padding: pad_l = (k-1)//2, pad_r = k//2 (attentions.py:422-429)
+    WETTS_TRY(pack(m, f + ".conv_1.weight", f + ".conv_1.bias", F, H, ks, 1, (ks - 1) / 2, 0, 0, s,
+                   &e.f1));
+    WETTS_TRY(pack(m, f + ".conv_2.weight", f + ".conv_2.bias", H, F, ks, 1, (ks - 1) / 2, 0, 0, s,
+                   &e.f2));
+  }
+  WETTS_TRY(pack(m, "enc_p.proj.weight", "enc_p.proj.bias", 2 * I, H, 1, 1, 0, 0, 0, s,
+                 &m->enc_proj));
+  m->emb_g = m->T("emb_g.weight");
+
+  m->dp_cond_w = m->T("dp.cond.weight");
+  m->dp_cond_b = m->T("dp.cond.bias");
+  if (c->use_sdp) {
+    WETTS_TRY(pack(m, "dp.pre.weight", "dp.pre.bias", H, H, 1, 1, 0, 0, 0, s, &m->sdp_pre));
+    WETTS_TRY(pack(m, "dp.proj.weight", "dp.proj.bias", H, H, 1, 1, 0, 0, 0, s, &m->sdp_proj));
+    WETTS_TRY(load_dds(m, "dp.convs", H, s, &m->sdp_dds));
+    m->ea_m = m->T("dp.flows.0.m");
+    m->ea_logs = m->T("dp.flows.0.logs");
+    m->cflows.resize(c->sdp_n_flows - 1);
+    for (int f = 1; f < c->sdp_n_flows; ++f) {
+      ConvFlowW& cf = m->cflows[f - 1];
+      std::string p = S("dp.flows.%d", 2 * f + 1);
+      cf.pre_w = m->T(p + ".pre.weight");
+      cf.pre_b = m->T(p + ".pre.bias");
+      WETTS_TRY(load_dds(m, p + ".convs", H, s, &cf.dds));
+      WETTS_TRY(pack(m, p + ".proj.weight", p + ".proj.bias", 29, H, 1, 1, 0, 0, 0, s, &cf.proj));
+    }
+  } else {
+    const int Fd = c->dp_filter_channels;
+    WETTS_TRY(pack(m, "dp.conv_1.weight", "dp.conv_1.bias", Fd, H, 3, 1, 1, 0, 0, s, &m->dp_c1));
+    WETTS_TRY(pack(m, "dp.conv_2.weight", "dp.conv_2.bias", Fd, Fd, 3, 1, 1, 0, 0, s, &m->dp_c2));
+    WETTS_TRY(pack(m, "dp.proj.weight", "dp.proj.bias", 1, Fd, 1, 1, 0, 0, 0, s, &m->dp_proj));
+    m->dp_n1g = m->T("dp.norm_1.gamma");
+    m->dp_n1b = m->T("dp.norm_1.beta");
+    m->dp_n2g = m->T("dp.norm_2.gamma");
+    m->dp_n2b = m->T("dp.norm_2.beta");
+  }
+
+  m->flows.resize(c->flow_n_flows);
+  for (int f = 0; f < c->flow_n_flows; ++f) {
+    FlowW& fw = m->flows[f];
+    std::string p = S("flow.flows.%d", 2 * f);
+    WETTS_TRY(pack(m, p + ".pre.weight", p + ".pre.bias", H, I / 2, 1, 1, 0, 0, 0, s, &fw.pre));
+    WETTS_TRY(pack(m, p + ".post.weight", p + ".post.bias", I / 2, H, 1, 1, 0, 0, 0, s, &fw.post));
+    fw.in_layers.resize(c->flow_wn_layers);
+    fw.res_skip.resize(c->flow_wn_layers);
+    const int fk = c->flow_kernel_size;
+    for (int i = 0; i < c->flow_wn_layers; ++i) {
+      // WN dilation_rate = 1 (models.py:133-138) => dilation 1**i = 1, padding (k-1)/2
+      WETTS_TRY(pack(m, p + S(".enc.in_layers.%d.weight", i), p + S(".enc.in_layers.%d.bias", i),
+                     2 * H, H, fk, 1, (fk - 1) / 2, 0, 0, s, &fw.in_layers[i]));
+      int rs = (i < c->flow_wn_layers - 1) ? 2 * H : H;
+      WETTS_TRY(pack(m, p + S(".enc.res_skip_layers.%d.weight", i),
+                     p + S(".enc.res_skip_layers.%d.bias", i), rs, H, 1, 1, 0, 0, 0, s,
+                     &fw.res_skip[i]));
+    }
+    fw.cond_w = m->T(p + ".enc.cond_layer.weight");
+    fw.cond_b = m->T(p + ".enc.cond_layer.bias");
+  }
+
+  const int C0 = c->upsample_initial_channel;
+  WETTS_TRY(pack(m, "dec.conv_pre.weight", "dec.conv_pre.bias", C0, I, 7, 1, 3, 0, 0, s,
+                 &m->conv_pre));
+  m->ups.resize(c->n_upsamples);
+  m->rbs.resize(c->n_upsamples * c->n_resblock_kernels);
+  int ch = C0;
+  m->hop = 1;
+  for (int i = 0; i < c->n_upsamples; ++i) {
+    const int u = c->upsample_rates[i], uk = c->upsample_kernel_sizes[i];
+    WETTS_TRY(pack(m, S("dec.ups.%d.weight", i), S("dec.ups.%d.bias", i), ch / 2, ch, uk, 1,
+                   (uk - u) / 2, 1, u, s, &m->ups[i]));
+    ch /= 2;
+    m->hop *= u;
+    for (int j = 0; j < c->n_resblock_kernels; ++j) {
+      int n = i * c->n_resblock_kernels + j;
+      int k = c->resblock_kernel_sizes[j];
+      RB& rb = m->rbs[n];
+      rb.c1.resize(c->n_resblock_dilations);
+      if (c->resblock == 1) rb.c2.resize(c->n_resblock_dilations);
+      for (int d = 0; d < c->n_resblock_dilations; ++d) {
+        int dil = c->resblock_dilation_sizes[j][d];
+        int pad = (k * dil - dil) / 2;  // get_padding, commons.py:13-14
+        if (c->resblock == 1) {
+          WETTS_TRY(pack(m, S("dec.resblocks.%d.convs1.%d.weight", n, d),
+                         S("dec.resblocks.%d.convs1.%d.bias", n, d), ch, ch, k, dil, pad, 0, 0, s,
+                         &rb.c1[d]));
+          WETTS_TRY(pack(m, S("dec.resblocks.%d.convs2.%d.weight", n, d),
+                         S("dec.resblocks.%d.convs2.%d.bias", n, d), ch, ch, k, 1, (k - 1) / 2, 0,
+                         0, s, &rb.c2[d]));
+        } else {
+          WETTS_TRY(pack(m, S("dec.resblocks.%d.convs.%d.weight", n, d),
+                         S("dec.resblocks.%d.convs.%d.bias", n, d), ch, ch, k, dil, pad, 0, 0, s,
+                         &rb.c1[d]));
+        }
+      }
+    }
+  }
+  m->conv_post_w = m->T("dec.conv_post.weight");
+  m->dec_cond_w = m->T("dec.cond.weight");
+  m->dec_cond_b = m->T("dec.cond.bias");
+  return WETTS_OK;
+}
+
+// default-initialised ConvParams for a plain contiguous [B,C,T] -> [B,Cout,T] conv
+static ConvParams conv_io(const float* x, int Cin, int T, float* out, int Cout, int B) {
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.x_bs = (int64_t)Cin * T;
+  p.x_cs = T;
+  p.Tin = T;
+  p.in_rev_base = -1;
+  p.in_act = IN_NONE;
+  p.in_slope = 0.f;
+  p.out = out;
+  p.o_bs = (int64_t)Cout * T;
+  p.o_cs = T;
+  p.Tout = T;
+  p.out_act = OUT_NONE;
+  p.out_div = 1.f;
+  p.B = B;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace sizing
+// ---------------------------------------------------------------------------------------------
+static int64_t A256(int64_t n_floats) { return align_up(n_floats * 4, 256); }
+
+static int64_t ws_encoder(const wetts_config_t* c, int B, int Tx) {
+  const int64_t H = c->hidden_channels, F = c->filter_channels, nh = c->n_heads;
+  int64_t n = 0;
+  n += 5 * A256(B * H * Tx);          // q,k,v,att,y
+  n += A256(B * F * Tx);              // ffn hidden
+  n += A256(B * nh * (int64_t)Tx * Tx);  // scores
+  n += A256(B * H * Tx);              // x ping
+  return n;
+}
+
+static int64_t ws_sdp(const wetts_config_t* c, int B, int Tx) {
+  const int64_t H = c->hidden_channels;
+  return 5 * A256(B * H * Tx) + A256(B * 32 * Tx) + A256(B * 2 * Tx) + A256(B * H) + 256;
+}
+
+static int64_t ws_dp(const wetts_config_t* c, int B, int Tx) {
+  const int64_t H = c->hidden_channels, Fd = c->dp_filter_channels;
+  return A256(B * H * Tx) + 2 * A256(B * Fd * Tx) + A256(B * H);
+}
+
+static int64_t ws_flow(const wetts_config_t* c, int B, int Ty) {
+  const int64_t H = c->hidden_channels, I = c->inter_channels;
+  return 2 * A256(B * I * Ty) + 3 * A256(B * H * Ty) + 2 * A256(B * 2 * H * Ty) +
+         A256(B * (I / 2) * Ty) + A256(B * 2 * H * c->flow_wn_layers);
+}
+
+static int64_t dec_max_elems(const wetts_config_t* c, int B, int L) {
+  int64_t ch = c->upsample_initial_channel, len = L, mx = (int64_t)B * ch * len;
+  for (int i = 0; i < c->n_upsamples; ++i) {
+    ch /= 2;
+    len *= c->upsample_rates[i];
+    int64_t e = (int64_t)B * ch * len;
+    if (e > mx) mx = e;
+  }
+  return mx;
+}
+
+static int64_t ws_decoder(const wetts_config_t* c, int B, int L) {
+  return 5 * A256(dec_max_elems(c, B, L)) + A256((int64_t)B * c->upsample_initial_channel);
+}
+
+}  // namespace wetts
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int32_t wetts_abi_version(void) { return WETTS_ABI_VERSION; }
+const char* wetts_last_error(void) { return g_err; }
+
+int32_t wetts_blob_num_tensors(const wetts_config_t* cfg) {
+  if (validate_config(cfg) != WETTS_OK) return WETTS_E_INVALID;
+  Layout L;
+  build_layout(cfg, L);
+  return (int32_t)L.specs.size();
+}
+
+int32_t wetts_blob_tensor_info(const wetts_config_t* cfg, int32_t index, char* name_buf,
+                               size_t name_buf_len, int64_t* offset, int64_t* numel,
+                               int64_t shape[4]) {
+  WETTS_TRY(validate_config(cfg));
+  Layout L;
+  build_layout(cfg, L);
+  WETTS_REQUIRE(index >= 0 && index < (int32_t)L.specs.size(), "tensor index %d out of range",
+                index);
+  const TensorSpec& t = L.specs[index];
+  WETTS_REQUIRE(name_buf && name_buf_len > t.name.size(), "name buffer too small");
+  strcpy(name_buf, t.name.c_str());
+  if (offset) *offset = t.offset;
+  if (numel) *numel = t.numel;
+  if (shape)
+    for (int i = 0; i < 4; ++i) shape[i] = t.shape[i];
+  return WETTS_OK;
+}
+
+int64_t wetts_blob_numel(const wetts_config_t* cfg) {
+  if (validate_config(cfg) != WETTS_OK) return WETTS_E_INVALID;
+  Layout L;
+  build_layout(cfg, L);
+  return L.total;
+}
+
+int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t blob_numel,
+                     void* stream, wetts_model_t** out) {
+  WETTS_TRY(validate_config(cfg));
+  WETTS_REQUIRE(out != nullptr && blob_dev != nullptr, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  wetts_model* m = new wetts_model();
+  m->cfg = *cfg;
+  build_layout(cfg, m->layout);
+  if (blob_numel != m->layout.total) {
+    set_error("blob has %lld floats, layout needs %lld", (long long)blob_numel,
+              (long long)m->layout.total);
+    delete m;
+    return WETTS_E_INVALID;
+  }
+  hipError_t e = hipMalloc((void**)&m->blob, (size_t)blob_numel * sizeof(float));
+  if (e != hipSuccess) {
+    set_error("hipMalloc(blob) failed: %s", hipGetErrorString(e));
+    delete m;
+    return WETTS_E_HIP;
+  }
+  e = hipMemcpyAsync(m->blob, blob_dev, (size_t)blob_numel * sizeof(float),
+                     hipMemcpyDeviceToDevice, s);
+  int32_t r = (e == hipSuccess) ? build_model(m, s) : WETTS_E_HIP;
+  if (r == WETTS_OK) {
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      set_error("weight packing failed: %s", hipGetErrorString(e));
+      r = WETTS_E_HIP;
+    }
+  }
+  if (r != WETTS_OK) {
+    wetts_destroy(m);
+    return r;
+  }
+  *out = m;
+  return WETTS_OK;
+}
+
+void wetts_destroy(wetts_model_t* m) {
+  if (!m) return;
+  for (PackedConv* pc : m->all_packed) free_packed(pc);
+  if (m->blob) (void)hipFree(m->blob);
+  delete m;
+}
+
+int32_t wetts_hop_length(const wetts_model_t* m) { return m ? m->hop : WETTS_E_INVALID; }
+
+int64_t wetts_workspace_bytes(const wetts_model_t* m, int32_t B, int32_t Tx, int32_t Ty) {
+  if (!m || B < 0 || Tx < 0 || Ty < 0) return WETTS_E_INVALID;
+  const wetts_config_t* c = &m->cfg;
+  int64_t a = ws_encoder(c, B, Tx);
+  int64_t b = c->use_sdp ? ws_sdp(c, B, Tx) : ws_dp(c, B, Tx);
+  int64_t need = a > b ? a : b;
+  if (Ty > 0) {
+    int64_t f = ws_flow(c, B, Ty), d = ws_decoder(c, B, Ty);
+    if (f > need) need = f;
+    if (d > need) need = d;
+  }
+  return need + 4096;
+}
+
+int32_t wetts_speaker_embedding(const wetts_model_t* m, const int64_t* sid, int32_t B,
+                                float* g_out, void* stream) {
+  WETTS_REQUIRE(m && g_out, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int gin = m->cfg.gin_channels > 0 ? m->cfg.gin_channels : 1;
+  if (!has_g(&m->cfg)) {
+    WETTS_HIP_CHECK(hipMemsetAsync(g_out, 0, (size_t)B * gin * sizeof(float), s));
+    return WETTS_OK;
+  }
+  WETTS_REQUIRE(sid != nullptr, "sid required when n_speakers > 0");
+  return k_gather_rows(sid, m->emb_g, m->cfg.n_speakers, B, gin, g_out, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+int32_t wetts_text_encoder(const wetts_model_t* m, const int64_t* x, const int64_t* x_lengths,
+                           int32_t B, int32_t Tx, float* x_enc, float* stats, float* x_mask,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+  WETTS_REQUIRE(m && x && x_lengths && x_enc && stats && x_mask, "null argument");
+  if (B == 0 || Tx == 0) return WETTS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const wetts_config_t* c = &m->cfg;
+  const int H = c->hidden_channels, F = c->filter_channels, I = c->inter_channels;
+  const int nh = c->n_heads, dk = H / nh;
+  Bump ws(workspace, workspace_bytes);
+  float* q = ws.take<float>((int64_t)B * H * Tx);
+  float* k = ws.take<float>((int64_t)B * H * Tx);
+  float* v = ws.take<float>((int64_t)B * H * Tx);
+  float* att = ws.take<float>((int64_t)B * H * Tx);
+  float* y = ws.take<float>((int64_t)B * H * Tx);
+  float* hid = ws.take<float>((int64_t)B * F * Tx);
+  float* sc = ws.take<float>((int64_t)B * nh * Tx * Tx);
+  float* xb = ws.take<float>((int64_t)B * H * Tx);
+  if (!ws.ok) {
+    set_error("text_encoder: workspace too small (%lld bytes)", (long long)workspace_bytes);
+    return WETTS_E_WORKSPACE;
+  }
+  // x = emb(x)*sqrt(H), masked (encoders.py:48-53; Encoder.forward x = x * x_mask, attentions.py:72)
+  float* xa = x_enc;  // current activations live in xa
+  WETTS_TRY(k_embed_mask(x, x_lengths, m->emb, c->n_vocab, B, H, Tx, xa, x_mask, s));
+  for (int l = 0; l < c->n_layers; ++l) {
+    const EncLayer& e = m->enc[l];
+    const bool last = (l == c->n_layers - 1);
+    WETTS_TRY(launch_conv(e.q, conv_io(xa, H, Tx, q, H, B), s));
+    WETTS_TRY(launch_conv(e.k, conv_io(xa, H, Tx, k, H, B), s));
+    WETTS_TRY(launch_conv(e.v, conv_io(xa, H, Tx, v, H, B), s));
+    WETTS_TRY(k_rel_attention(q, k, v, x_mask, e.rel_k, e.rel_v, c->window_size, B, nh, dk, Tx, sc,
+                              att, s));
+    WETTS_TRY(launch_conv(e.o, conv_io(att, H, Tx, y, H, B), s));
+    // x = norm_layers_1(x + y)
+    WETTS_TRY(k_layernorm(xa, y, e.n1g, e.n1b, nullptr, nullptr, 0, B, H, Tx, xb, s));
+    // FFN: conv_1(pad(x*mask)) -> relu -> conv_2(pad(.*mask)) * mask
+    {
+      ConvParams p = conv_io(xb, H, Tx, hid, F, B);
+      p.in_mask = x_mask;
+      p.in_mask_stride = Tx;
+      p.out_act = OUT_RELU;
+      WETTS_TRY(launch_conv(e.f1, p, s));
+    }
+    {
+      ConvParams p = conv_io(hid, F, Tx, y, H, B);
+      p.in_mask = x_mask;
+      p.in_mask_stride = Tx;
+      p.out_mask = x_mask;
+      p.out_mask_stride = Tx;
+      WETTS_TRY(launch_conv(e.f2, p, s));
+    }
+    // x = norm_layers_2(x + y); the final `x = x * x_mask` is fused into the last layer
+    WETTS_TRY(k_layernorm(xb, y, e.n2g, e.n2b, nullptr, last ? x_mask : nullptr, 0, B, H, Tx, xa,
+                          s));
+  }
+  if (c->n_layers == 0) {
+    // Encoder with no layers still masks its input; embed_mask already did.
+  }
+  // stats = proj(x) * x_mask
+  ConvParams p = conv_io(xa, H, Tx, stats, 2 * I, B);
+  p.out_mask = x_mask;
+  p.out_mask_stride = Tx;
+  WETTS_TRY(launch_conv(m->enc_proj, p, s));
+  return WETTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+namespace wetts {
+// DDSConv.forward (duration_predictors.py:45-57); x is updated in place; `x + g` is the caller's.
+static int32_t run_dds(const DDS& d, float* x, const float* mask, int B, int C, int T, float* t1,
+                       float* t2, hipStream_t s) {
+  int dil = 1;
+  for (int i = 0; i < 3; ++i) {
+    WETTS_TRY(k_dwconv(x, mask, d.sep_w[i], d.sep_b[i], 3, dil, B, C, T, t1, s));
+    WETTS_TRY(k_layernorm(t1, nullptr, d.n1g[i], d.n1b[i], nullptr, nullptr, 1, B, C, T, t2, s));
+    WETTS_TRY(launch_conv(d.c1x1[i], conv_io(t2, C, T, t1, C, B), s));
+    // x = x + gelu(norm_2(y)); the trailing `x * x_mask` is fused into the last layer
+    WETTS_TRY(k_layernorm(t1, nullptr, d.n2g[i], d.n2b[i], x, i == 2 ? mask : nullptr, 1, B, C, T,
+                          x, s));
+    dil *= 3;
+  }
+  return WETTS_OK;
+}
+}  // namespace wetts
+
+int32_t wetts_duration_sdp(const wetts_model_t* m, const float* x_enc, const float* x_mask,
+                           const float* g, const float* eps_w, float noise_scale_w, int32_t B,
+                           int32_t Tx, float* logw, int32_t* status_dev, void* workspace,
+                           int64_t workspace_bytes, void* stream) {
+  WETTS_REQUIRE(m && x_enc && x_mask && eps_w && logw, "null argument");
+  WETTS_REQUIRE(m->cfg.use_sdp, "model was built with use_sdp=false");
+  if (B == 0 || Tx == 0) return WETTS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const wetts_config_t* c = &m->cfg;
+  const int H = c->hidden_channels;
+  Bump ws(workspace, workspace_bytes);
+  float* xd = ws.take<float>((int64_t)B * H * Tx);
+  float* t1 = ws.take<float>((int64_t)B * H * Tx);
+  float* t2 = ws.take<float>((int64_t)B * H * Tx);
+  float* hh = ws.take<float>((int64_t)B * H * Tx);
+  float* xg = ws.take<float>((int64_t)B * H * Tx);
+  float* hp = ws.take<float>((int64_t)B * 32 * Tx);
+  float* z = ws.take<float>((int64_t)B * 2 * Tx);
+  float* cond = ws.take<float>((int64_t)B * H);
+  if (!ws.ok) {
+    set_error("duration_sdp: workspace too small");
+    return WETTS_E_WORKSPACE;
+  }
+  if (status_dev) WETTS_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(int32_t), s));
+  // x = pre(x) + cond(g)
+  {
+    ConvParams p = conv_io(x_enc, H, Tx, xd, H, B);
+    if (has_g(c) && g) {
+      WETTS_TRY(k_cond_linear(g, m->dp_cond_w, m->dp_cond_b, B, H, c->gin_channels, cond, s));
+      p.bias_b = cond;
+      p.bias_b_stride = H;
+    }
+    WETTS_TRY(launch_conv(m->sdp_pre, p, s));
+  }
+  WETTS_TRY(run_dds(m->sdp_dds, xd, x_mask, B, H, Tx, t1, t2, s));
+  {
+    ConvParams p = conv_io(xd, H, Tx, xg, H, B);  // x = proj(x) * x_mask
+    p.out_mask = x_mask;
+    p.out_mask_stride = Tx;
+    WETTS_TRY(launch_conv(m->sdp_proj, p, s));
+  }
+  // z = randn * noise_scale  (not masked, duration_predictors.py:257-258)
+  WETTS_TRY(k_scale(eps_w, noise_scale_w, (int64_t)B * 2 * Tx, z, s));
+  // reversed flows with the useless CF1 removed: [Flip, CFn, Flip, ..., CF2, Flip, EA]
+  int swapped = 0;  // logical channel c lives at physical channel c ^ swapped
+  for (int f = (int)m->cflows.size() - 1; f >= 0; --f) {
+    swapped ^= 1;  // Flip
+    const ConvFlowW& cf = m->cflows[f];
+    const int ch0 = 0 ^ swapped, ch1 = 1 ^ swapped;
+    // h = pre(x0); DDSConv(h, mask, g=x): h = h + g first
+    WETTS_TRY(k_convflow_pre(z, ch0, cf.pre_w, cf.pre_b, xg, B, H, Tx, hh, s));
+    WETTS_TRY(run_dds(cf.dds, hh, x_mask, B, H, Tx, t1, t2, s));
+    {
+      ConvParams p = conv_io(hh, H, Tx, hp, 29, B);  // h = proj(h) * x_mask
+      p.out_mask = x_mask;
+      p.out_mask_stride = Tx;
+      WETTS_TRY(launch_conv(cf.proj, p, s));
+    }
+    WETTS_TRY(k_spline_inverse(z, ch0, ch1, hp, x_mask, 10, 5.0f, (float)sqrt((double)H), B, Tx,
+                               status_dev, s));
+  }
+  swapped ^= 1;  // the Flip in front of ElementwiseAffine
+  // EA reverse, then logw = z0
+  WETTS_TRY(k_affine_reverse(z, 0 ^ swapped, m->ea_m, m->ea_logs, 0, x_mask, B, Tx, logw, s));
+  return WETTS_OK;
+}
+
+int32_t wetts_duration_dp(const wetts_model_t* m, const float* x_enc, const float* x_mask,
+                          const float* g, int32_t B, int32_t Tx, float* logw, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+  WETTS_REQUIRE(m && x_enc && x_mask && logw, "null argument");
+  WETTS_REQUIRE(!m->cfg.use_sdp, "model was built with use_sdp=true");
+  if (B == 0 || Tx == 0) return WETTS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const wetts_config_t* c = &m->cfg;
+  const int H = c->hidden_channels, Fd = c->dp_filter_channels;
+  Bump ws(workspace, workspace_bytes);
+  float* xc = ws.take<float>((int64_t)B * H * Tx);
+  float* a = ws.take<float>((int64_t)B * Fd * Tx);
+  float* b = ws.take<float>((int64_t)B * Fd * Tx);
+  float* cond = ws.take<float>((int64_t)B * H);
+  if (!ws.ok) {
+    set_error("duration_dp: workspace too small");
+    return WETTS_E_WORKSPACE;
+  }
+  const float* xin = x_enc;
+  if (has_g(c) && g) {  // x = x + cond(g)
+    WETTS_TRY(k_cond_linear(g, m->dp_cond_w, m->dp_cond_b, B, H, c->gin_channels, cond, s));
+    WETTS_HIP_CHECK(hipMemcpyAsync(xc, x_enc, (size_t)B * H * Tx * 4, hipMemcpyDeviceToDevice, s));
+    WETTS_TRY(k_add_bias_b(xc, cond, B, H, Tx, s));
+    xin = xc;
+  }
+  {
+    ConvParams p = conv_io(xin, H, Tx, a, Fd, B);  // relu(conv_1(x*mask))
+    p.in_mask = x_mask;
+    p.in_mask_stride = Tx;
+    p.out_act = OUT_RELU;
+    WETTS_TRY(launch_conv(m->dp_c1, p, s));
+  }
+  WETTS_TRY(k_layernorm(a, nullptr, m->dp_n1g, m->dp_n1b, nullptr, nullptr, 0, B, Fd, Tx, b, s));
+  {
+    ConvParams p = conv_io(b, Fd, Tx, a, Fd, B);
+    p.in_mask = x_mask;
+    p.in_mask_stride = Tx;
+    p.out_act = OUT_RELU;
+    WETTS_TRY(launch_conv(m->dp_c2, p, s));
+  }
+  WETTS_TRY(k_layernorm(a, nullptr, m->dp_n2g, m->dp_n2b, nullptr, nullptr, 0, B, Fd, Tx, b, s));
+  {
+    ConvParams p = conv_io(b, Fd, Tx, logw, 1, B);  // proj(x*mask) * mask
+    p.in_mask = x_mask;
+    p.in_mask_stride = Tx;
+    p.out_mask = x_mask;
+    p.out_mask_stride = Tx;
+    WETTS_TRY(launch_conv(m->dp_proj, p, s));
+  }
+  return WETTS_OK;
+}
+
+int32_t wetts_durations_to_lengths(const float* logw, const float* x_mask, float length_scale,
+                                   int32_t B, int32_t Tx, float* w_ceil, float* cum,
+                                   int64_t* y_lengths, void* stream) {
+  WETTS_REQUIRE(logw && x_mask && w_ceil && cum && y_lengths, "null argument");
+  return k_durations_to_lengths(logw, x_mask, length_scale, B, Tx, w_ceil, cum, y_lengths,
+                                (hipStream_t)stream);
+}
+
+int32_t wetts_length_regulate(const wetts_model_t* m, const float* stats, const float* cum,
+                              const float* x_mask, const int64_t* y_lengths, const float* eps_z,
+                              int64_t eps_batch_stride, int64_t eps_channel_stride,
+                              float noise_scale, int32_t B, int32_t Tx, int32_t Ty,
+                              int32_t* frame2phone, float* y_mask, float* attn, float* m_p_exp,
+                              float* logs_p_exp, float* z_p, void* stream) {
+  WETTS_REQUIRE(m && stats && cum && y_lengths && eps_z && frame2phone && y_mask && z_p,
+                "null argument");
+  (void)x_mask;
+  hipStream_t s = (hipStream_t)stream;
+  const int I = m->cfg.inter_channels;
+  WETTS_TRY(k_frame_index(cum, y_lengths, B, Tx, Ty, frame2phone, y_mask, s));
+  WETTS_TRY(k_expand_prior(stats, frame2phone, eps_z, eps_batch_stride, eps_channel_stride,
+                           noise_scale, B, I, Tx, Ty, m_p_exp, logs_p_exp, z_p, s));
+  if (attn) WETTS_TRY(k_attn_path(frame2phone, B, Tx, Ty, attn, s));
+  return WETTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float* y_mask,
+                           const float* g, int32_t B, int32_t Ty, float* z_out, void* workspace,
+                           int64_t workspace_bytes, void* stream) {
+  WETTS_REQUIRE(m && z_p && y_mask && z_out, "null argument");
+  if (B == 0 || Ty == 0) return WETTS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const wetts_config_t* c = &m->cfg;
+  const int H = c->hidden_channels, I = c->inter_channels, NL = c->flow_wn_layers;
+  Bump ws(workspace, workspace_bytes);
+  float* xa = ws.take<float>((int64_t)B * I * Ty);
+  float* xb = ws.take<float>((int64_t)B * I * Ty);
+  float* h = ws.take<float>((int64_t)B * H * Ty);
+  float* acts = ws.take<float>((int64_t)B * H * Ty);
+  float* skip = ws.take<float>((int64_t)B * H * Ty);
+  float* xin = ws.take<float>((int64_t)B * 2 * H * Ty);
+  float* rs = ws.take<float>((int64_t)B * 2 * H * Ty);
+  float* mm = ws.take<float>((int64_t)B * (I / 2) * Ty);
+  float* gl = ws.take<float>((int64_t)B * 2 * H * NL);
+  if (!ws.ok) {
+    set_error("flow_reverse: workspace too small");
+    return WETTS_E_WORKSPACE;
+  }
+  const float* cur = z_p;
+  for (int f = c->flow_n_flows - 1; f >= 0; --f) {
+    const FlowW& fw = m->flows[f];
+    float* dst = (f == 0) ? z_out : ((cur == xa) ? xb : xa);
+    // Flip then ResidualCouplingLayer(reverse): x0 = flipped[:I/2] = cur[I-1 .. I/2]
+    {
+      ConvParams p = conv_io(cur, I, Ty, h, H, B);  // h = pre(x0) * mask
+      p.in_rev_base = I - 1;
+      p.out_mask = y_mask;
+      p.out_mask_stride = Ty;
+      WETTS_TRY(launch_conv(fw.pre, p, s));
+    }
+    const bool use_g = has_g(c) && g;
+    if (use_g)
+      WETTS_TRY(k_cond_linear(g, fw.cond_w, fw.cond_b, B, 2 * H * NL, c->gin_channels, gl, s));
+    for (int i = 0; i < NL; ++i) {
+      {
+        ConvParams p = conv_io(h, H, Ty, xin, 2 * H, B);  // x_in = in_layer(h) (+ g_l)
+        if (use_g) {
+          p.bias_b = gl + (int64_t)i * 2 * H;
+          p.bias_b_stride = (int64_t)2 * H * NL;
+        }
+        WETTS_TRY(launch_conv(fw.in_layers[i], p, s));
+      }
+      WETTS_TRY(k_gate(xin, B, H, Ty, acts, s));
+      const bool last = (i == NL - 1);
+      WETTS_TRY(launch_conv(fw.res_skip[i], conv_io(acts, H, Ty, rs, last ? H : 2 * H, B), s));
+      WETTS_TRY(k_wn_update(rs, h, skip, y_mask, last ? 1 : 0, i == 0 ? 1 : 0, B, H, Ty, s));
+    }
+    {
+      ConvParams p = conv_io(skip, H, Ty, mm, I / 2, B);  // m = post(output*mask) * mask
+      p.in_mask = y_mask;
+      p.in_mask_stride = Ty;
+      p.out_mask = y_mask;
+      p.out_mask_stride = Ty;
+      WETTS_TRY(launch_conv(fw.post, p, s));
+    }
+    WETTS_TRY(k_coupling_flip(cur, mm, y_mask, B, I, Ty, dst, s));
+    cur = dst;
+  }
+  return WETTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+namespace wetts {
+struct DecTiming {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  double mrf_ms = 0;
+  int launches = 0;
+  bool on = false;
+};
+
+static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, int64_t z_cs,
+                           const float* y_mask, int64_t mask_stride, const float* g, int B, int L,
+                           float* audio, void* workspace, int64_t workspace_bytes, hipStream_t s,
+                           DecTiming* tm) {
+  const wetts_config_t* c = &m->cfg;
+  const int I = c->inter_channels, C0 = c->upsample_initial_channel;
+  const int64_t mx = dec_max_elems(c, B, L);
+  Bump ws(workspace, workspace_bytes);
+  float* bx = ws.take<float>(mx);
+  float* bt = ws.take<float>(mx);
+  float* ba = ws.take<float>(mx);
+  float* bb = ws.take<float>(mx);
+  float* bs = ws.take<float>(mx);
+  float* cond = ws.take<float>((int64_t)B * C0);
+  if (!ws.ok) {
+    set_error("hifigan: workspace too small (need %lld bytes)",
+              (long long)ws_decoder(c, B, L));
+    return WETTS_E_WORKSPACE;
+  }
+  // x = conv_pre(z [* y_mask]) + cond(g)
+  {
+    ConvParams p = conv_io(z, I, L, bx, C0, B);
+    p.x_bs = z_bs;
+    p.x_cs = z_cs;
+    if (y_mask) {
+      p.in_mask = y_mask;
+      p.in_mask_stride = mask_stride;
+    }
+    if (has_g(c) && g) {
+      WETTS_TRY(k_cond_linear(g, m->dec_cond_w, m->dec_cond_b, B, C0, c->gin_channels, cond, s));
+      p.bias_b = cond;
+      p.bias_b_stride = C0;
+    }
+    WETTS_TRY(launch_conv(m->conv_pre, p, s));
+  }
+  int ch = C0, len = L;
+  float* x = bx;   // stage input / MRF output
+  float* xs = bs;  // MRF accumulator
+  const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
+  for (int i = 0; i < c->n_upsamples; ++i) {
+    const int u = c->upsample_rates[i];
+    // x = ups[i](leaky_relu(x, 0.1))
+    {
+      ConvParams p = conv_io(x, ch, len, bt, ch / 2, B);
+      p.in_act = IN_LRELU;
+      p.in_slope = 0.1f;
+      p.Tout = len * u;  // (len-1)*u - 2*pad + k with pad=(k-u)/2
+      p.o_bs = (int64_t)(ch / 2) * len * u;
+      p.o_cs = (int64_t)len * u;
+      WETTS_TRY(launch_conv(m->ups[i], p, s));
+    }
+    ch /= 2;
+    len *= u;
+    float* xu = bt;                    // upsampled x, input of every resblock of this stage
+    float* fa = ba;                    // resblock running x
+    float* fb = bb;                    // second running buffer
+    float* ft = (x == bx) ? bx : bs;   // conv1 output scratch (old stage input is dead now)
+    float* xsum = (x == bx) ? bs : bx; // MRF accumulator for this stage
+    (void)xs;
+    if (tm && tm->on) WETTS_HIP_CHECK(hipEventRecord(tm->e0, s));
+    for (int j = 0; j < nk; ++j) {
+      const RB& rb = m->rbs[i * nk + j];
+      const float* rx = xu;  // current resblock x
+      for (int d = 0; d < nd; ++d) {
+        const bool last_d = (d == nd - 1);
+        // where does this unit's output go?
+        float* outp;
+        int accum = 0;
+        float odiv = 1.f;
+        if (last_d) {
+          outp = xsum;
+          accum = (j > 0) ? 1 : 0;
+          odiv = (j == nk - 1) ? (float)nk : 1.f;  // x = xs / self.num_kernels
+        } else {
+          outp = (rx == fa) ? fb : fa;
+        }
+        if (c->resblock == 1) {
+          // xt = c1(lrelu(x)); x = c2(lrelu(xt)) + x
+          ConvParams p1 = conv_io(rx, ch, len, ft, ch, B);
+          p1.in_act = IN_LRELU;
+          p1.in_slope = 0.1f;
+          WETTS_TRY(launch_conv(rb.c1[d], p1, s));
+          ConvParams p2 = conv_io(ft, ch, len, outp, ch, B);
+          p2.in_act = IN_LRELU;
+          p2.in_slope = 0.1f;
+          p2.res = rx;
+          p2.r_bs = (int64_t)ch * len;
+          p2.r_cs = len;
+          p2.accum = accum;
+          p2.out_div = odiv;
+          WETTS_TRY(launch_conv(rb.c2[d], p2, s));
+          if (tm && tm->on) tm->launches += 2;
+        } else {
+          // x = c(lrelu(x)) + x
+          ConvParams p1 = conv_io(rx, ch, len, outp, ch, B);
+          p1.in_act = IN_LRELU;
+          p1.in_slope = 0.1f;
+          p1.res = rx;
+          p1.r_bs = (int64_t)ch * len;
+          p1.r_cs = len;
+          p1.accum = accum;
+          p1.out_div = odiv;
+          WETTS_TRY(launch_conv(rb.c1[d], p1, s));
+          if (tm && tm->on) tm->launches += 1;
+        }
+        rx = outp;
+      }
+    }
+    if (tm && tm->on) {
+      WETTS_HIP_CHECK(hipEventRecord(tm->e1, s));
+      WETTS_HIP_CHECK(hipEventSynchronize(tm->e1));
+      float ms = 0.f;
+      WETTS_HIP_CHECK(hipEventElapsedTime(&ms, tm->e0, tm->e1));
+      tm->mrf_ms += ms;
+    }
+    x = xsum;
+  }
+  // x = tanh(conv_post(leaky_relu(x)))   (default slope 0.01, decoders.py:78)
+  WETTS_TRY(k_conv_post_tanh(x, m->conv_post_w, 7, B, ch, len, audio, s));
+  return WETTS_OK;
+}
+}  // namespace wetts
+
+int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_stride,
+                      int64_t z_channel_stride, const float* y_mask, int64_t mask_stride,
+                      const float* g, int32_t B, int32_t L, float* audio, void* workspace,
+                      int64_t workspace_bytes, void* stream) {
+  WETTS_REQUIRE(m && z && audio, "null argument");
+  if (B == 0 || L == 0) return WETTS_OK;
+  return run_hifigan(m, z, z_batch_stride, z_channel_stride, y_mask, mask_stride, g, B, L, audio,
+                     workspace, workspace_bytes, (hipStream_t)stream, nullptr);
+}
+
+int32_t wetts_profile_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_stride,
+                              int64_t z_channel_stride, const float* g, int32_t B, int32_t L,
+                              float* audio, void* workspace, int64_t workspace_bytes, void* stream,
+                              double* mrf_ms, double* total_ms, int32_t* mrf_launches) {
+  WETTS_REQUIRE(m && z && audio && mrf_ms && total_ms && mrf_launches, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  DecTiming tm;
+  tm.on = true;
+  hipEvent_t t0, t1;
+  WETTS_HIP_CHECK(hipEventCreate(&tm.e0));
+  WETTS_HIP_CHECK(hipEventCreate(&tm.e1));
+  WETTS_HIP_CHECK(hipEventCreate(&t0));
+  WETTS_HIP_CHECK(hipEventCreate(&t1));
+  WETTS_HIP_CHECK(hipEventRecord(t0, s));
+  int32_t r = run_hifigan(m, z, z_batch_stride, z_channel_stride, nullptr, 0, g, B, L, audio,
+                          workspace, workspace_bytes, s, &tm);
+  if (r == WETTS_OK) {
+    WETTS_HIP_CHECK(hipEventRecord(t1, s));
+    WETTS_HIP_CHECK(hipEventSynchronize(t1));
+    float ms = 0.f;
+    WETTS_HIP_CHECK(hipEventElapsedTime(&ms, t0, t1));
+    *total_ms = ms;
+    *mrf_ms = tm.mrf_ms;
+    *mrf_launches = tm.launches;
+  }
+  (void)hipEventDestroy(tm.e0);
+  (void)hipEventDestroy(tm.e1);
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  return r;
+}
+
+int32_t wetts_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, int32_t B,
+                  int32_t Ty, int32_t Tx, int32_t* path, void* workspace, int64_t workspace_bytes,
+                  void* stream) {
+  WETTS_REQUIRE(neg_cent && t_ys && t_xs && path, "null argument");
+  if (B == 0 || Ty == 0 || Tx == 0) return WETTS_OK;
+  if (workspace == nullptr || workspace_bytes < (int64_t)B * Ty * Tx * 4) {
+    set_error("mas: workspace too small (need %lld bytes)", (long long)B * Ty * Tx * 4);
+    return WETTS_E_WORKSPACE;
+  }
+  return k_mas(neg_cent, t_ys, t_xs, B, Ty, Tx, path, (float*)workspace, (hipStream_t)stream);
+}
+
+int32_t wetts_audio_to_int16(const float* audio, const int64_t* lengths_samples, int32_t B,
+                             int64_t L, int16_t* pcm, void* stream) {
+  WETTS_REQUIRE(audio && pcm, "null argument");
+  return k_audio_to_int16(audio, lengths_samples, B, L, pcm, (hipStream_t)stream);
+}
+
+int32_t wetts_hifigan_cost(const wetts_config_t* c, double* flops_per_frame,
+                           double* bytes_per_frame_perconv, double* mrf_flops_per_frame,
+                           double* mrf_bytes_per_frame_perconv) {
+  WETTS_TRY(validate_config(c));
+  // SURVEY.md §8(d) formulas (per input frame; L = samples per frame at the current stage)
+  double mac = 0, elems = 0, mrf_mac = 0, mrf_elems = 0;
+  const double C0 = c->upsample_initial_channel, I = c->inter_channels;
+  mac += I * C0 * 7;
+  elems += I + C0;
+  double ch = C0, Ls = 1;
+  const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
+  const int nconv = (c->resblock == 1 ? 2 : 1) * nd, nres = nd;
+  for (int i = 0; i < c->n_upsamples; ++i) {
+    double co = ch / 2, Lo = Ls * c->upsample_rates[i];
+    mac += ch * co * c->upsample_kernel_sizes[i] * Ls;
+    elems += ch * Ls + co * Lo;
+    ch = co;
+    Ls = Lo;
+    for (int j = 0; j < nk; ++j) {
+      double m1 = (double)nconv * ch * ch * c->resblock_kernel_sizes[j] * Ls;
+      double e1 = (double)nconv * 2 * ch * Ls + (double)nres * ch * Ls;
+      mrf_mac += m1;
+      mrf_elems += e1;
+    }
+    mrf_elems += (double)(nk + 1) * ch * Ls;
+  }
+  mac += mrf_mac + ch * 7 * Ls;
+  elems += mrf_elems + ch * Ls + Ls;
+  if (flops_per_frame) *flops_per_frame = 2 * mac;
+  if (bytes_per_frame_perconv) *bytes_per_frame_perconv = 4 * elems;
+  if (mrf_flops_per_frame) *mrf_flops_per_frame = 2 * mrf_mac;
+  if (mrf_bytes_per_frame_perconv) *mrf_bytes_per_frame_perconv = 4 * mrf_elems;
+  return WETTS_OK;
+}
+
+int64_t wetts_infer_workspace_bytes(const wetts_model_t* m, int32_t B, int32_t Tx,
+                                    int32_t max_frames) {
+  if (!m || B < 0 || Tx < 0 || max_frames < 0) return WETTS_E_INVALID;
+  const wetts_config_t* c = &m->cfg;
+  const int64_t H = c->hidden_channels, I = c->inter_channels;
+  const int64_t gin = c->gin_channels > 0 ? c->gin_channels : 1;
+  int64_t n = A256(B * gin) + A256(B * H * Tx) + A256(B * 2 * I * Tx) + 4 * A256((int64_t)B * Tx) +
+              align_up((int64_t)B * 8, 256) + 2 * A256((int64_t)B * max_frames) +
+              2 * A256(B * I * (int64_t)max_frames);
+  return n + wetts_workspace_bytes(m, B, Tx, max_frames);
+}
+
+int32_t wetts_infer(const wetts_model_t* m, const int64_t* x, const int64_t* x_lengths,
+                    const int64_t* sid, const float* eps_w, const float* eps_z,
+                    float noise_scale, float length_scale, float noise_scale_w, int32_t B,
+                    int32_t Tx, int32_t max_frames, float* audio, int64_t* y_lengths_host,
+                    int32_t* frames_out, void* workspace, int64_t workspace_bytes, void* stream) {
+  WETTS_REQUIRE(m && x && x_lengths && eps_z && audio && y_lengths_host && frames_out,
+                "null argument");
+  WETTS_REQUIRE(B > 0 && Tx > 0 && max_frames > 0, "empty batch");
+  hipStream_t s = (hipStream_t)stream;
+  const wetts_config_t* c = &m->cfg;
+  const int H = c->hidden_channels, I = c->inter_channels;
+  const int gin = c->gin_channels > 0 ? c->gin_channels : 1;
+  // persistent region at the head of the workspace, stage scratch after it
+  Bump ws(workspace, workspace_bytes);
+  float* g = ws.take<float>((int64_t)B * gin);
+  float* x_enc = ws.take<float>((int64_t)B * H * Tx);
+  float* stats = ws.take<float>((int64_t)B * 2 * I * Tx);
+  float* x_mask = ws.take<float>((int64_t)B * Tx);
+  float* logw = ws.take<float>((int64_t)B * Tx);
+  float* w_ceil = ws.take<float>((int64_t)B * Tx);
+  float* cum = ws.take<float>((int64_t)B * Tx);
+  int64_t* ylen = ws.take<int64_t>(B);
+  int32_t* f2p = ws.take<int32_t>((int64_t)B * max_frames);
+  float* y_mask = ws.take<float>((int64_t)B * max_frames);
+  float* z_p = ws.take<float>((int64_t)B * I * max_frames);
+  float* z = ws.take<float>((int64_t)B * I * max_frames);
+  if (!ws.ok) {
+    set_error("infer: workspace too small");
+    return WETTS_E_WORKSPACE;
+  }
+  void* scratch = (char*)workspace + ws.off;
+  const int64_t scratch_bytes = workspace_bytes - ws.off;
+  WETTS_TRY(wetts_speaker_embedding(m, sid, B, g, stream));
+  const float* gp = has_g(c) ? g : nullptr;
+  WETTS_TRY(wetts_text_encoder(m, x, x_lengths, B, Tx, x_enc, stats, x_mask, scratch,
+                               scratch_bytes, stream));
+  if (c->use_sdp) {
+    WETTS_REQUIRE(eps_w != nullptr, "eps_w required for the stochastic duration predictor");
+    WETTS_TRY(wetts_duration_sdp(m, x_enc, x_mask, gp, eps_w, noise_scale_w, B, Tx, logw, nullptr,
+                                 scratch, scratch_bytes, stream));
+  } else {
+    WETTS_TRY(wetts_duration_dp(m, x_enc, x_mask, gp, B, Tx, logw, scratch, scratch_bytes, stream));
+  }
+  WETTS_TRY(wetts_durations_to_lengths(logw, x_mask, length_scale, B, Tx, w_ceil, cum, ylen,
+                                       stream));
+  WETTS_HIP_CHECK(hipMemcpyAsync(y_lengths_host, ylen, (size_t)B * sizeof(int64_t),
+                                 hipMemcpyDeviceToHost, s));
+  WETTS_HIP_CHECK(hipStreamSynchronize(s));  // commons.py:114-115 `length.max()`
+  int64_t Ty = 1;
+  for (int b = 0; b < B; ++b)
+    if (y_lengths_host[b] > Ty) Ty = y_lengths_host[b];
+  *frames_out = (int32_t)Ty;
+  if (Ty > max_frames) {
+    set_error("infer: predicted %lld frames > capacity %d", (long long)Ty, max_frames);
+    return WETTS_E_WORKSPACE;
+  }
+  WETTS_TRY(wetts_length_regulate(m, stats, cum, x_mask, ylen, eps_z, (int64_t)I * max_frames,
+                                  max_frames, noise_scale, B, Tx, (int)Ty, f2p, y_mask, nullptr,
+                                  nullptr, nullptr, z_p, stream));
+  WETTS_TRY(wetts_flow_reverse(m, z_p, y_mask, gp, B, (int)Ty, z, scratch, scratch_bytes, stream));
+  // o = dec((z * y_mask), g); audio rows are packed with stride Ty*hop
+  WETTS_TRY(wetts_hifigan(m, z, (int64_t)I * Ty, Ty, y_mask, Ty, gp, B, (int)Ty, audio, scratch,
+                          scratch_bytes, stream));
+  return WETTS_OK;
+}
+
+}  // extern "C"
