@@ -1,0 +1,141 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/wetts_hip.h declares,
+the blob layout agrees with the reference's state_dict, host logic behaves."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+from wetts_amd import _lib, checkpoint, config, synth
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include",
+                      "wetts_hip.h")
+
+
+def test_library_exports_every_declared_symbol():
+    src = open(HEADER).read()
+    declared = set(re.findall(r"\b(wetts_[a-z0-9_]+)\s*\(", src))
+    declared -= {"wetts_config", "wetts_model"}
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert _lib.load().wetts_abi_version() == 1
+
+
+@pytest.mark.parametrize("mname", ["v1", "v2", "v3", "stress48k", "tiny", "tiny_dp"])
+def test_blob_layout_is_consistent(mname):
+    cfg = config.make_config(config.MODEL_CONFIGS[mname], 100, 4)
+    lay = checkpoint.blob_layout(cfg)
+    names = [n for n, *_ in lay]
+    assert len(set(names)) == len(names)
+    end = 0
+    for n, off, numel, shape in lay:
+        assert off >= end and off % 64 == 0 and numel == int(np.prod(shape))
+        end = off + numel
+    assert checkpoint.blob_numel(cfg) >= end
+
+
+def test_layout_names_and_shapes_match_reference_state_dict():
+    """Golden list of the reference's own state_dict keys/shapes (dumped from the real
+    SynthesizerTrn in the build container) covers every blob tensor after weight-norm folding."""
+    from oracle import ref_import
+    if not ref_import.available():
+        pytest.skip("reference not present on this box")
+    import contextlib, io
+    S, *_ = ref_import.import_reference()
+    for mname, nspk in [("v1", 1), ("v3", 2)]:
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = S(50, 513, 32, n_speakers=nspk, **config.MODEL_CONFIGS[mname])
+        ref = {k: tuple(v.shape) for k, v in checkpoint.fold_weight_norm(net.state_dict()).items()}
+        cfg = config.make_config(config.MODEL_CONFIGS[mname], 50, nspk)
+        for n, _, _, shape in checkpoint.blob_layout(cfg):
+            assert n in ref, n
+            assert ref[n] == shape, (n, ref[n], shape)
+        # and nothing on the infer path is left out
+        ours = {n for n, *_ in checkpoint.blob_layout(cfg)}
+        skipped = [k for k in ref if k not in ours and not (
+            k.startswith("enc_q.") or k.startswith("dp.post_") or k.startswith("dp.flows.1."))]
+        assert not skipped, skipped
+
+
+def test_fold_weight_norm_matches_torch():
+    conv = torch.nn.utils.weight_norm(torch.nn.Conv1d(6, 8, 3))
+    convt = torch.nn.utils.weight_norm(torch.nn.ConvTranspose1d(6, 4, 4, 2))
+    with torch.no_grad():
+        conv.weight_g.mul_(1.3)
+        convt.weight_g.mul_(0.7)
+    x = torch.randn(2, 6, 11)
+    ref_w, ref_wt = conv(x), convt(x)
+    f = checkpoint.fold_weight_norm({**{"a." + k: v for k, v in conv.state_dict().items()},
+                                     **{"b." + k: v for k, v in convt.state_dict().items()}})
+    got = torch.nn.functional.conv1d(x, f["a.weight"], f["a.bias"])
+    gott = torch.nn.functional.conv_transpose1d(x, f["b.weight"], f["b.bias"], stride=2)
+    assert torch.allclose(got, ref_w, atol=1e-6) and torch.allclose(gott, ref_wt, atol=1e-6)
+
+
+def test_pack_blob_roundtrip_and_errors():
+    cfg = config.make_config(config.MODEL_CONFIGS["tiny"], 30, 2)
+    sd = synth.make_state_dict(cfg, 1)
+    blob = checkpoint.pack_blob(cfg, sd)
+    W = checkpoint.fold_weight_norm(sd)
+    for n, off, numel, shape in checkpoint.blob_layout(cfg):
+        assert torch.equal(blob[off:off + numel].view(shape), W[n].float())
+    bad = dict(sd)
+    bad.pop("enc_p.proj.bias")
+    with pytest.raises(KeyError):
+        checkpoint.pack_blob(cfg, bad, strict=True)
+    bad = dict(sd)
+    bad["enc_p.proj.bias"] = torch.zeros(3)
+    with pytest.raises(ValueError):
+        checkpoint.pack_blob(cfg, bad)
+
+
+def test_config_validation_and_unsupported_options():
+    with pytest.raises(NotImplementedError):
+        config.make_config(dict(config.MODEL_CONFIGS["v1"], use_transformer_flows=True), 10, 1)
+    with pytest.raises(NotImplementedError):
+        config.make_config(dict(config.MODEL_CONFIGS["v1"], vocoder_type="vocos"), 10, 1)
+    cfg = config.make_config(config.MODEL_CONFIGS["v1"], 10, 1)
+    cfg.resblock = 3
+    assert _lib.load().wetts_blob_num_tensors(C.byref(cfg)) < 0
+    assert "resblock" in _lib.last_error()
+
+
+def test_hifigan_cost_matches_survey_figures():
+    """v1 2.402 MFLOP / 21,239 B per output sample (fp32, per-conv traffic)."""
+    lib = _lib.load()
+    for mname, mflop, byts in [("v1", 2.402, 21239), ("v3", 0.177, 5007), ("v2", 0.151, 5315)]:
+        cfg = config.make_config(config.MODEL_CONFIGS[mname], 10, 1)
+        fl, by, mfl, mby = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        assert lib.wetts_hifigan_cost(C.byref(cfg), C.byref(fl), C.byref(by), C.byref(mfl),
+                                      C.byref(mby)) == 0
+        hop = int(np.prod(config.MODEL_CONFIGS[mname]["upsample_rates"]))
+        assert abs(fl.value / hop / 1e6 - mflop) < 0.002, fl.value / hop / 1e6
+        assert abs(by.value / hop - byts) < 2, by.value / hop
+        assert mfl.value < fl.value and mby.value < by.value
+
+
+def test_drop_in_surface_and_loud_failure_without_gpu():
+    from wetts_amd import SynthesizerTrn
+    net = SynthesizerTrn(10, 513, 32, n_speakers=0, **config.MODEL_CONFIGS["tiny"]).eval()
+    assert net.hop_length == 8
+    for meth in ("infer", "infer_encoder", "export_forward", "export_encoder_forward",
+                 "export_decoder_forward", "load_state_dict", "to", "eval"):
+        assert callable(getattr(net, meth))
+    with pytest.raises(_lib.WettsError):  # no silent CPU fallback
+        net.infer(torch.zeros(1, 3, dtype=torch.long), torch.tensor([3]))
+    with pytest.raises(NotImplementedError):
+        net.forward()
+
+
+def test_hparams_mirror(tmp_path):
+    p = tmp_path / "c.json"
+    p.write_text('{"train": {"segment_size": 8192}, "data": {"hop_length": 256, '
+                 '"sampling_rate": 22050}, "model": {"resblock": "1"}}')
+    h = config.get_hparams_from_file(str(p))
+    assert h.train.segment_size // h.data.hop_length == 32 and "resblock" in h.model.keys()
+    assert dict(**h.model) == {"resblock": "1"}

@@ -65,3 +65,39 @@ def test_audio_to_int16_matches_cli_formula():
     ref = np.clip(ref, -32767.0, 32767.0).astype(np.int16)
     got = vo.audio_to_int16(a)
     assert np.abs(got.astype(np.int32) - ref.astype(np.int32)).max() <= 1
+
+
+def _c_mas():
+    import ctypes as C
+    import os
+    import subprocess
+    odir = os.path.join(os.path.dirname(util.GOLDEN), "..", "oracle")
+    subprocess.check_call(["make", "-s", "-C", odir])
+    lib = C.CDLL(os.path.join(odir, "_build", "libmas_oracle.so"))
+    lib.mas_oracle.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                               C.c_int]
+    lib.mas_oracle.restype = None
+
+    def run(neg, t_ys, t_xs):
+        values = np.array(neg, dtype=np.float32, copy=True)
+        paths = np.zeros(values.shape, dtype=np.int32)
+        t_ys = np.ascontiguousarray(t_ys, dtype=np.int32)
+        t_xs = np.ascontiguousarray(t_xs, dtype=np.int32)
+        b, ty, tx = values.shape
+        lib.mas_oracle(paths.ctypes.data, values.ctypes.data, t_ys.ctypes.data, t_xs.ctypes.data,
+                       b, ty, tx)
+        return paths
+    return run
+
+
+def test_mas_c_oracle_known_answers_and_numpy_twin():
+    run = _c_mas()
+    d = np.load(util.GOLDEN + "/mas_kat.npz")
+    for i in range(int(d["n"])):
+        assert np.array_equal(run(d[f"neg{i}"], d[f"ty{i}"], d[f"tx{i}"]).astype(np.int8),
+                              d[f"path{i}"]), f"case {i}"
+    rng = np.random.default_rng(1)
+    neg = rng.standard_normal((3, 60, 17)).astype(np.float32)
+    t_y = np.array([60, 41, 33], np.int32)
+    t_x = np.array([17, 9, 17], np.int32)
+    assert np.array_equal(run(neg, t_y, t_x), vo.maximum_path_numpy(neg, t_y, t_x))

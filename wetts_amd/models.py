@@ -1,0 +1,348 @@
+"""SynthesizerTrn -- drop-in for the reference's inference surface
+(wetts/vits/model/models.py:14-363) running on hand-written gfx950 HIP kernels through the
+C ABI in include/wetts_hip.h.  PyTorch is used for device memory, streams and nothing else:
+there is no eager / CPU fallback anywhere in this module.
+
+Same constructor arguments, same `infer` / `infer_encoder` / `export_*` signatures and return
+tuples as the reference; training-only members (`forward`, `voice_conversion`, `enc_q`) are out of
+scope and raise.
+
+Extra, optional keyword arguments (not in the reference): `eps_w` / `eps_z` inject the two
+standard-normal draws the reference makes with torch.randn (duration_predictors.py:257,
+models.py:267) so results can be compared bit-for-noise with a CPU run.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, checkpoint, config as _config
+
+
+class _Workspace:
+    """Grow-only device scratch (one per model; the kernels themselves never allocate)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class SynthesizerTrn:
+    """Inference-only synthesizer with the reference's constructor signature (models.py:19-51)."""
+
+    def __init__(self, n_vocab, spec_channels, segment_size, inter_channels, hidden_channels,
+                 filter_channels, n_heads, n_layers, kernel_size, p_dropout, resblock,
+                 resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, n_speakers=0, gin_channels=0,
+                 use_sdp=True, vocoder_type="hifigan", **kwargs):
+        self.n_vocab = n_vocab
+        self.spec_channels = spec_channels
+        self.segment_size = segment_size
+        self.inter_channels = inter_channels
+        self.hidden_channels = hidden_channels
+        self.n_speakers = n_speakers
+        self.gin_channels = gin_channels
+        self.use_sdp = use_sdp
+        self.upsample_rates = list(upsample_rates)
+        model = dict(inter_channels=inter_channels, hidden_channels=hidden_channels,
+                     filter_channels=filter_channels, n_heads=n_heads, n_layers=n_layers,
+                     kernel_size=kernel_size, p_dropout=p_dropout, resblock=resblock,
+                     resblock_kernel_sizes=resblock_kernel_sizes,
+                     resblock_dilation_sizes=resblock_dilation_sizes,
+                     upsample_rates=upsample_rates,
+                     upsample_initial_channel=upsample_initial_channel,
+                     upsample_kernel_sizes=upsample_kernel_sizes, gin_channels=gin_channels,
+                     use_sdp=use_sdp, vocoder_type=vocoder_type, **kwargs)
+        self.cfg = _config.make_config(model, n_vocab, n_speakers)
+        self.hop_length = 1
+        for u in upsample_rates:
+            self.hop_length *= int(u)
+        self.device = torch.device("cpu")
+        self._blob = None      # CPU float32 blob (weights live here until .to(device))
+        self._handle = None    # wetts_model_t*
+        self._ws = _Workspace()
+        self.quiet = True      # the reference prints stage timers on every call (:273-279)
+        self.last_status = 0
+
+    # ---- nn.Module-shaped plumbing the reference's callers use -------------------------------
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("training is out of scope of the MI355X inference path")
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if device != self.device:
+            self._destroy()
+            self.device = device
+            if self._blob is not None and device.type == "cuda":
+                self._create()
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def blob_layout(self):
+        return checkpoint.blob_layout(self.cfg)
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts the reference's `G_*.pth["model"]` dict (weight-norm pairs folded here)."""
+        self._blob = checkpoint.pack_blob(self.cfg, state_dict, strict=strict)
+        self._destroy()
+        if self.device.type == "cuda":
+            self._create()
+        return self
+
+    def load_blob(self, blob):
+        """Adopts an already packed float32 blob (CPU or device tensor), e.g. after a broadcast."""
+        n = checkpoint.blob_numel(self.cfg)
+        if blob.dtype != torch.float32 or blob.numel() != n:
+            raise ValueError(f"blob must be float32[{n}]")
+        self._destroy()
+        if blob.device.type == "cuda":
+            self.device = blob.device
+            self._blob = None
+            self._create(dev_blob=blob.contiguous())
+        else:
+            self._blob = blob.contiguous()
+            if self.device.type == "cuda":
+                self._create()
+        return self
+
+    def _create(self, dev_blob=None):
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.WettsError("no HIP device visible; the product path has no CPU fallback")
+        with torch.cuda.device(self.device):
+            if dev_blob is None:
+                dev_blob = self._blob.to(self.device)
+            h = C.c_void_p()
+            rc = lib.wetts_create(C.byref(self.cfg), _lib.ptr(dev_blob), dev_blob.numel(),
+                                  _lib.current_stream_ptr(), C.byref(h))
+            _lib.check(rc, "wetts_create")
+            self._handle = h
+
+    def _destroy(self):
+        if self._handle is not None:
+            _lib.load().wetts_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def _require(self):
+        if self._handle is None:
+            raise _lib.WettsError(
+                "model is not on a HIP device with weights loaded: call load_state_dict(...) and "
+                ".to('cuda') first (there is no CPU path)")
+        return _lib.load()
+
+    def _workspace(self, B, Tx, Ty):
+        lib = _lib.load()
+        n = lib.wetts_workspace_bytes(self._handle, B, Tx, Ty)
+        if n < 0:
+            raise _lib.WettsError("workspace_bytes failed")
+        return self._ws.get(n, self.device), n
+
+    # ---- out-of-scope training surface ---------------------------------------------------------
+    def forward(self, *a, **k):
+        raise NotImplementedError("SynthesizerTrn.forward (training, models.py:161-226) is out of "
+                                  "scope; this is the inference hot path only")
+
+    __call__ = forward
+
+    def voice_conversion(self, *a, **k):
+        raise NotImplementedError("voice_conversion needs the posterior encoder (out of scope)")
+
+    # ---- stages ----------------------------------------------------------------------------------
+    def _ids(self, t):
+        return t.to(device=self.device, dtype=torch.int64).contiguous()
+
+    def _f32(self, t):
+        return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _speaker(self, sid, B):
+        lib = self._require()
+        gin = max(1, self.gin_channels)
+        g = torch.empty(B, gin, dtype=torch.float32, device=self.device)
+        if self.n_speakers > 0:
+            if sid is None:
+                raise ValueError("sid is required when n_speakers > 0")
+            sid = self._ids(sid)
+        else:
+            sid = None
+        _lib.check(lib.wetts_speaker_embedding(self._handle, _lib.ptr(sid), B, _lib.ptr(g),
+                                               _lib.current_stream_ptr()), "speaker_embedding")
+        return g if self.n_speakers > 0 else None
+
+    def _encode(self, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, eps_w, eps_z):
+        """Everything of infer() up to and including flow^-1 (== infer_encoder, models.py:282-331).
+        Returns a dict of stage tensors."""
+        lib = self._require()
+        dev = self.device
+        x = self._ids(x)
+        x_lengths = self._ids(x_lengths)
+        B, Tx = x.shape
+        H, I = self.hidden_channels, self.inter_channels
+        s = _lib.current_stream_ptr()
+        g = self._speaker(sid, B)
+        ws, nws = self._workspace(B, Tx, 0)
+        x_enc = torch.empty(B, H, Tx, dtype=torch.float32, device=dev)
+        stats = torch.empty(B, 2 * I, Tx, dtype=torch.float32, device=dev)
+        x_mask = torch.empty(B, Tx, dtype=torch.float32, device=dev)
+        _lib.check(lib.wetts_text_encoder(self._handle, _lib.ptr(x), _lib.ptr(x_lengths), B, Tx,
+                                          _lib.ptr(x_enc), _lib.ptr(stats), _lib.ptr(x_mask),
+                                          _lib.ptr(ws), nws, s), "text_encoder")
+        logw = torch.empty(B, Tx, dtype=torch.float32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        if self.use_sdp:
+            if eps_w is None:
+                eps_w = torch.randn(B, 2, Tx, dtype=torch.float32, device=dev)
+            eps_w = self._f32(eps_w)
+            if tuple(eps_w.shape) != (B, 2, Tx):
+                raise ValueError(f"eps_w must be [{B},2,{Tx}]")
+            _lib.check(lib.wetts_duration_sdp(self._handle, _lib.ptr(x_enc), _lib.ptr(x_mask),
+                                              _lib.ptr(g), _lib.ptr(eps_w), float(noise_scale_w),
+                                              B, Tx, _lib.ptr(logw), _lib.ptr(status),
+                                              _lib.ptr(ws), nws, s), "duration_sdp")
+        else:
+            _lib.check(lib.wetts_duration_dp(self._handle, _lib.ptr(x_enc), _lib.ptr(x_mask),
+                                             _lib.ptr(g), B, Tx, _lib.ptr(logw), _lib.ptr(ws),
+                                             nws, s), "duration_dp")
+        w_ceil = torch.empty(B, Tx, dtype=torch.float32, device=dev)
+        cum = torch.empty(B, Tx, dtype=torch.float32, device=dev)
+        y_lengths = torch.empty(B, dtype=torch.int64, device=dev)
+        _lib.check(lib.wetts_durations_to_lengths(_lib.ptr(logw), _lib.ptr(x_mask),
+                                                  float(length_scale), B, Tx, _lib.ptr(w_ceil),
+                                                  _lib.ptr(cum), _lib.ptr(y_lengths), s),
+                   "durations_to_lengths")
+        # the one host sync of infer(): output length is data dependent (commons.py:114-115)
+        y_host = y_lengths.cpu()
+        if self.use_sdp and int(status.item()) != 0:
+            # the reference dies on `assert (discriminant >= 0).all()` (transforms.py:171)
+            raise AssertionError("spline inverse: negative discriminant (transforms.py:171)")
+        Ty = int(y_host.max().item()) if B > 0 else 0
+        if eps_z is None:
+            eps_z = torch.randn(B, I, Ty, dtype=torch.float32, device=dev)
+        eps_z = self._f32(eps_z)
+        if tuple(eps_z.shape) != (B, I, Ty):
+            raise ValueError(f"eps_z must be [{B},{I},{Ty}], got {tuple(eps_z.shape)}")
+        f2p = torch.empty(B, Ty, dtype=torch.int32, device=dev)
+        y_mask = torch.empty(B, Ty, dtype=torch.float32, device=dev)
+        attn = torch.empty(B, Ty, Tx, dtype=torch.float32, device=dev)
+        m_p = torch.empty(B, I, Ty, dtype=torch.float32, device=dev)
+        logs_p = torch.empty(B, I, Ty, dtype=torch.float32, device=dev)
+        z_p = torch.empty(B, I, Ty, dtype=torch.float32, device=dev)
+        _lib.check(lib.wetts_length_regulate(self._handle, _lib.ptr(stats), _lib.ptr(cum),
+                                             _lib.ptr(x_mask), _lib.ptr(y_lengths),
+                                             _lib.ptr(eps_z), I * Ty, Ty, float(noise_scale), B,
+                                             Tx, Ty, _lib.ptr(f2p), _lib.ptr(y_mask),
+                                             _lib.ptr(attn), _lib.ptr(m_p), _lib.ptr(logs_p),
+                                             _lib.ptr(z_p), s), "length_regulate")
+        ws, nws = self._workspace(B, Tx, Ty)
+        z = torch.empty(B, I, Ty, dtype=torch.float32, device=dev)
+        _lib.check(lib.wetts_flow_reverse(self._handle, _lib.ptr(z_p), _lib.ptr(y_mask),
+                                          _lib.ptr(g), B, Ty, _lib.ptr(z), _lib.ptr(ws), nws, s),
+                   "flow_reverse")
+        return dict(g=g, x_enc=x_enc, stats=stats, x_mask=x_mask, logw=logw, w_ceil=w_ceil,
+                    y_lengths=y_lengths, y_lengths_host=y_host, frame2phone=f2p, y_mask=y_mask,
+                    attn=attn, m_p=m_p, logs_p=logs_p, z_p=z_p, z=z, B=B, Tx=Tx, Ty=Ty)
+
+    def _decode(self, z, g, y_mask, L):
+        """dec((z * y_mask)[:, :, :L], g) without materialising the masked / sliced copy."""
+        lib = self._require()
+        B = z.shape[0]
+        ws, nws = self._workspace(B, 0, L)
+        audio = torch.empty(B, 1, L * self.hop_length, dtype=torch.float32, device=self.device)
+        _lib.check(lib.wetts_hifigan(self._handle, _lib.ptr(z), z.stride(0), z.stride(1),
+                                     _lib.ptr(y_mask),
+                                     y_mask.stride(0) if y_mask is not None else 0,
+                                     _lib.ptr(g), B, L, _lib.ptr(audio), _lib.ptr(ws), nws,
+                                     _lib.current_stream_ptr()), "hifigan")
+        return audio
+
+    # ---- the reference's public inference API ----------------------------------------------------
+    def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0,
+              max_len=None, eps_w=None, eps_z=None):
+        """models.py:228-280.  Returns (o [B,1,Ty*hop], attn [B,1,Ty,Tx], y_mask [B,1,Ty],
+        (z, z_p, m_p, logs_p) [B,inter,Ty]); z is unmasked, as in the reference."""
+        st = self._encode(x, x_lengths, sid, float(noise_scale), float(length_scale),
+                          float(noise_scale_w), eps_w, eps_z)
+        Ty = st["Ty"]
+        L = Ty if max_len is None else max(0, min(Ty, int(max_len)))
+        o = self._decode(st["z"], st["g"], st["y_mask"], L)
+        self._last = st
+        return (o, st["attn"].unsqueeze(1), st["y_mask"].unsqueeze(1),
+                (st["z"], st["z_p"], st["m_p"], st["logs_p"]))
+
+    def infer_encoder(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1,
+                      noise_scale_w=1.0, eps_w=None, eps_z=None):
+        """models.py:282-331.  Returns (attn, y_mask, (z*y_mask, z_p, m_p, logs_p), g)."""
+        st = self._encode(x, x_lengths, sid, float(noise_scale), float(length_scale),
+                          float(noise_scale_w), eps_w, eps_z)
+        z = st["z"] * st["y_mask"].unsqueeze(1)
+        g = st["g"].unsqueeze(-1) if st["g"] is not None else None
+        return (st["attn"].unsqueeze(1), st["y_mask"].unsqueeze(1),
+                (z, st["z_p"], st["m_p"], st["logs_p"]), g)
+
+    def export_forward(self, x, x_lengths, scales, sid):
+        """models.py:333-344: row 0 of `scales` [B,3] = (noise_scale, length_scale, noise_scale_w)
+        applies to the whole batch."""
+        sc = torch.as_tensor(scales).detach().cpu().to(torch.float32)
+        audio, *_ = self.infer(x, x_lengths, sid, noise_scale=float(sc[0][0]),
+                               length_scale=float(sc[0][1]), noise_scale_w=float(sc[0][2]))
+        return audio
+
+    def export_encoder_forward(self, x, x_lengths, scales, sid):
+        """models.py:346-358: returns z [B, L, inter] (time-major so callers slice chunks)."""
+        sc = torch.as_tensor(scales).detach().cpu().to(torch.float32)
+        _, _, (z, _, _, _), _ = self.infer_encoder(x, x_lengths, sid, noise_scale=float(sc[0][0]),
+                                                   length_scale=float(sc[0][1]),
+                                                   noise_scale_w=float(sc[0][2]))
+        return z.transpose(1, 2)
+
+    def export_decoder_forward(self, z, sid):
+        """models.py:360-363: z [B, L, inter] -> audio [B,1,L*hop]."""
+        z = self._f32(z).transpose(1, 2).contiguous()
+        g = self._speaker(sid, z.shape[0])
+        return self._decode(z, g, None, z.shape[2])
+
+    def hifigan(self, z, g=None):
+        """Generator.forward(z, g) (decoders.py:63-82) on [B,inter,L]; g is [B,gin] or [B,gin,1]."""
+        z = self._f32(z)
+        if g is not None:
+            g = self._f32(g).reshape(z.shape[0], -1)
+        return self._decode(z, g, None, z.shape[2])
+
+    def audio_to_int16(self, audio, lengths_samples=None):
+        """inference.py:100-110 scaling on the device; audio [B,1,L] or [B,L] -> int16 [B,L]."""
+        lib = self._require()
+        a = self._f32(audio)
+        if a.dim() == 3:
+            a = a[:, 0].contiguous()
+        B, L = a.shape
+        pcm = torch.empty(B, L, dtype=torch.int16, device=self.device)
+        ln = self._ids(lengths_samples) if lengths_samples is not None else None
+        _lib.check(lib.wetts_audio_to_int16(_lib.ptr(a), _lib.ptr(ln), B, L, _lib.ptr(pcm),
+                                            _lib.current_stream_ptr()), "audio_to_int16")
+        return pcm
+
+
+def load_checkpoint(checkpoint_path, model, optimizer=None):
+    """task.load_checkpoint (utils/task.py:31-56) for the drop-in model: reads `G_*.pth`, folds
+    weight norm, uploads.  Returns (model, optimizer, learning_rate, iteration) like the
+    reference."""
+    sd, iteration, lr = checkpoint.load_state_dict_file(checkpoint_path)
+    model.load_state_dict(sd, strict=False)
+    return model, optimizer, lr, iteration
