@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X VITS hot path (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one SynthesizerTrn.infer() over one synthetic batch per rank: Baker VITS (v1 config,
+22.05 kHz, SDP, ResBlock1, C0=512), batch = 16 utterances x 128 phonemes, fp32
+(BASELINE.json configs[1]).  Inputs are resident in HBM when the timed region starts; outputs
+stay in HBM.  One process per GPU; weights are broadcast once from rank 0 (RCCL), then every rank
+decodes its own utterance shard with no collective in the loop (weak scaling).
+
+Prints ONE JSON line on rank 0 (see the driver contract).  Extra keys:
+  roofline     dominant kernel = the MRF ResBlock conv stack (conv_mfma_kernel), timed live with
+               HIP events recorded on the launch stream inside the timed steps
+  cpu_baseline the oracle (oracle/vits_oracle.py, a port of the reference running the same ATen
+               CPU kernels) timed on this box's host cores on a bounded sample of the workload
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= f32 vector)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="v1")
+    ap.add_argument("--batch", type=int, default=16, help="utterances per rank per step")
+    ap.add_argument("--phonemes", type=int, default=128)
+    ap.add_argument("--ragged", action="store_true", help="Tx ~ U{32..phonemes} (configs[3] style)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="utterances in the CPU sample")
+    return ap.parse_args()
+
+
+def make_inputs(model_name, n_vocab, n_speakers, total_utts, tx, ragged, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randint(0, n_vocab, (total_utts, tx), generator=g)
+    if ragged:
+        lens = torch.randint(32, tx + 1, (total_utts,), generator=g)
+    else:
+        lens = torch.full((total_utts,), tx, dtype=torch.long)
+    sid = torch.randint(0, max(1, n_speakers), (total_utts,), generator=g)
+    return x, lens, sid
+
+
+def cpu_baseline(cfg, sd, x, lens, sid, n_utts, sr, hop):
+    """Times the oracle (CPU port of the reference path, same ATen kernels) on `n_utts` utterances
+    of the same workload.  Returns the cpu_baseline object."""
+    from oracle import vits_oracle as vo  # checker / baseline only -- never on the product path
+    from tests import util
+    from wetts_amd import checkpoint
+    W = checkpoint.fold_weight_norm(sd)
+    cd = util.cfg_dict(cfg)
+    xs, ls, ss = x[:n_utts], lens[:n_utts], sid[:n_utts]
+    torch.manual_seed(1)
+    cores = torch.get_num_threads()
+    vo.infer(W, cd, xs[:1, :16], torch.tensor([16]), ss[:1], 0.667, 1.0, 0.8)  # warm-up (tiny)
+    t0 = time.perf_counter()
+    o, _, y_mask, _ = vo.infer(W, cd, xs, ls, ss, noise_scale=0.667, length_scale=1.0,
+                               noise_scale_w=0.8)
+    dt = time.perf_counter() - t0
+    samples = float(y_mask.sum().item()) * hop
+    return {"value": samples / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n_utts} of the batch's utterances ({int(ls.sum())} phonemes, "
+                      f"{int(y_mask.sum().item())} frames), oracle infer() once, {dt:.1f} s",
+            "rtf": dt / (samples / sr)}
+
+
+def main():
+    args = parse_args()
+    from wetts_amd import SynthesizerTrn, _lib, checkpoint, config, sharding, synth
+
+    rank, local_rank, world = sharding.init_process_group()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    lib = _lib.load()
+
+    n_vocab, n_speakers = 256, 1  # SURVEY §8(d) cfg 2: synthetic phone table, Baker single speaker
+    model = config.MODEL_CONFIGS[args.model]
+    sr = config.SAMPLING_RATES[args.model]
+    net = SynthesizerTrn(n_vocab, 513, 32, n_speakers=n_speakers, **model)
+    cfg = net.cfg
+    hop = net.hop_length
+
+    # ---- weights: rank 0 builds the blob, one broadcast over RCCL, every rank repacks locally
+    numel = checkpoint.blob_numel(cfg)
+    sd = None
+    if rank == 0:
+        sd = synth.make_state_dict(cfg, seed=0)
+        blob = checkpoint.pack_blob(cfg, sd).to(dev)
+    else:
+        blob = torch.empty(numel, dtype=torch.float32, device=dev)
+    t_b0 = time.perf_counter()
+    sharding.broadcast_blob(blob, src=0)
+    torch.cuda.synchronize()
+    bcast_ms = (time.perf_counter() - t_b0) * 1e3
+    net.load_blob(blob)
+
+    # ---- inputs: global utterance list, LPT-dealt to ranks, resident on the device
+    total = args.batch * world
+    x, lens, sid = make_inputs(args.model, n_vocab, n_speakers, total, args.phonemes, args.ragged)
+    shards = sharding.shard_utterances(lens.tolist(), world)
+    mine = torch.tensor(shards[rank], dtype=torch.long)
+    xd, ld, sd_ids = x[mine].to(dev), lens[mine].to(dev), sid[mine].to(dev)
+
+    def step():
+        o, attn, y_mask, _ = net.infer(xd, ld, sid=sd_ids, noise_scale=0.667, length_scale=1.0,
+                                       noise_scale_w=0.8)
+        return o, y_mask
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    _lib.check(lib.wetts_set_mrf_timing(net._handle, 1), "set_mrf_timing")
+    frames = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    masks = []
+    for _ in range(args.steps):
+        o, y_mask = step()
+        masks.append(y_mask)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    for ym in masks:
+        frames += float(ym.sum().item())
+    ms, nl, nc = C.c_double(), C.c_int64(), C.c_int32()
+    _lib.check(lib.wetts_read_mrf_timing(net._handle, C.byref(ms), C.byref(nl), C.byref(nc)),
+               "read_mrf_timing")
+    _lib.check(lib.wetts_set_mrf_timing(net._handle, 0), "set_mrf_timing")
+    padded_frames = float(sum(ym.numel() for ym in masks))  # B*Ty: what the decoder computes
+
+    # PCIe-inclusive variant (never `value`): one extra step with D2H of the audio
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    o, y_mask = step()
+    _ = o.cpu()
+    pcie_s = time.perf_counter() - t1
+    pcie_rate = float(y_mask.sum().item()) * hop / pcie_s
+
+    # ---- reduce over ranks: time = max, work = sum
+    stat = torch.tensor([elapsed, frames, padded_frames, ms.value, float(nl.value)],
+                        dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stat.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stat.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, frames = float(mx[0]), float(sm[1])
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+        return
+
+    samples = frames * hop
+    value = samples / elapsed
+    fl, by, mfl, mby = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    lib.wetts_hifigan_cost(C.byref(cfg), C.byref(fl), C.byref(by), C.byref(mfl), C.byref(mby))
+    # dominant kernel: algorithmic FLOPs of the MRF convs over the frames rank 0 decoded
+    # (padded frames: the decoder has no masks, decoders.py:63-82), / live device time
+    mrf_flops = mfl.value * padded_frames
+    mrf_tflops = mrf_flops / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    mrf_gbs = mby.value * padded_frames / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0
+    roofline = {
+        "kernel": "conv_mfma_kernel (MRF ResBlock convs)",
+        "bound": "mfma", "achieved": mrf_tflops, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": mrf_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+        "launches": int(nl.value), "avg_launch_ms": ms.value / max(1, nl.value),
+        "flops_per_launch": mrf_flops / max(1, nl.value),
+        "hbm_view": {"achieved": mrf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": mrf_gbs / HBM_PEAK_GBS,
+                     "note": "per-conv algorithmic bytes (SURVEY 8d); fp32 convs are "
+                             "compute-bound (AI 113 flop/B > ridge ~20)"},
+        "mrf_share_of_step": ms.value / (elapsed * 1e3),
+    }
+    out = {
+        "metric": "audio samples/sec + RTF @22.05 kHz, VITS-Baker, 1/2/4/8 MI355X",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (seeded phoneme ids, seeded random-init weights, ~6.5 frames/phoneme)",
+        "rtf": elapsed / (samples / sr), "x_realtime": (samples / sr) / elapsed,
+        "config": {"workload": f"baker_{args.model} infer(): B={args.batch}/GPU x "
+                               f"{args.phonemes} phonemes{' ragged' if args.ragged else ''}, fp32, "
+                               f"{sr} Hz (BASELINE.json configs[1])",
+                   "global_batch": total, "phonemes": args.phonemes, "hop": hop,
+                   "valid_frames_per_step": frames / args.steps,
+                   "parallelism": f"utterance-shard x{world}, weights broadcast once "
+                                  f"({numel * 4 / 1e6:.0f} MB, {bcast_ms:.1f} ms), no collectives "
+                                  "in the decode loop"},
+        "pcie_inclusive_samples_per_s": pcie_rate,
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, sd, x, lens, sid, min(args.cpu_sample, total), sr,
+                                           hop)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -220,6 +220,15 @@ int32_t wetts_hifigan_cost(const wetts_config_t* cfg, double* flops_per_frame,
                            double* bytes_per_frame_perconv, double* mrf_flops_per_frame,
                            double* mrf_bytes_per_frame_perconv);
 
+/* Live timing of the dominant kernel class (every ResBlock conv of the MRF stack) inside
+ * normal wetts_hifigan / wetts_infer calls: when enabled, a HIP event pair is recorded on the
+ * call's stream around each stage's ResBlock launches (no synchronisation at record time).
+ * wetts_read_mrf_timing synchronises the recorded events and returns the summed device time,
+ * the number of MRF conv launches and of hifigan calls since enabling; set(…,0/1) resets. */
+int32_t wetts_set_mrf_timing(const wetts_model_t* m, int32_t enable);
+int32_t wetts_read_mrf_timing(const wetts_model_t* m, double* mrf_ms, int64_t* conv_launches,
+                              int32_t* hifigan_calls);
+
 /* Times `iters` launches of the dominant MRF conv kernel class (all ResBlock convs of the
  * decoder) with HIP events on `stream`; returns total ms and the number of conv launches.
  * Used by bench.py for roofline.achieved. */

@@ -281,6 +281,12 @@ struct wetts_model {
   const float* conv_post_w = nullptr;
   const float *dec_cond_w = nullptr, *dec_cond_b = nullptr;
   int hop = 1;
+  // live MRF timing (wetts_set_mrf_timing): event pairs recorded around each stage's ResBlock
+  // launches, resolved lazily by wetts_read_mrf_timing so the timed region is not perturbed.
+  mutable bool mrf_timing = false;
+  mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> mrf_events;
+  mutable int64_t mrf_launches = 0;
+  mutable int32_t mrf_calls = 0;
 
   const float* T(const std::string& name) const {
     auto it = layout.index.find(name);
@@ -1007,6 +1013,12 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
     float* xsum = (x == bx) ? bs : bx; // MRF accumulator for this stage
     (void)xs;
     if (tm && tm->on) WETTS_HIP_CHECK(hipEventRecord(tm->e0, s));
+    hipEvent_t lv0 = nullptr, lv1 = nullptr;
+    if (m->mrf_timing) {
+      WETTS_HIP_CHECK(hipEventCreate(&lv0));
+      WETTS_HIP_CHECK(hipEventCreate(&lv1));
+      WETTS_HIP_CHECK(hipEventRecord(lv0, s));
+    }
     for (int j = 0; j < nk; ++j) {
       const RB& rb = m->rbs[i * nk + j];
       const float* rx = xu;  // current resblock x
@@ -1055,6 +1067,11 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
         rx = outp;
       }
     }
+    if (m->mrf_timing) {
+      WETTS_HIP_CHECK(hipEventRecord(lv1, s));
+      m->mrf_events.emplace_back(lv0, lv1);
+      m->mrf_launches += (int64_t)nk * nd * (c->resblock == 1 ? 2 : 1);
+    }
     if (tm && tm->on) {
       WETTS_HIP_CHECK(hipEventRecord(tm->e1, s));
       WETTS_HIP_CHECK(hipEventSynchronize(tm->e1));
@@ -1066,6 +1083,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
   }
   // x = tanh(conv_post(leaky_relu(x)))   (default slope 0.01, decoders.py:78)
   WETTS_TRY(k_conv_post_tanh(x, m->conv_post_w, 7, B, ch, len, audio, s));
+  if (m->mrf_timing) m->mrf_calls += 1;
   return WETTS_OK;
 }
 }  // namespace wetts
@@ -1110,6 +1128,35 @@ int32_t wetts_profile_hifigan(const wetts_model_t* m, const float* z, int64_t z_
   (void)hipEventDestroy(t0);
   (void)hipEventDestroy(t1);
   return r;
+}
+
+int32_t wetts_set_mrf_timing(const wetts_model_t* m, int32_t enable) {
+  WETTS_REQUIRE(m != nullptr, "null model");
+  for (auto& pr : m->mrf_events) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  m->mrf_events.clear();
+  m->mrf_launches = 0;
+  m->mrf_calls = 0;
+  m->mrf_timing = enable != 0;
+  return WETTS_OK;
+}
+
+int32_t wetts_read_mrf_timing(const wetts_model_t* m, double* mrf_ms, int64_t* conv_launches,
+                              int32_t* hifigan_calls) {
+  WETTS_REQUIRE(m && mrf_ms && conv_launches && hifigan_calls, "null argument");
+  double tot = 0;
+  for (auto& pr : m->mrf_events) {
+    WETTS_HIP_CHECK(hipEventSynchronize(pr.second));
+    float ms = 0.f;
+    WETTS_HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+    tot += ms;
+  }
+  *mrf_ms = tot;
+  *conv_launches = m->mrf_launches;
+  *hifigan_calls = m->mrf_calls;
+  return WETTS_OK;
 }
 
 int32_t wetts_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, int32_t B,
