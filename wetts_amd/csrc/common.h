@@ -62,6 +62,7 @@ struct ConvParams {
   const float* x;
   int64_t x_bs, x_cs;  // batch / channel strides (floats); time stride is 1
   int Cin, Tin;
+  int vec_in;            // set by the launcher: 16-byte aligned input rows (float4 staging)
   int in_rev_base;       // >=0: physical channel = in_rev_base - ci (Flip folded into indexing)
   int in_act;            // InAct
   float in_slope;
@@ -113,6 +114,9 @@ void free_packed(PackedConv* pc);
 
 // Launches the conv.  Fills geometry fields of `p` from `pc`; caller fills the I/O fields.
 int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream);
+
+int conv_variant();
+void set_conv_variant(int v);
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }

@@ -1159,6 +1159,85 @@ int32_t wetts_read_mrf_timing(const wetts_model_t* m, double* mrf_ms, int64_t* c
   return WETTS_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// conv micro-benchmark (measurement helper, allocates its own buffers; not on the product path)
+// ---------------------------------------------------------------------------------------------
+namespace wetts {
+__global__ void fill_pseudo_kernel(float* p, int64_t n, unsigned seed, float scale) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned h = (unsigned)i * 2654435761u + seed;
+  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+  p[i] = ((float)(h & 0xffffff) / 8388608.f - 1.f) * scale;
+}
+static int32_t fill_pseudo(float* p, int64_t n, unsigned seed, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(fill_pseudo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n,
+                     seed, scale);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+}  // namespace wetts
+
+int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int32_t B, int32_t T,
+                         int32_t flags, int32_t variant, int32_t iters, double* ms_out,
+                         double* checksum_out) {
+  WETTS_REQUIRE(ms_out && Cin > 0 && Cout > 0 && k > 0 && B > 0 && T > 0 && iters > 0,
+                "bad argument");
+  hipStream_t s = nullptr;
+  const int64_t nx = (int64_t)B * Cin * T, no = (int64_t)B * Cout * T, nw = (int64_t)Cout * Cin * k;
+  float *x = nullptr, *o = nullptr, *r = nullptr, *w = nullptr, *bias = nullptr;
+  WETTS_HIP_CHECK(hipMalloc((void**)&x, nx * 4));
+  WETTS_HIP_CHECK(hipMalloc((void**)&o, no * 4));
+  WETTS_HIP_CHECK(hipMalloc((void**)&r, no * 4));
+  WETTS_HIP_CHECK(hipMalloc((void**)&w, nw * 4));
+  WETTS_HIP_CHECK(hipMalloc((void**)&bias, (int64_t)Cout * 4));
+  WETTS_TRY(fill_pseudo(x, nx, 1, 1.f, s));
+  WETTS_TRY(fill_pseudo(r, no, 2, 1.f, s));
+  WETTS_TRY(fill_pseudo(w, nw, 3, 1.f / sqrtf((float)Cin * k), s));
+  WETTS_TRY(fill_pseudo(bias, Cout, 4, 0.1f, s));
+  WETTS_HIP_CHECK(hipMemsetAsync(o, 0, no * 4, s));
+  PackedConv pc;
+  WETTS_TRY(pack_conv_weight(w, bias, Cout, Cin, k, dil, (k * dil - dil) / 2, 0, 0, s, &pc));
+  ConvParams p = conv_io(x, Cin, T, o, Cout, B);
+  if (flags & 1) { p.in_act = IN_LRELU; p.in_slope = 0.1f; }
+  if (flags & 2) { p.res = r; p.r_bs = (int64_t)Cout * T; p.r_cs = T; }
+  if (flags & 4) { p.accum = 1; }
+  const int saved = conv_variant();
+  set_conv_variant(variant);
+  int32_t rc = WETTS_OK;
+  for (int i = 0; i < 2 && rc == WETTS_OK; ++i) rc = launch_conv(pc, p, s);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < iters && rc == WETTS_OK; ++i) rc = launch_conv(pc, p, s);
+  (void)hipEventRecord(e1, s);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *ms_out = ms / iters;
+  set_conv_variant(saved);
+  if (checksum_out) {
+    // cheap order-insensitive fingerprint so variants can be compared for equality
+    std::vector<float> host((size_t)(no < 65536 ? no : 65536));
+    (void)hipMemcpy(host.data(), o, host.size() * 4, hipMemcpyDeviceToHost);
+    double cs = 0;
+    for (size_t i = 0; i < host.size(); ++i) cs += (double)host[i] * (double)((i % 7) + 1);
+    *checksum_out = cs;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  free_packed(&pc);
+  (void)hipFree(x); (void)hipFree(o); (void)hipFree(r); (void)hipFree(w); (void)hipFree(bias);
+  return rc;
+}
+
+int32_t wetts_set_conv_variant(int32_t v) {
+  set_conv_variant(v);
+  return WETTS_OK;
+}
+
 int32_t wetts_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, int32_t B,
                   int32_t Ty, int32_t Tx, int32_t* path, void* workspace, int64_t workspace_bytes,
                   void* stream) {
