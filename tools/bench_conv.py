@@ -9,7 +9,7 @@ from wetts_amd import _lib  # noqa: E402
 
 lib = _lib.load()
 B, Ty = 16, 864
-variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,1").split(",")]
+variants = [int(v, 0) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,1").split(",")]
 shapes = []
 L = Ty
 for C_, u in [(256, 8), (128, 8), (64, 2), (32, 2)]:
@@ -21,7 +21,7 @@ only = os.environ.get("WETTS_SHAPES")
 if only:
     keep = {tuple(int(v) for v in it.split(":")) for it in only.split(",")}
     shapes = [sh for sh in shapes if (sh[0], sh[1]) in keep]
-print(f"{'shape':34s}" + "".join(f"  v{v}: ms / TF/s      " for v in variants))
+print(f"{'shape':34s}" + "".join(f"  v{v:#x}: ms / TF/s   " for v in variants))
 for (ch, k, d, L, fl) in shapes:
     row = f"C={ch:3d} k={k:2d} d={d} L={L:6d} fl={fl}      "
     ref = None

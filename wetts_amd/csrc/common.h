@@ -91,6 +91,7 @@ struct ConvParams {
   int accum;             // 1: add the previous contents of out
   float out_div;         // final true division (MRF mean: xs / num_kernels), 1 = none
   int B;
+  int ablate;            // microbenchmark-only ablation mask (see conv_mfma_kernel DBG)
 };
 
 // Packed weight descriptor held by the model.

@@ -108,8 +108,10 @@ void free_packed(PackedConv* pc) {
 // ------------------------------------------------------------------------------------------
 // the conv kernel
 // ------------------------------------------------------------------------------------------
-template <int MB, int NB, int WM, int WN, bool PF>
+template <int MB, int NB, int WM, int WN, bool PF, bool DBG = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+  // DBG instantiations honour p.ablate (microbenchmark only): 1 no MFMA, 2 no staging loads,
+  // 4 no A loads, 8 no epilogue stores, 16 no LDS B reads
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int CK = kConvCK;
   constexpr int MT = 32 * MB * WM;
@@ -164,12 +166,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
       for (int i = 0; i < MAXCI; ++i) {
         float v = 0.f;
-        if (cok && tcol[i] >= 0) v = xr[tcol[i]];
-        if (p.in_act == IN_LRELU) v = v > 0.f ? v : v * p.in_slope;
-        stage[r][i] = v * mcol[i];
+        if (DBG && (p.ablate & 2)) {
+          v = 0.25f;
+        } else if (cok && tcol[i] >= 0) {
+          v = xr[tcol[i]];
+        }
+        stage[r][i] = v;  // raw: no use of the value here, so the loads stay in flight
       }
     }
   };
+  // activation + mask are applied on the way into LDS, i.e. AFTER the chunk's MFMA work, so the
+  // HBM latency of the staging loads is hidden behind the matrix cores instead of stalling here
   auto store_chunk = [&](float* buf) {
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
@@ -177,7 +184,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
       for (int i = 0; i < MAXCI; ++i) {
         int col = lane + 64 * i;
-        if (col < W) row[col] = stage[r][i];
+        if (col < W) {
+          float v = stage[r][i];
+          if (p.in_act == IN_LRELU) v = v > 0.f ? v : v * p.in_slope;
+          row[col] = v * mcol[i];
+        }
       }
     }
   };
@@ -230,6 +241,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   float4 a_nxt[MB];
 #pragma unroll
   for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][0];
+  const bool no_a = DBG && (p.ablate & 4);
+  const bool no_mfma = DBG && (p.ablate & 1);
+  const bool no_b = DBG && (p.ablate & 16);
+  float dbg_sink = 0.f;
 
   load_chunk(0);
   store_chunk(buf0);
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < MB; ++i) a_cur[i] = a_nxt[i];
         ++g;
-        if (g < G) {
+        if (g < G && !no_a) {
 #pragma unroll
           for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][(int64_t)g * 64];
         }
@@ -268,16 +283,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
               for (int j = 0; j < NB; ++j) bv[(s + 1) & 1][j] = brow0[(s + 1) * 2 * W + 32 * j];
             }
           } else {
+            if (no_b) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) bv[s & 1][j] = brow0[s * 2 * W + 32 * j];
+              for (int j = 0; j < NB; ++j) bv[s & 1][j] = 0.5f;
+            } else {
+#pragma unroll
+              for (int j = 0; j < NB; ++j) bv[s & 1][j] = brow0[s * 2 * W + 32 * j];
+            }
           }
 #pragma unroll
           for (int i = 0; i < MB; ++i) {
             const float av = s == 0 ? a_cur[i].x : s == 1 ? a_cur[i].y : s == 2 ? a_cur[i].z
                                                                                  : a_cur[i].w;
+            if (no_mfma) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s & 1][j], acc[i][j], 0, 0, 0);
+              for (int j = 0; j < NB; ++j) dbg_sink += av * bv[s & 1][j];
+            } else {
+#pragma unroll
+              for (int j = 0; j < NB; ++j)
+                acc[i][j] =
+                    __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s & 1][j], acc[i][j], 0, 0, 0);
+            }
           }
         }
       }
@@ -286,6 +312,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     __syncthreads();
   }
 
+  if (DBG && no_mfma) acc[0][0][0] += dbg_sink;
   // ---- epilogue ---------------------------------------------------------------------------
   const int64_t ob = (int64_t)b * p.o_bs;
   const int64_t rb = (int64_t)b * p.r_bs;
@@ -319,7 +346,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
           if (p.accum) v += *dst;
         }
         if (p.out_div != 1.f) v = v / p.out_div;
-        *dst = v;
+        if (DBG && (p.ablate & 8)) {
+          if (v == 123.456f + dbg_sink) *dst = v;  // keeps v live, practically never stores
+        } else {
+          *dst = v;
+        }
       }
     }
   }
@@ -603,6 +634,15 @@ static int32_t launch_cfg_ws(ConvParams p, hipStream_t stream) {
 
 template <int MB, int NB, int WM, int WN, bool PF = false>
 static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
+  if (p.ablate) {
+    constexpr int NTd = 32 * NB * WN;
+    int64_t blocksd = (int64_t)cdiv(p.N, NTd) * cdiv(p.M, 32 * MB * WM) * p.B;
+    size_t ldsd = (size_t)2 * kConvCK * (NTd + p.span) * sizeof(float);
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, true>), dim3((unsigned)blocksd),
+                       dim3(256), ldsd, stream, p);
+    WETTS_LAUNCH_CHECK();
+    return WETTS_OK;
+  }
   constexpr int MT = 32 * MB * WM, NT = 32 * NB * WN;
   int ntiles = cdiv(p.N, NT), mtiles = cdiv(p.M, MT);
   int64_t blocks = (int64_t)ntiles * mtiles * p.B;

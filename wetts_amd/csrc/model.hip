@@ -1204,7 +1204,8 @@ int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int3
   if (flags & 2) { p.res = r; p.r_bs = (int64_t)Cout * T; p.r_cs = T; }
   if (flags & 4) { p.accum = 1; }
   const int saved = conv_variant();
-  set_conv_variant(variant);
+  set_conv_variant(variant & 0xff);
+  p.ablate = variant >> 8;
   int32_t rc = WETTS_OK;
   for (int i = 0; i < 2 && rc == WETTS_OK; ++i) rc = launch_conv(pc, p, s);
   hipEvent_t e0, e1;
