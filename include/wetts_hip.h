@@ -237,6 +237,10 @@ int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int3
                          int32_t flags, int32_t variant, int32_t iters, double* ms_out,
                          double* checksum_out);
 int32_t wetts_set_conv_variant(int32_t variant);
+/* Calibration: sustained v_mfma_f32_32x32x2_f32 rate with `blocks_per_cu` 4-wave blocks per CU
+ * and `nacc` (1,2,4) independent accumulators per wave, no memory traffic. */
+int32_t wetts_bench_mfma_peak(int32_t blocks_per_cu, int32_t nacc, int32_t iters, double* tflops,
+                              double* ms);
 
 /* Times `iters` launches of the dominant MRF conv kernel class (all ResBlock convs of the
  * decoder) with HIP events on `stream`; returns total ms and the number of conv launches.

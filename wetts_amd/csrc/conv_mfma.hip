@@ -90,7 +90,9 @@ int32_t pack_conv_weight(const float* w_dev, const float* bias_dev, int Cout, in
   int G = pc->nchunks * pc->ktaps * 2;
   int mt32 = cdiv(pc->M, 128) * 4;
   int64_t total = (int64_t)mt32 * G * 256;
-  WETTS_HIP_CHECK(hipMalloc((void**)&pc->wpk, total * sizeof(float)));
+  // + one zero tile: the tap-specialised kernel prefetches group G (one past the end) blindly
+  WETTS_HIP_CHECK(hipMalloc((void**)&pc->wpk, (total + (int64_t)G * 256) * sizeof(float)));
+  WETTS_HIP_CHECK(hipMemsetAsync(pc->wpk + total, 0, (size_t)G * 256 * sizeof(float), stream));
   int threads = 256;
   int64_t blocks = (total + threads - 1) / threads;
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream,
@@ -603,6 +605,321 @@ __global__ __launch_bounds__(320) void conv_mfma_ws_kernel(const ConvParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// tap-count-specialised variant (the production kernel for the common tap counts).
+// The whole chunk body -- 2*KT groups of 4 k-steps -- is straight-line code:
+//   * every global load is UNCONDITIONAL (addresses clamped, validity applied when the value is
+//     written to LDS), so there is no control flow between loads and the compiler can emit exact
+//     counted `s_waitcnt vmcnt(N)`: the A-fragment wait no longer drains the staging loads;
+//   * the staging loads of chunk c+1 are issued right after the A prefetch of group 0 and their
+//     LDS stores sit after group GS, in the middle of the MFMA stream, so the end-of-chunk barrier
+//     is a bare rendezvous instead of a store phase all co-resident blocks hit together;
+//   * B operands are prefetched one k-step ahead across group boundaries.
+// ------------------------------------------------------------------------------------------
+template <int MB, int NB, int WM, int WN, int KT, int CI>
+__global__ __launch_bounds__(256) void conv_mfma_kt_kernel(const ConvParams p) {
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int CK = kConvCK;
+  constexpr int MT = 32 * MB * WM;
+  constexpr int NT = 32 * NB * WN;
+  constexpr int WL = CI * 64;                    // LDS row width: every lane stores, no branches
+  constexpr int RPW = CK / 4;
+  constexpr int NG = 2 * KT;                     // groups of 4 k-steps per chunk
+  constexpr int GS = NG >= 6 ? 3 : (NG - 1);     // group after which the staged chunk goes to LDS
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5;
+
+  const int ntiles = (p.N + NT - 1) / NT;
+  const int mtiles = (p.M + MT - 1) / MT;
+  int bid = blockIdx.x;
+  const int ntile = bid % ntiles;
+  bid /= ntiles;
+  const int mtile = bid % mtiles;
+  const int b = bid / mtiles;
+
+  const int n0 = ntile * NT;
+  const int W = NT + p.span;
+  float* buf0 = smem;
+  float* buf1 = smem + CK * WL;
+
+  const float* xb = p.x + (int64_t)b * p.x_bs;
+  const float* mrow = p.in_mask ? p.in_mask + (int64_t)b * p.in_mask_stride : nullptr;
+
+  // per-column staging info (tile constant): clamped sample index + multiplier (0 = padding)
+  int tcl[CI];
+  float mcol[CI];
+#pragma unroll
+  for (int i = 0; i < CI; ++i) {
+    const int col = lane + 64 * i;
+    const int t = n0 + p.off_lo + col;
+    const bool ok = (col < W) && (t >= 0) && (t < p.Tin);
+    const int tc = t < 0 ? 0 : (t >= p.Tin ? p.Tin - 1 : t);
+    tcl[i] = tc;
+    mcol[i] = ok ? (mrow ? mrow[tc] : 1.f) : 0.f;
+  }
+  const bool lrelu = p.in_act == IN_LRELU;
+  const float slope = lrelu ? p.in_slope : 1.f;  // v>0 ? v : v*slope with slope 1 == identity
+
+  float stage[RPW][CI];
+  auto load_chunk = [&](int c) {  // unconditional loads from clamped addresses
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      int ci = c * CK + wave + 4 * r;
+      ci = ci < p.Cin ? ci : p.Cin - 1;
+      const int ch = p.in_rev_base >= 0 ? (p.in_rev_base - ci) : ci;
+      const float* xr = xb + (int64_t)ch * p.x_cs;
+#pragma unroll
+      for (int i = 0; i < CI; ++i) stage[r][i] = xr[tcl[i]];
+    }
+  };
+  auto store_chunk = [&](int c, float* buf) {  // unconditional stores (row width = CI*64)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const float rowok = (c * CK + wave + 4 * r) < p.Cin ? 1.f : 0.f;
+      float* row = buf + (wave + 4 * r) * WL + lane;
+#pragma unroll
+      for (int i = 0; i < CI; ++i) {
+        float v = stage[r][i];
+        v = v > 0.f ? v : v * slope;
+        row[64 * i] = v * (mcol[i] * rowok);
+      }
+    }
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bool pre_res = (p.res != nullptr || p.accum) && p.up == 0 && p.out_act == OUT_NONE &&
+                       p.out_mask == nullptr;
+  if (pre_res) {
+    const int64_t ob0 = (int64_t)b * p.o_bs;
+    const int64_t rb0 = (int64_t)b * p.r_bs;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const int mrow0 = mtile * MT + (wm * MB + i) * 32 + 4 * half;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int col = n0 + wn * (32 * NB) + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mrow0 + (r & 3) + 8 * (r >> 2);
+          float v = 0.f;
+          if (col < p.N && row < p.M) {
+            if (p.res) v = p.res[rb0 + (int64_t)row * p.r_cs + col];
+            if (p.accum) v += p.out[ob0 + (int64_t)row * p.o_cs + col];
+          }
+          acc[i][j][r] = v;
+        }
+      }
+    }
+  }
+
+  // packed A stream; the buffer carries one padding tile so group G may be prefetched blindly
+  const int G = p.nchunks * NG;
+  const float4* abase[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int mt32 = mtile * (MB * WM) + wm * MB + i;
+    abase[i] = reinterpret_cast<const float4*>(p.wpk) + ((int64_t)mt32 * G) * 64 + lane;
+  }
+  float4 a_nxt[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][0];
+
+  load_chunk(0);
+  store_chunk(0, buf0);
+  __syncthreads();
+
+  const int bcol0 = half * WL + wn * (32 * NB) + (lane & 31) - p.pad - p.off_lo;
+  for (int c = 0; c < p.nchunks; ++c) {
+    const float* cur = ((c & 1) ? buf1 : buf0) + bcol0;
+    float* nxt = (c & 1) ? buf0 : buf1;
+    const int cn = (c + 1 < p.nchunks) ? (c + 1) : c;  // last chunk re-stages itself (harmless)
+    float bv[2][NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bv[0][j] = cur[32 * j];
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      float4 a_cur[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][(int64_t)(c * NG + gi + 1) * 64];
+      if (gi == 0) {
+        load_chunk(cn);
+        __builtin_amdgcn_sched_barrier(0);  // keep the staging loads HERE, early in the chunk
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int ks = gi * 4 + s + 1;  // B operands of the next k-step (next group / tap too)
+        if (ks < NG * 4) {
+          const float* brow = cur + ((ks & 7) * 2) * WL + (ks >> 3) * p.dil;
+#pragma unroll
+          for (int j = 0; j < NB; ++j) bv[ks & 1][j] = brow[32 * j];
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const float av = s == 0 ? a_cur[i].x : s == 1 ? a_cur[i].y : s == 2 ? a_cur[i].z
+                                                                               : a_cur[i].w;
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[(gi * 4 + s) & 1][j],
+                                                              acc[i][j], 0, 0, 0);
+        }
+      }
+      if (gi == GS) {
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk(cn, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------
+  const int64_t ob = (int64_t)b * p.o_bs;
+  const int64_t rb = (int64_t)b * p.r_bs;
+  const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
+  const float* omask = p.out_mask ? p.out_mask + (int64_t)b * p.out_mask_stride : nullptr;
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int mrow0 = mtile * MT + (wm * MB + i) * 32 + 4 * half;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int col = n0 + wn * (32 * NB) + j * 32 + (lane & 31);
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mrow0 + (r & 3) + 8 * (r >> 2);
+        if (row >= p.M) continue;
+        int co = row, t = col;
+        if (p.up > 0) {
+          co = row / p.up;
+          t = col * p.up + (row - co * p.up) - p.up_pad;
+          if (t < 0 || t >= p.Tout) continue;
+        }
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[co];
+        if (bb) v += bb[co];
+        if (p.out_act == OUT_RELU) v = v > 0.f ? v : 0.f;
+        if (omask) v *= omask[t];
+        float* dst = p.out + ob + (int64_t)co * p.o_cs + t;
+        if (!pre_res) {
+          if (p.res) v += p.res[rb + (int64_t)co * p.r_cs + t];
+          if (p.accum) v += *dst;
+        }
+        if (p.out_div != 1.f) v = v / p.out_div;
+        *dst = v;
+      }
+    }
+  }
+}
+
+template <int MB, int NB, int WM, int WN, int KT, int CI>
+static int32_t launch_cfg_kt(const ConvParams& p, hipStream_t stream) {
+  constexpr int MT = 32 * MB * WM, NT = 32 * NB * WN;
+  int64_t blocks = (int64_t)cdiv(p.N, NT) * cdiv(p.M, MT) * p.B;
+  if (blocks <= 0) return WETTS_OK;
+  WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
+  size_t lds = (size_t)2 * kConvCK * (CI * 64) * sizeof(float);
+  hipLaunchKernelGGL((conv_mfma_kt_kernel<MB, NB, WM, WN, KT, CI>), dim3((unsigned)blocks),
+                     dim3(256), lds, stream, p);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+template <int MB, int NB, int WM, int WN, int KT>
+static int32_t launch_kt_ci(const ConvParams& p, hipStream_t stream, bool* handled) {
+  constexpr int NT = 32 * NB * WN;
+  constexpr int CI0 = NT / 64 + 1;
+  const int need = cdiv(NT + p.span, 64);
+  if (need <= CI0) return launch_cfg_kt<MB, NB, WM, WN, KT, CI0>(p, stream);
+  if (need <= CI0 + 1) return launch_cfg_kt<MB, NB, WM, WN, KT, CI0 + 1>(p, stream);
+  *handled = false;
+  return WETTS_OK;
+}
+
+template <int MB, int NB, int WM, int WN>
+static int32_t launch_kt_dispatch(const ConvParams& p, hipStream_t stream, bool* handled) {
+  *handled = true;
+  switch (p.ktaps) {
+    case 1: return launch_kt_ci<MB, NB, WM, WN, 1>(p, stream, handled);
+    case 2: return launch_kt_ci<MB, NB, WM, WN, 2>(p, stream, handled);
+    case 3: return launch_kt_ci<MB, NB, WM, WN, 3>(p, stream, handled);
+    case 5: return launch_kt_ci<MB, NB, WM, WN, 5>(p, stream, handled);
+    case 7: return launch_kt_ci<MB, NB, WM, WN, 7>(p, stream, handled);
+    case 11: return launch_kt_ci<MB, NB, WM, WN, 11>(p, stream, handled);
+    default: *handled = false; return WETTS_OK;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// calibration: sustained rate of v_mfma_f32_32x32x2_f32 on this chip (no memory traffic)
+// ------------------------------------------------------------------------------------------
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, float a0, float b0) {
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a = a0 + (threadIdx.x & 7) * 1e-3f, b = b0 + (threadIdx.x & 3) * 1e-3f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int i = 0; i < NACC; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+int32_t bench_mfma_peak(int blocks_per_cu, int nacc, int iters, double* tflops, double* ms_out) {
+  float* out = nullptr;
+  WETTS_HIP_CHECK(hipMalloc((void**)&out, 4096));
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const int grid = 256 * blocks_per_cu;
+  auto launch = [&]() {
+    if (nacc == 1) hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f, 1.f);
+    else if (nacc == 2) hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f, 1.f);
+    else hipLaunchKernelGGL(mfma_peak_kernel<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f, 1.f);
+  };
+  launch();
+  (void)hipEventRecord(e0, 0);
+  launch();
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const int na = nacc >= 4 ? 4 : nacc;
+  double flops = (double)grid * 4 /*waves*/ * (double)iters * 8 * na * 4096.0;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  *ms_out = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(out);
+  return WETTS_OK;
+}
+
 static int g_conv_variant = -1;  // -1: read WETTS_CONV_VARIANT once; 0 single-role, 1 wave-specialised
 
 int conv_variant() {
@@ -684,6 +1001,15 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
   }
   const int var = conv_variant();
   const int64_t cols = (int64_t)p.N * p.B;
+  if (var == 5 && !p.ablate) {
+    bool handled = false;
+    int32_t rc;
+    if (p.M >= 128 && cols >= 4096) rc = launch_kt_dispatch<2, 2, 2, 2>(p, stream, &handled);
+    else if (p.M > 32 && cols >= 8192) rc = launch_kt_dispatch<2, 2, 1, 4>(p, stream, &handled);
+    else if (p.M <= 32 && cols >= 8192) rc = launch_kt_dispatch<1, 2, 1, 4>(p, stream, &handled);
+    else rc = launch_kt_dispatch<1, 1, 2, 2>(p, stream, &handled);
+    if (handled) return rc;
+  }
   if (var == 2 || var == 3) {  // B-operand register prefetch
     if (p.M >= 128 && cols >= 4096) {
       // few tiles per CU slot => quantisation tail; use half-width tiles there (variant 3)

@@ -1234,6 +1234,12 @@ int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int3
   return rc;
 }
 
+int32_t wetts_bench_mfma_peak(int32_t blocks_per_cu, int32_t nacc, int32_t iters, double* tflops,
+                              double* ms) {
+  WETTS_REQUIRE(tflops && ms && blocks_per_cu > 0 && iters > 0, "bad argument");
+  return bench_mfma_peak(blocks_per_cu, nacc, iters, tflops, ms);
+}
+
 int32_t wetts_set_conv_variant(int32_t v) {
   set_conv_variant(v);
   return WETTS_OK;
