@@ -110,7 +110,9 @@ void free_packed(PackedConv* pc) {
 // ------------------------------------------------------------------------------------------
 // the conv kernel
 // ------------------------------------------------------------------------------------------
-template <int MB, int NB, int WM, int WN, bool PF, bool DBG = false>
+// EPI: 0 = generic epilogue (runtime activation / masks / late residual), 1 = plain
+// (acc + bias [+ per-utterance bias]), 2 = plain followed by the MRF mean division.
+template <int MB, int NB, int WM, int WN, bool PF, bool DBG = false, int EPI = 0>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   // DBG instantiations honour p.ablate (microbenchmark only): 1 no MFMA, 2 no staging loads,
   // 4 no A loads, 8 no epilogue stores, 16 no LDS B reads
@@ -208,7 +210,38 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   // chunk 0 and the epilogue becomes store-only.  (Sum order changes by one f32 rounding.)
   const bool pre_res = (p.res != nullptr || p.accum) && p.up == 0 && p.out_act == OUT_NONE &&
                        p.out_mask == nullptr;
-  if (pre_res) {
+  // fast path: the whole tile lies inside the output and this is a plain (non-transposed) conv;
+  // then every address is  uniform 64-bit base + 32-bit (row*stride + lane) offset  and there are
+  // no per-element bounds checks -- the prologue/epilogue shrink from ~25 to ~4 instructions per
+  // element, which matters most for the C=32/64 stages whose MFMA loop is only a few k-steps.
+  const bool full_tile = (p.up == 0) && (n0 + NT <= p.N) && (mtile * MT + MT <= p.M);
+  const int wrow0 = mtile * MT + wm * MB * 32;  // first row of this wave (uniform)
+  const int wcol0 = n0 + wn * (32 * NB);        // first column of this wave (uniform)
+  if (pre_res && full_tile) {
+    const char* rbase = p.res ? reinterpret_cast<const char*>(
+                                    p.res + (int64_t)b * p.r_bs + (int64_t)wrow0 * p.r_cs + wcol0)
+                              : nullptr;
+    const char* abase_o = reinterpret_cast<const char*>(
+        p.out + (int64_t)b * p.o_bs + (int64_t)wrow0 * p.o_cs + wcol0);
+    const unsigned rcs4 = (unsigned)p.r_cs * 4u, ocs4 = (unsigned)p.o_cs * 4u;
+    const unsigned rlane = (unsigned)(4 * (lane >> 5)) * rcs4 + (unsigned)(lane & 31) * 4u;
+    const unsigned olane = (unsigned)(4 * (lane >> 5)) * ocs4 + (unsigned)(lane & 31) * 4u;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned rr = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2));
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          float v = 0.f;
+          if (rbase) v = *reinterpret_cast<const float*>(rbase + (rr * rcs4 + rlane + 128u * j));
+          if (p.accum)
+            v += *reinterpret_cast<const float*>(abase_o + (rr * ocs4 + olane + 128u * j));
+          acc[i][j][r] = v;
+        }
+      }
+    }
+  } else if (pre_res) {
     const int64_t ob0 = (int64_t)b * p.o_bs;
     const int64_t rb0 = (int64_t)b * p.r_bs;
 #pragma unroll
@@ -310,16 +343,69 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         }
       }
     }
-    if (more) store_chunk((c & 1) ? buf0 : buf1);
-    __syncthreads();
+    if (!(DBG && (p.ablate & 32))) {
+      if (more) store_chunk((c & 1) ? buf0 : buf1);
+      __syncthreads();
+    }
   }
 
   if (DBG && no_mfma) acc[0][0][0] += dbg_sink;
+  if (DBG && (p.ablate & 64)) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 123.456f) p.out[0] = sacc;
+    return;
+  }
   // ---- epilogue ---------------------------------------------------------------------------
   const int64_t ob = (int64_t)b * p.o_bs;
   const int64_t rb = (int64_t)b * p.r_bs;
   const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
   const float* omask = p.out_mask ? p.out_mask + (int64_t)b * p.out_mask_stride : nullptr;
+  if (EPI != 0 && full_tile) {
+    char* obase = reinterpret_cast<char*>(p.out + ob + (int64_t)wrow0 * p.o_cs + wcol0);
+    const unsigned ocs4 = (unsigned)p.o_cs * 4u;
+    const unsigned olane = (unsigned)(4 * half) * ocs4 + (unsigned)(lane & 31) * 4u;
+    // all bias loads first (back to back), then the store stream
+    float bia[MB][16];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bia[i][r] = 0.f;
+    if (p.bias) {
+      const float* bp = p.bias + wrow0 + 4 * half;
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bia[i][r] = bp[i * 32 + (r & 3) + 8 * (r >> 2)];
+    }
+    if (bb) {
+      const float* bp = bb + wrow0 + 4 * half;
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bia[i][r] += bp[i * 32 + (r & 3) + 8 * (r >> 2)];
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rloc = i * 32 + (r & 3) + 8 * (r >> 2);
+        const unsigned roff = (unsigned)rloc * ocs4 + olane;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          float v = acc[i][j][r] + bia[i][r];
+          if (EPI == 2) v = v / p.out_div;
+          *reinterpret_cast<float*>(obase + (roff + 128u * j)) = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MB; ++i) {
     const int mrow0 = mtile * MT + (wm * MB + i) * 32 + 4 * half;
@@ -875,12 +961,33 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, f
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   float a = a0 + (threadIdx.x & 7) * 1e-3f, b = b0 + (threadIdx.x & 3) * 1e-3f;
-  for (int it = 0; it < iters; ++it) {
+  if (a0 < 0.f) {
+    // random-operand mode: 8 distinct pseudo-random A and B registers per lane (data toggling
+    // like a real conv), products have random sign so the accumulators random-walk
+    float ar[8], br[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
+      unsigned h = (threadIdx.x * 8 + u + blockIdx.x * 2048) * 2654435761u;
+      h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+      ar[u] = ((float)(h & 0xffff) / 32768.f - 1.f);
+      br[u] = ((float)((h >> 16) & 0xffff) / 32768.f - 1.f);
+    }
+    for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int i = 0; i < NACC; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[u], br[(u + i) & 7], acc[i], 0, 0, 0);
+      }
+    }
+  } else {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+      }
     }
   }
   float s = 0.f;
@@ -892,16 +999,18 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, f
 }
 
 int32_t bench_mfma_peak(int blocks_per_cu, int nacc, int iters, double* tflops, double* ms_out) {
+  const float a0 = nacc < 0 ? -1.f : 1.f;
+  nacc = nacc < 0 ? -nacc : nacc;
   float* out = nullptr;
   WETTS_HIP_CHECK(hipMalloc((void**)&out, 4096));
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  const int grid = 256 * blocks_per_cu;
+  const int grid = blocks_per_cu >= 1000 ? blocks_per_cu : 256 * blocks_per_cu;
   auto launch = [&]() {
-    if (nacc == 1) hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f, 1.f);
-    else if (nacc == 2) hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f, 1.f);
-    else hipLaunchKernelGGL(mfma_peak_kernel<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f, 1.f);
+    if (nacc == 1) hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(grid), dim3(256), 0, 0, out, iters, a0, 1.f);
+    else if (nacc == 2) hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(grid), dim3(256), 0, 0, out, iters, a0, 1.f);
+    else hipLaunchKernelGGL(mfma_peak_kernel<4>, dim3(grid), dim3(256), 0, 0, out, iters, a0, 1.f);
   };
   launch();
   (void)hipEventRecord(e0, 0);
@@ -951,23 +1060,31 @@ static int32_t launch_cfg_ws(ConvParams p, hipStream_t stream) {
 
 template <int MB, int NB, int WM, int WN, bool PF = false>
 static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
-  if (p.ablate) {
-    constexpr int NTd = 32 * NB * WN;
-    int64_t blocksd = (int64_t)cdiv(p.N, NTd) * cdiv(p.M, 32 * MB * WM) * p.B;
-    size_t ldsd = (size_t)2 * kConvCK * (NTd + p.span) * sizeof(float);
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, true>), dim3((unsigned)blocksd),
-                       dim3(256), ldsd, stream, p);
-    WETTS_LAUNCH_CHECK();
-    return WETTS_OK;
-  }
   constexpr int MT = 32 * MB * WM, NT = 32 * NB * WN;
   int ntiles = cdiv(p.N, NT), mtiles = cdiv(p.M, MT);
   int64_t blocks = (int64_t)ntiles * mtiles * p.B;
   if (blocks <= 0) return WETTS_OK;
   WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
   size_t lds = (size_t)2 * kConvCK * (NT + p.span) * sizeof(float);
-  hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF>), dim3((unsigned)blocks), dim3(256), lds,
-                     stream, p);
+  if (p.ablate) {
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, true, 0>), dim3((unsigned)blocks),
+                       dim3(256), lds, stream, p);
+    WETTS_LAUNCH_CHECK();
+    return WETTS_OK;
+  }
+  // epilogue specialisation: residual / running sum are folded into the accumulator init
+  // whenever there is no output activation or mask, which leaves "acc + bias [/ div]"
+  const bool plain = p.up == 0 && p.out_act == OUT_NONE && p.out_mask == nullptr;
+  if (plain && p.out_div == 1.f) {
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 1>), dim3((unsigned)blocks),
+                       dim3(256), lds, stream, p);
+  } else if (plain) {
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 2>), dim3((unsigned)blocks),
+                       dim3(256), lds, stream, p);
+  } else {
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 0>), dim3((unsigned)blocks),
+                       dim3(256), lds, stream, p);
+  }
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
