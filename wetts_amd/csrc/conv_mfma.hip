@@ -446,511 +446,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
 
 // ------------------------------------------------------------------------------------------
-// wave-specialised variant: waves 0-3 run the MFMA loop and only ever wait on their own
-// A-fragment prefetch; wave 4 is a dedicated loader that streams the next input chunk
-// HBM -> registers -> LDS (16-byte loads when the layout allows) while the others compute.
-// vmcnt is per wave, so the compute waves' `s_waitcnt vmcnt(0)` no longer drains the staging
-// loads (the coupling the single-role kernel above suffers once per chunk).
-// ------------------------------------------------------------------------------------------
-template <int MB, int NB, int WM, int WN>
-__global__ __launch_bounds__(320) void conv_mfma_ws_kernel(const ConvParams p) {
-  static_assert(WM * WN == 4, "4 compute waves per block");
-  constexpr int CK = kConvCK;
-  constexpr int MT = 32 * MB * WM;
-  constexpr int NT = 32 * NB * WN;
-  constexpr int MAXW = NT + 128 + 8;           // span <= 128 enforced on the host, +shift/round
-  constexpr int MAXCI = (MAXW + 63) / 64;      // scalar path: dwords per lane per row
-  constexpr int MAXV = (MAXW / 4 + 63) / 64;   // vector path: float4 per lane per row
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  const int ntiles = (p.N + NT - 1) / NT;
-  const int mtiles = (p.M + MT - 1) / MT;
-  int bid = blockIdx.x;
-  const int ntile = bid % ntiles;
-  bid /= ntiles;
-  const int mtile = bid % mtiles;
-  const int b = bid / mtiles;
-
-  const int n0 = ntile * NT;
-  const int t_start = n0 + p.off_lo;                       // first input sample of the tile
-  const int shift = ((t_start % 4) + 4) % 4;               // distance to the 16-byte boundary below
-  const int t_al = t_start - shift;
-  const int Wl = (NT + p.span + shift + 3) & ~3;            // LDS row width (floats)
-  float* buf0 = smem;
-  float* buf1 = smem + CK * Wl;
-
-  if (wave == 4) {
-    // ================================ loader wave ========================================
-    const float* xb = p.x + (int64_t)b * p.x_bs;
-    const float* mrow = p.in_mask ? p.in_mask + (int64_t)b * p.in_mask_stride : nullptr;
-    const bool lrelu = p.in_act == IN_LRELU;
-    const float slope = p.in_slope;
-    if (p.vec_in) {
-      const int nv = Wl / 4;
-      float4 mk[MAXV];
-      bool vok[MAXV];
-#pragma unroll
-      for (int i = 0; i < MAXV; ++i) {
-        const int v = lane + 64 * i;
-        const int t = t_al + 4 * v;
-        vok[i] = (v < nv) && (t >= 0) && (t + 3 < p.Tin);
-        mk[i] = (vok[i] && mrow) ? *reinterpret_cast<const float4*>(mrow + t)
-                                 : make_float4(1.f, 1.f, 1.f, 1.f);
-      }
-      auto stage = [&](int c, float* buf) {
-        float4 st[CK][MAXV];
-#pragma unroll
-        for (int r = 0; r < CK; ++r) {
-          const int ci = c * CK + r;
-          const int ch = p.in_rev_base >= 0 ? (p.in_rev_base - ci) : ci;
-          const float* xr = xb + (int64_t)ch * p.x_cs + t_al;
-#pragma unroll
-          for (int i = 0; i < MAXV; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < p.Cin && vok[i]) v = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * i));
-            st[r][i] = v;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < CK; ++r) {
-#pragma unroll
-          for (int i = 0; i < MAXV; ++i) {
-            const int v = lane + 64 * i;
-            if (v < nv) {
-              float4 q = st[r][i];
-              if (lrelu) {
-                q.x = q.x > 0.f ? q.x : q.x * slope;
-                q.y = q.y > 0.f ? q.y : q.y * slope;
-                q.z = q.z > 0.f ? q.z : q.z * slope;
-                q.w = q.w > 0.f ? q.w : q.w * slope;
-              }
-              q.x *= mk[i].x; q.y *= mk[i].y; q.z *= mk[i].z; q.w *= mk[i].w;
-              *reinterpret_cast<float4*>(buf + r * Wl + 4 * v) = q;
-            }
-          }
-        }
-      };
-      stage(0, buf0);
-      __syncthreads();
-      for (int c = 0; c < p.nchunks; ++c) {
-        if (c + 1 < p.nchunks) stage(c + 1, (c & 1) ? buf0 : buf1);
-        __syncthreads();
-      }
-    } else {
-      int tcol[MAXCI];
-      float mcol[MAXCI];
-#pragma unroll
-      for (int i = 0; i < MAXCI; ++i) {
-        const int col = lane + 64 * i;
-        const int t = t_al + col;
-        const bool ok = (col < Wl) && (t >= 0) && (t < p.Tin);
-        tcol[i] = ok ? t : -1;
-        mcol[i] = (ok && mrow) ? mrow[t] : 1.f;
-      }
-      auto stage = [&](int c, float* buf) {
-        for (int r0 = 0; r0 < CK; r0 += 4) {
-          float st[4][MAXCI];
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int ci = c * CK + r0 + rr;
-            const int ch = p.in_rev_base >= 0 ? (p.in_rev_base - ci) : ci;
-            const float* xr = xb + (int64_t)ch * p.x_cs;
-#pragma unroll
-            for (int i = 0; i < MAXCI; ++i) {
-              float v = 0.f;
-              if (ci < p.Cin && tcol[i] >= 0) v = xr[tcol[i]];
-              st[rr][i] = v;
-            }
-          }
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-            for (int i = 0; i < MAXCI; ++i) {
-              const int col = lane + 64 * i;
-              if (col < Wl) {
-                float v = st[rr][i];
-                if (lrelu) v = v > 0.f ? v : v * slope;
-                buf[(r0 + rr) * Wl + col] = v * mcol[i];
-              }
-            }
-          }
-        }
-      };
-      stage(0, buf0);
-      __syncthreads();
-      for (int c = 0; c < p.nchunks; ++c) {
-        if (c + 1 < p.nchunks) stage(c + 1, (c & 1) ? buf0 : buf1);
-        __syncthreads();
-      }
-    }
-    return;
-  }
-
-  // ================================= compute waves =========================================
-  const int wm = wave / WN, wn = wave % WN;
-  f32x16 acc[MB][NB];
-#pragma unroll
-  for (int i = 0; i < MB; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int G = p.nchunks * p.ktaps * 2;
-  const float4* abase[MB];
-#pragma unroll
-  for (int i = 0; i < MB; ++i) {
-    int mt32 = mtile * (MB * WM) + wm * MB + i;
-    abase[i] = reinterpret_cast<const float4*>(p.wpk) + ((int64_t)mt32 * G) * 64 + lane;
-  }
-  float4 a_nxt[MB];
-#pragma unroll
-  for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][0];
-
-  const int half = lane >> 5;
-  const int bcol0 = wn * (32 * NB) + (lane & 31) - p.pad - p.off_lo + shift;
-  int g = 0;
-  __syncthreads();
-  for (int c = 0; c < p.nchunks; ++c) {
-    const float* cur = (c & 1) ? buf1 : buf0;
-    for (int tap = 0; tap < p.ktaps; ++tap) {
-      const int coff = bcol0 + tap * p.dil;
-#pragma unroll
-      for (int hp = 0; hp < 2; ++hp) {
-        float4 a_cur[MB];
-#pragma unroll
-        for (int i = 0; i < MB; ++i) a_cur[i] = a_nxt[i];
-        ++g;
-        if (g < G) {
-#pragma unroll
-          for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][(int64_t)g * 64];
-        }
-        const float* brow = cur + (hp * 8 + half) * Wl + coff;
-        float bv[2][NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) bv[0][j] = brow[32 * j];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          if (s < 3) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j) bv[(s + 1) & 1][j] = brow[(s + 1) * 2 * Wl + 32 * j];
-          }
-#pragma unroll
-          for (int i = 0; i < MB; ++i) {
-            const float av = s == 0 ? a_cur[i].x : s == 1 ? a_cur[i].y : s == 2 ? a_cur[i].z
-                                                                                 : a_cur[i].w;
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s & 1][j], acc[i][j], 0, 0, 0);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue (same as the single-role kernel) --------------------------------------------
-  const int64_t ob = (int64_t)b * p.o_bs;
-  const int64_t rb = (int64_t)b * p.r_bs;
-  const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
-  const float* omask = p.out_mask ? p.out_mask + (int64_t)b * p.out_mask_stride : nullptr;
-#pragma unroll
-  for (int i = 0; i < MB; ++i) {
-    const int mrow0 = mtile * MT + (wm * MB + i) * 32 + 4 * half;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int col = n0 + wn * (32 * NB) + j * 32 + (lane & 31);
-      if (col >= p.N) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mrow0 + (r & 3) + 8 * (r >> 2);
-        if (row >= p.M) continue;
-        int co = row, t = col;
-        if (p.up > 0) {
-          co = row / p.up;
-          t = col * p.up + (row - co * p.up) - p.up_pad;
-          if (t < 0 || t >= p.Tout) continue;
-        }
-        float v = acc[i][j][r];
-        if (p.bias) v += p.bias[co];
-        if (bb) v += bb[co];
-        if (p.out_act == OUT_RELU) v = v > 0.f ? v : 0.f;
-        if (omask) v *= omask[t];
-        if (p.res) v += p.res[rb + (int64_t)co * p.r_cs + t];
-        float* dst = p.out + ob + (int64_t)co * p.o_cs + t;
-        if (p.accum) v += *dst;
-        if (p.out_div != 1.f) v = v / p.out_div;
-        *dst = v;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// tap-count-specialised variant (the production kernel for the common tap counts).
-// The whole chunk body -- 2*KT groups of 4 k-steps -- is straight-line code:
-//   * every global load is UNCONDITIONAL (addresses clamped, validity applied when the value is
-//     written to LDS), so there is no control flow between loads and the compiler can emit exact
-//     counted `s_waitcnt vmcnt(N)`: the A-fragment wait no longer drains the staging loads;
-//   * the staging loads of chunk c+1 are issued right after the A prefetch of group 0 and their
-//     LDS stores sit after group GS, in the middle of the MFMA stream, so the end-of-chunk barrier
-//     is a bare rendezvous instead of a store phase all co-resident blocks hit together;
-//   * B operands are prefetched one k-step ahead across group boundaries.
-// ------------------------------------------------------------------------------------------
-template <int MB, int NB, int WM, int WN, int KT, int CI>
-__global__ __launch_bounds__(256) void conv_mfma_kt_kernel(const ConvParams p) {
-  static_assert(WM * WN == 4, "4 waves per block");
-  constexpr int CK = kConvCK;
-  constexpr int MT = 32 * MB * WM;
-  constexpr int NT = 32 * NB * WN;
-  constexpr int WL = CI * 64;                    // LDS row width: every lane stores, no branches
-  constexpr int RPW = CK / 4;
-  constexpr int NG = 2 * KT;                     // groups of 4 k-steps per chunk
-  constexpr int GS = NG >= 6 ? 3 : (NG - 1);     // group after which the staged chunk goes to LDS
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int half = lane >> 5;
-
-  const int ntiles = (p.N + NT - 1) / NT;
-  const int mtiles = (p.M + MT - 1) / MT;
-  int bid = blockIdx.x;
-  const int ntile = bid % ntiles;
-  bid /= ntiles;
-  const int mtile = bid % mtiles;
-  const int b = bid / mtiles;
-
-  const int n0 = ntile * NT;
-  const int W = NT + p.span;
-  float* buf0 = smem;
-  float* buf1 = smem + CK * WL;
-
-  const float* xb = p.x + (int64_t)b * p.x_bs;
-  const float* mrow = p.in_mask ? p.in_mask + (int64_t)b * p.in_mask_stride : nullptr;
-
-  // per-column staging info (tile constant): clamped sample index + multiplier (0 = padding)
-  int tcl[CI];
-  float mcol[CI];
-#pragma unroll
-  for (int i = 0; i < CI; ++i) {
-    const int col = lane + 64 * i;
-    const int t = n0 + p.off_lo + col;
-    const bool ok = (col < W) && (t >= 0) && (t < p.Tin);
-    const int tc = t < 0 ? 0 : (t >= p.Tin ? p.Tin - 1 : t);
-    tcl[i] = tc;
-    mcol[i] = ok ? (mrow ? mrow[tc] : 1.f) : 0.f;
-  }
-  const bool lrelu = p.in_act == IN_LRELU;
-  const float slope = lrelu ? p.in_slope : 1.f;  // v>0 ? v : v*slope with slope 1 == identity
-
-  float stage[RPW][CI];
-  auto load_chunk = [&](int c) {  // unconditional loads from clamped addresses
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      int ci = c * CK + wave + 4 * r;
-      ci = ci < p.Cin ? ci : p.Cin - 1;
-      const int ch = p.in_rev_base >= 0 ? (p.in_rev_base - ci) : ci;
-      const float* xr = xb + (int64_t)ch * p.x_cs;
-#pragma unroll
-      for (int i = 0; i < CI; ++i) stage[r][i] = xr[tcl[i]];
-    }
-  };
-  auto store_chunk = [&](int c, float* buf) {  // unconditional stores (row width = CI*64)
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      const float rowok = (c * CK + wave + 4 * r) < p.Cin ? 1.f : 0.f;
-      float* row = buf + (wave + 4 * r) * WL + lane;
-#pragma unroll
-      for (int i = 0; i < CI; ++i) {
-        float v = stage[r][i];
-        v = v > 0.f ? v : v * slope;
-        row[64 * i] = v * (mcol[i] * rowok);
-      }
-    }
-  };
-
-  f32x16 acc[MB][NB];
-#pragma unroll
-  for (int i = 0; i < MB; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const bool pre_res = (p.res != nullptr || p.accum) && p.up == 0 && p.out_act == OUT_NONE &&
-                       p.out_mask == nullptr;
-  if (pre_res) {
-    const int64_t ob0 = (int64_t)b * p.o_bs;
-    const int64_t rb0 = (int64_t)b * p.r_bs;
-#pragma unroll
-    for (int i = 0; i < MB; ++i) {
-      const int mrow0 = mtile * MT + (wm * MB + i) * 32 + 4 * half;
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const int col = n0 + wn * (32 * NB) + j * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = mrow0 + (r & 3) + 8 * (r >> 2);
-          float v = 0.f;
-          if (col < p.N && row < p.M) {
-            if (p.res) v = p.res[rb0 + (int64_t)row * p.r_cs + col];
-            if (p.accum) v += p.out[ob0 + (int64_t)row * p.o_cs + col];
-          }
-          acc[i][j][r] = v;
-        }
-      }
-    }
-  }
-
-  // packed A stream; the buffer carries one padding tile so group G may be prefetched blindly
-  const int G = p.nchunks * NG;
-  const float4* abase[MB];
-#pragma unroll
-  for (int i = 0; i < MB; ++i) {
-    const int mt32 = mtile * (MB * WM) + wm * MB + i;
-    abase[i] = reinterpret_cast<const float4*>(p.wpk) + ((int64_t)mt32 * G) * 64 + lane;
-  }
-  float4 a_nxt[MB];
-#pragma unroll
-  for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][0];
-
-  load_chunk(0);
-  store_chunk(0, buf0);
-  __syncthreads();
-
-  const int bcol0 = half * WL + wn * (32 * NB) + (lane & 31) - p.pad - p.off_lo;
-  for (int c = 0; c < p.nchunks; ++c) {
-    const float* cur = ((c & 1) ? buf1 : buf0) + bcol0;
-    float* nxt = (c & 1) ? buf0 : buf1;
-    const int cn = (c + 1 < p.nchunks) ? (c + 1) : c;  // last chunk re-stages itself (harmless)
-    float bv[2][NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) bv[0][j] = cur[32 * j];
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-      float4 a_cur[MB];
-#pragma unroll
-      for (int i = 0; i < MB; ++i) a_cur[i] = a_nxt[i];
-#pragma unroll
-      for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][(int64_t)(c * NG + gi + 1) * 64];
-      if (gi == 0) {
-        load_chunk(cn);
-        __builtin_amdgcn_sched_barrier(0);  // keep the staging loads HERE, early in the chunk
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int ks = gi * 4 + s + 1;  // B operands of the next k-step (next group / tap too)
-        if (ks < NG * 4) {
-          const float* brow = cur + ((ks & 7) * 2) * WL + (ks >> 3) * p.dil;
-#pragma unroll
-          for (int j = 0; j < NB; ++j) bv[ks & 1][j] = brow[32 * j];
-        }
-#pragma unroll
-        for (int i = 0; i < MB; ++i) {
-          const float av = s == 0 ? a_cur[i].x : s == 1 ? a_cur[i].y : s == 2 ? a_cur[i].z
-                                                                               : a_cur[i].w;
-#pragma unroll
-          for (int j = 0; j < NB; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[(gi * 4 + s) & 1][j],
-                                                              acc[i][j], 0, 0, 0);
-        }
-      }
-      if (gi == GS) {
-        __builtin_amdgcn_sched_barrier(0);
-        store_chunk(cn, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue ---------------------------------------------------------------------------
-  const int64_t ob = (int64_t)b * p.o_bs;
-  const int64_t rb = (int64_t)b * p.r_bs;
-  const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
-  const float* omask = p.out_mask ? p.out_mask + (int64_t)b * p.out_mask_stride : nullptr;
-#pragma unroll
-  for (int i = 0; i < MB; ++i) {
-    const int mrow0 = mtile * MT + (wm * MB + i) * 32 + 4 * half;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int col = n0 + wn * (32 * NB) + j * 32 + (lane & 31);
-      if (col >= p.N) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mrow0 + (r & 3) + 8 * (r >> 2);
-        if (row >= p.M) continue;
-        int co = row, t = col;
-        if (p.up > 0) {
-          co = row / p.up;
-          t = col * p.up + (row - co * p.up) - p.up_pad;
-          if (t < 0 || t >= p.Tout) continue;
-        }
-        float v = acc[i][j][r];
-        if (p.bias) v += p.bias[co];
-        if (bb) v += bb[co];
-        if (p.out_act == OUT_RELU) v = v > 0.f ? v : 0.f;
-        if (omask) v *= omask[t];
-        float* dst = p.out + ob + (int64_t)co * p.o_cs + t;
-        if (!pre_res) {
-          if (p.res) v += p.res[rb + (int64_t)co * p.r_cs + t];
-          if (p.accum) v += *dst;
-        }
-        if (p.out_div != 1.f) v = v / p.out_div;
-        *dst = v;
-      }
-    }
-  }
-}
-
-template <int MB, int NB, int WM, int WN, int KT, int CI>
-static int32_t launch_cfg_kt(const ConvParams& p, hipStream_t stream) {
-  constexpr int MT = 32 * MB * WM, NT = 32 * NB * WN;
-  int64_t blocks = (int64_t)cdiv(p.N, NT) * cdiv(p.M, MT) * p.B;
-  if (blocks <= 0) return WETTS_OK;
-  WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
-  size_t lds = (size_t)2 * kConvCK * (CI * 64) * sizeof(float);
-  hipLaunchKernelGGL((conv_mfma_kt_kernel<MB, NB, WM, WN, KT, CI>), dim3((unsigned)blocks),
-                     dim3(256), lds, stream, p);
-  WETTS_LAUNCH_CHECK();
-  return WETTS_OK;
-}
-
-template <int MB, int NB, int WM, int WN, int KT>
-static int32_t launch_kt_ci(const ConvParams& p, hipStream_t stream, bool* handled) {
-  constexpr int NT = 32 * NB * WN;
-  constexpr int CI0 = NT / 64 + 1;
-  const int need = cdiv(NT + p.span, 64);
-  if (need <= CI0) return launch_cfg_kt<MB, NB, WM, WN, KT, CI0>(p, stream);
-  if (need <= CI0 + 1) return launch_cfg_kt<MB, NB, WM, WN, KT, CI0 + 1>(p, stream);
-  *handled = false;
-  return WETTS_OK;
-}
-
-template <int MB, int NB, int WM, int WN>
-static int32_t launch_kt_dispatch(const ConvParams& p, hipStream_t stream, bool* handled) {
-  *handled = true;
-  switch (p.ktaps) {
-    case 1: return launch_kt_ci<MB, NB, WM, WN, 1>(p, stream, handled);
-    case 2: return launch_kt_ci<MB, NB, WM, WN, 2>(p, stream, handled);
-    case 3: return launch_kt_ci<MB, NB, WM, WN, 3>(p, stream, handled);
-    case 5: return launch_kt_ci<MB, NB, WM, WN, 5>(p, stream, handled);
-    case 7: return launch_kt_ci<MB, NB, WM, WN, 7>(p, stream, handled);
-    case 11: return launch_kt_ci<MB, NB, WM, WN, 11>(p, stream, handled);
-    default: *handled = false; return WETTS_OK;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // calibration: sustained rate of v_mfma_f32_32x32x2_f32 on this chip (no memory traffic)
 // ------------------------------------------------------------------------------------------
 template <int NACC>
@@ -1040,24 +535,6 @@ int conv_variant() {
 }
 void set_conv_variant(int v) { g_conv_variant = v; }
 
-template <int MB, int NB, int WM, int WN>
-static int32_t launch_cfg_ws(ConvParams p, hipStream_t stream) {
-  constexpr int MT = 32 * MB * WM, NT = 32 * NB * WN;
-  int ntiles = cdiv(p.N, NT), mtiles = cdiv(p.M, MT);
-  int64_t blocks = (int64_t)ntiles * mtiles * p.B;
-  if (blocks <= 0) return WETTS_OK;
-  WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
-  const bool al16 = ((uintptr_t)p.x % 16 == 0) && (p.x_bs % 4 == 0) && (p.x_cs % 4 == 0) &&
-                    (p.Tin % 4 == 0);
-  const bool mal16 = !p.in_mask || (((uintptr_t)p.in_mask % 16 == 0) && (p.in_mask_stride % 4 == 0));
-  p.vec_in = (al16 && mal16) ? 1 : 0;
-  size_t lds = (size_t)2 * kConvCK * (NT + p.span + 8) * sizeof(float);
-  hipLaunchKernelGGL((conv_mfma_ws_kernel<MB, NB, WM, WN>), dim3((unsigned)blocks), dim3(320), lds,
-                     stream, p);
-  WETTS_LAUNCH_CHECK();
-  return WETTS_OK;
-}
-
 template <int MB, int NB, int WM, int WN, bool PF = false>
 static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
   constexpr int MT = 32 * MB * WM, NT = 32 * NB * WN;
@@ -1110,34 +587,7 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
     p.N = p.Tout;
   }
   // tile selection: fill the chip first, then maximise per-wave register reuse
-  if (conv_variant() == 1) {
-    if (p.M >= 128 && (int64_t)p.N * p.B >= 4096) return launch_cfg_ws<2, 2, 2, 2>(p, stream);
-    if (p.M > 32 && (int64_t)p.N * p.B >= 8192) return launch_cfg_ws<2, 2, 1, 4>(p, stream);
-    if (p.M <= 32 && (int64_t)p.N * p.B >= 8192) return launch_cfg_ws<1, 2, 1, 4>(p, stream);
-    return launch_cfg_ws<1, 1, 2, 2>(p, stream);
-  }
-  const int var = conv_variant();
   const int64_t cols = (int64_t)p.N * p.B;
-  if (var == 5 && !p.ablate) {
-    bool handled = false;
-    int32_t rc;
-    if (p.M >= 128 && cols >= 4096) rc = launch_kt_dispatch<2, 2, 2, 2>(p, stream, &handled);
-    else if (p.M > 32 && cols >= 8192) rc = launch_kt_dispatch<2, 2, 1, 4>(p, stream, &handled);
-    else if (p.M <= 32 && cols >= 8192) rc = launch_kt_dispatch<1, 2, 1, 4>(p, stream, &handled);
-    else rc = launch_kt_dispatch<1, 1, 2, 2>(p, stream, &handled);
-    if (handled) return rc;
-  }
-  if (var == 2 || var == 3) {  // B-operand register prefetch
-    if (p.M >= 128 && cols >= 4096) {
-      // few tiles per CU slot => quantisation tail; use half-width tiles there (variant 3)
-      const int64_t tiles = (int64_t)cdiv(p.N, 128) * cdiv(p.M, 128) * p.B;
-      if (var == 3 && tiles < 768 * 4) return launch_cfg<2, 1, 2, 2, true>(p, stream);
-      return launch_cfg<2, 2, 2, 2, true>(p, stream);
-    }
-    if (p.M > 32 && cols >= 8192) return launch_cfg<2, 2, 1, 4, true>(p, stream);
-    if (p.M <= 32 && cols >= 8192) return launch_cfg<1, 2, 1, 4, true>(p, stream);
-    return launch_cfg<1, 1, 2, 2, true>(p, stream);
-  }
   if (p.M >= 128 && cols >= 4096) return launch_cfg<2, 2, 2, 2>(p, stream);
   if (p.M > 32 && cols >= 8192) return launch_cfg<2, 2, 1, 4>(p, stream);
   if (p.M <= 32 && cols >= 8192) return launch_cfg<1, 2, 1, 4>(p, stream);
