@@ -1,0 +1,134 @@
+"""ONNX-Runtime-shaped sessions over the HIP path.
+
+Every Python caller of the reference's exported models goes through
+`session.run(output_names, feeds)` with the tensor names fixed by export_onnx.py:95-189:
+    full model : input int64[B,T], input_lengths int64[B], scales f32[B,3], sid int64[B]
+                 -> output f32[B,1,T_audio]                       (wetts/cli/model.py:48-58)
+    encoder    : same feeds -> z f32[B,L,192]                     (inference_onnx.py:139-145)
+    decoder    : z f32[B,L,192], sid int64[B] -> output f32[B,1,L*hop]   (inference_onnx.py:146-151)
+These shims accept / return numpy arrays exactly like ort.InferenceSession so wetts/cli/model.py,
+inference_onnx.py or the Triton python backend can swap the session object and nothing else.
+"""
+import numpy as np
+import torch
+
+from .models import SynthesizerTrn
+
+
+class _Arg:
+    def __init__(self, name, shape, type_):
+        self.name, self.shape, self.type = name, shape, type_
+
+
+class _SessionBase:
+    def __init__(self, model: SynthesizerTrn):
+        if model._handle is None:
+            raise RuntimeError("model must have weights loaded and live on a HIP device")
+        self.model = model
+
+    def _dev(self, a, dtype):
+        return torch.as_tensor(np.asarray(a)).to(device=self.model.device, dtype=dtype)
+
+    def get_providers(self):
+        return ["WettsHIPExecutionProvider"]
+
+    def _check(self, output_names):
+        names = [o.name for o in self.get_outputs()]
+        if output_names is not None:
+            for n in output_names:
+                if n not in names:
+                    raise ValueError(f"unknown output {n!r}; available: {names}")
+
+
+class InferenceSession(_SessionBase):
+    """The non-streaming model (export_forward, models.py:333-344)."""
+
+    def get_inputs(self):
+        return [_Arg("input", ["B", "T"], "tensor(int64)"),
+                _Arg("input_lengths", ["B"], "tensor(int64)"),
+                _Arg("scales", ["B", 3], "tensor(float)"), _Arg("sid", ["B"], "tensor(int64)")]
+
+    def get_outputs(self):
+        return [_Arg("output", ["B", 1, "L"], "tensor(float)")]
+
+    def run(self, output_names, feeds, run_options=None):
+        self._check(output_names)
+        x = self._dev(feeds["input"], torch.int64)
+        xl = self._dev(feeds["input_lengths"], torch.int64)
+        scales = np.asarray(feeds["scales"], dtype=np.float32)
+        sid = feeds.get("sid")  # the Triton `generator` model omits it (config.pbtxt:21-46)
+        sid = self._dev(sid, torch.int64) if sid is not None else \
+            torch.zeros(x.shape[0], dtype=torch.int64, device=self.model.device)
+        audio = self.model.export_forward(x, xl, torch.from_numpy(scales), sid)
+        return [audio.cpu().numpy()]
+
+
+class EncoderSession(_SessionBase):
+    """Streaming front half (export_encoder_forward, models.py:346-358): -> z [B, L, inter]."""
+
+    def get_inputs(self):
+        return InferenceSession.get_inputs(self)
+
+    def get_outputs(self):
+        return [_Arg("z", ["B", "L", self.model.inter_channels], "tensor(float)")]
+
+    def run(self, output_names, feeds, run_options=None):
+        self._check(output_names)
+        x = self._dev(feeds["input"], torch.int64)
+        xl = self._dev(feeds["input_lengths"], torch.int64)
+        scales = np.asarray(feeds["scales"], dtype=np.float32)
+        sid = self._dev(feeds["sid"], torch.int64)
+        z = self.model.export_encoder_forward(x, xl, torch.from_numpy(scales), sid)
+        return [z.contiguous().cpu().numpy()]
+
+
+class DecoderSession(_SessionBase):
+    """Streaming back half (export_decoder_forward, models.py:360-363): z chunk -> audio."""
+
+    def get_inputs(self):
+        return [_Arg("z", ["B", "L", self.model.inter_channels], "tensor(float)"),
+                _Arg("sid", ["B"], "tensor(int64)")]
+
+    def get_outputs(self):
+        return [_Arg("output", ["B", 1, "L"], "tensor(float)")]
+
+    def run(self, output_names, feeds, run_options=None):
+        self._check(output_names)
+        z = self._dev(feeds["z"], torch.float32)
+        sid = self._dev(feeds["sid"], torch.int64)
+        return [self.model.export_decoder_forward(z, sid).cpu().numpy()]
+
+
+# ---- chunked streaming helpers -----------------------------------------------------------------
+# Same protocol as the reference's streaming clients (inference_onnx.py:37-76,
+# runtime/core/model/vits_model.cc:96-126): ceil(L/block) windows, each widened by `pad` frames
+# on both sides (clipped to [0, L]); after decoding, the samples that came from the padding are
+# discarded so the pieces concatenate to exactly L*hop samples.
+def get_chunks(mel_len, block_size, pad_size):
+    """[(window_start, window_end)] in frames; block_size == -1 => one window."""
+    if block_size == -1:
+        return [(0, mel_len)]
+    n = -(-mel_len // block_size)
+    return [(max(0, i * block_size - pad_size), min((i + 1) * block_size + pad_size, mel_len))
+            for i in range(n)]
+
+
+def depad_bounds(chunk_num, chunk_id, block, pad, upsample, n_samples):
+    """Sample range of a decoded window to keep (depadding, inference_onnx.py:60-76)."""
+    front = min(chunk_id * block, pad)
+    if chunk_id == 0:
+        return 0, min(n_samples, block * upsample)
+    if chunk_id == chunk_num - 1:
+        return front * upsample, n_samples
+    return front * upsample, (front + block) * upsample
+
+
+def stream_decode(decoder, z, sid, chunk_size=40, pad_size=10):
+    """Decodes z [1,L,C] window by window with overlap-discard; yields float32 audio pieces
+    (numpy) whose concatenation has L*hop samples.  `decoder` is a DecoderSession."""
+    hop = decoder.model.hop_length
+    wins = get_chunks(z.shape[1], chunk_size, pad_size)
+    for i, (ws, we) in enumerate(wins):
+        out = decoder.run(None, {"z": z[:, ws:we], "sid": sid})[0].reshape(1, -1)
+        a, b = depad_bounds(len(wins), i, chunk_size, pad_size, hop, out.shape[1])
+        yield out[0, a:b]
