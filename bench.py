@@ -182,10 +182,21 @@ def main():
     mrf_flops = mfl.value * padded_frames
     mrf_tflops = mrf_flops / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
     mrf_gbs = mby.value * padded_frames / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0
+    traffic, traffic_src = None, None
+    try:  # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+        if files and args.model == "v1" and args.batch == 16 and args.phonemes == 128:
+            dom = json.load(open(files[-1]))["dominant_conv_mfma"]
+            traffic, traffic_src = dom["hbm_bytes_per_launch"], os.path.basename(files[-1])
+    except Exception:
+        pass
     roofline = {
         "kernel": "conv_mfma_kernel (MRF ResBlock convs)",
         "bound": "mfma", "achieved": mrf_tflops, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": mrf_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+        "frac": mrf_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+        "traffic_unit": "HBM bytes per conv_mfma launch (2*FETCH_SIZE+WRITE_SIZE)*1024, PMC",
+        "traffic_source": traffic_src,
         "launches": int(nl.value), "avg_launch_ms": ms.value / max(1, nl.value),
         "flops_per_launch": mrf_flops / max(1, nl.value),
         "hbm_view": {"achieved": mrf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
