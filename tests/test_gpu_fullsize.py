@@ -1,0 +1,118 @@
+"""GPU tier, BASELINE.json full sizes: size-independent properties + one oracle spot check.
+
+configs[1] Baker v1 B=16x128 fp32; configs[2] shape (v3, B=64, speaker path; fp32 here -- the bf16
+variant is a later round); configs[3] style ragged batch (Tx ~ U{32..128})."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(mname, n_vocab, n_spk, seed=0):
+    from wetts_amd import SynthesizerTrn, config, synth
+    net = SynthesizerTrn(n_vocab, 513, 32, n_speakers=n_spk, **config.MODEL_CONFIGS[mname])
+    sd = synth.make_state_dict(net.cfg, seed)
+    net.load_state_dict(sd).to("cuda")
+    return net, sd
+
+
+def _run(net, x, xl, sid, eps_w, eps_z=None):
+    return net.infer(x.cuda(), xl.cuda(), sid=sid.cuda(), noise_scale=0.667, length_scale=1.0,
+                     noise_scale_w=0.8, eps_w=eps_w.cuda(),
+                     eps_z=None if eps_z is None else eps_z.cuda())
+
+
+def test_v1_b16x128_properties_and_oracle_spot_check():
+    from oracle import vits_oracle as vo
+    from wetts_amd import checkpoint
+    net, sd = _net("v1", 256, 1)
+    g = torch.Generator().manual_seed(0)
+    B, Tx = 16, 128
+    x = torch.randint(0, 256, (B, Tx), generator=g)
+    xl = torch.full((B,), Tx, dtype=torch.long)
+    sid = torch.zeros(B, dtype=torch.long)
+    eps_w = torch.randn(B, 2, Tx, generator=g)
+    # pass 1 to learn Ty, then fixed eps_z
+    o0, _, ym0, _ = _run(net, x, xl, sid, eps_w)
+    Ty = ym0.shape[-1]
+    eps_z = torch.randn(B, 192, Ty, generator=g)
+    o, attn, ym, (z, z_p, m_p, logs_p) = _run(net, x, xl, sid, eps_w, eps_z)
+    hop = net.hop_length
+    assert o.shape == (B, 1, Ty * hop) and torch.isfinite(o).all()
+    assert float(o.abs().max()) <= 1.0  # tanh
+    # alignment properties: every valid frame maps to exactly one phoneme, monotone, row sums
+    # equal the ceil'd durations
+    a = attn[:, 0]
+    ylen = ym[:, 0].sum(1)
+    assert torch.equal(a.sum(2), ym[:, 0])
+    assert torch.equal(a.sum(1).sum(1), ylen)
+    idx = a.argmax(2)
+    for b in range(B):
+        d = idx[b, :int(ylen[b])].diff()
+        assert (d >= 0).all()
+    # determinism
+    o2, *_ = _run(net, x, xl, sid, eps_w, eps_z)
+    assert torch.equal(o, o2)
+    # batch-permutation equivariance (same padded length => identical tiles)
+    perm = torch.randperm(B, generator=g)
+    op, *_ = _run(net, x[perm], xl[perm], sid[perm], eps_w[perm], eps_z[perm])
+    assert util.rms((op - o[perm]).cpu().numpy()) < 1e-6
+    # oracle spot check: utterance 3 alone, B=1 on both sides (same padding => same tail leakage)
+    b = 3
+    L = int(ylen[b])
+    W = checkpoint.fold_weight_norm(sd)
+    cd = util.cfg_dict(net.cfg)
+    ref = vo.infer(W, cd, x[b:b + 1], xl[b:b + 1], sid[b:b + 1], 0.667, 1.0, 0.8,
+                   eps_w=eps_w[b:b + 1], eps_z=eps_z[b:b + 1, :, :L], return_stages=True)
+    o1, _, ym1, _ = _run(net, x[b:b + 1], xl[b:b + 1], sid[b:b + 1], eps_w[b:b + 1],
+                         eps_z[b:b + 1, :, :L])
+    assert ym1.shape[-1] == L == ref["y_mask"].shape[-1]
+    err = util.rms(o1.cpu().numpy() - ref["o"].numpy())
+    print("v1 full-length utterance vs oracle: abs rms", err, "ref rms", util.rms(ref["o"].numpy()))
+    assert err < 1e-4
+
+
+def test_v3_b64_speaker_path_and_ragged_b64():
+    net, _ = _net("v3", 256, 2)
+    g = torch.Generator().manual_seed(1)
+    B, Tx = 64, 128
+    x = torch.randint(0, 256, (B, Tx), generator=g)
+    sid = (torch.arange(B) % 2)
+    for ragged in (False, True):
+        xl = torch.randint(32, Tx + 1, (B,), generator=g) if ragged else torch.full((B,), Tx)
+        xl = xl.long()
+        eps_w = torch.zeros(B, 2, Tx)
+        o, attn, ym, _ = _run(net, x, xl, sid, eps_w)
+        Ty = ym.shape[-1]
+        assert o.shape == (B, 1, Ty * net.hop_length) and torch.isfinite(o).all()
+        ylen = ym[:, 0].sum(1)
+        # DP head is pinned to log 6 + small => 5..8 frames per phoneme, lengths follow x_lengths
+        fpp = (ylen.cpu() / xl.float())
+        assert (fpp > 4).all() and (fpp < 9).all()
+        # padded phonemes get no frames
+        a = attn[:, 0].sum(1).cpu()  # [B,Tx] frames per phoneme
+        for b in range(B):
+            assert a[b, int(xl[b]):].sum() == 0
+        # speaker conditioning matters: same text, other speaker => different audio
+    o_a, *_ = _run(net, x[:2], torch.full((2,), Tx).long(), torch.tensor([0, 0]),
+                   torch.zeros(2, 2, Tx), torch.zeros(2, 192, 1).expand(2, 192, 1)
+                   if False else None)
+    o_b, *_ = _run(net, x[:2], torch.full((2,), Tx).long(), torch.tensor([1, 1]),
+                   torch.zeros(2, 2, Tx))
+    n = min(o_a.shape[-1], o_b.shape[-1])
+    assert util.rms((o_a[..., :n] - o_b[..., :n]).cpu().numpy()) > 1e-3
+
+
+def test_empty_and_tiny_inputs():
+    net, _ = _net("tiny", 20, 2)
+    # single phoneme, length 1
+    o, attn, ym, _ = _run(net, torch.tensor([[3]]), torch.tensor([1]), torch.tensor([1]),
+                          torch.zeros(1, 2, 1))
+    assert o.shape[-1] == ym.shape[-1] * net.hop_length and ym.sum() >= 1
+    # max_len = 0 slice => empty audio, like (z*y_mask)[:, :, :0]
+    o0, *_ = net.infer(torch.tensor([[3, 4]]).cuda(), torch.tensor([2]).cuda(),
+                       sid=torch.tensor([0]).cuda(), max_len=0)
+    assert o0.shape == (1, 1, 0)
