@@ -112,7 +112,10 @@ void free_packed(PackedConv* pc) {
 // ------------------------------------------------------------------------------------------
 // EPI: 0 = generic epilogue (runtime activation / masks / late residual), 1 = plain
 // (acc + bias [+ per-utterance bias]), 2 = plain followed by the MRF mean division.
-template <int MB, int NB, int WM, int WN, bool PF, bool DBG = false, int EPI = 0>
+// OPT (experiment bits): 1 = stagger the staging-load issue point across co-resident blocks, 2 = ping-pong A registers,
+// compile-time ablations for the microbenchmark: 4 no A loads, 8 no LDS B reads, 16 no staging
+// loads/stores, 32 no per-chunk barrier.
+template <int MB, int NB, int WM, int WN, bool PF, bool DBG = false, int EPI = 0, int OPT = 0>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   // DBG instantiations honour p.ablate (microbenchmark only): 1 no MFMA, 2 no staging loads,
   // 4 no A loads, 8 no epilogue stores, 16 no LDS B reads
@@ -276,6 +279,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   float4 a_nxt[MB];
 #pragma unroll
   for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][0];
+  float4 a_alt[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) a_alt[i] = a_nxt[i];
   const bool no_a = DBG && (p.ablate & 4);
   const bool no_mfma = DBG && (p.ablate & 1);
   const bool no_b = DBG && (p.ablate & 16);
@@ -288,21 +294,49 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   const int half = lane >> 5;
   const int bcol0 = wn * (32 * NB) + (lane & 31) - p.pad - p.off_lo;
   int g = 0;
+  const int stag_tap = (int)((blockIdx.x >> 8) % 3u) * p.ktaps / 4;
   for (int c = 0; c < p.nchunks; ++c) {
     const float* cur = (c & 1) ? buf1 : buf0;
     const bool more = (c + 1) < p.nchunks;
-    if (more) load_chunk(c + 1);
+    if (!(OPT & 1)) {
+      if (more && !(OPT & 16)) load_chunk(c + 1);
+    }
     for (int tap = 0; tap < p.ktaps; ++tap) {
+      if (OPT & 1) {
+        // co-resident blocks issue their staging loads at different taps so that the in-order
+        // vmcnt stall behind them does not hit every wave of the CU at the same moment
+        if (tap == stag_tap && more) load_chunk(c + 1);
+      }
       const int coff = bcol0 + tap * p.dil;
 #pragma unroll
       for (int hp = 0; hp < 2; ++hp) {
         float4 a_cur[MB];
+        if ((OPT & 2) && !DBG) {
+          // ping-pong: a_nxt holds the even groups, a_alt the odd ones; no register copies
+          ++g;
+          if (hp == 0) {
 #pragma unroll
-        for (int i = 0; i < MB; ++i) a_cur[i] = a_nxt[i];
-        ++g;
-        if (g < G && !no_a) {
+            for (int i = 0; i < MB; ++i) a_cur[i] = a_nxt[i];
+            if (g < G && !(OPT & 4)) {
 #pragma unroll
-          for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][(int64_t)g * 64];
+              for (int i = 0; i < MB; ++i) a_alt[i] = abase[i][(int64_t)g * 64];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < MB; ++i) a_cur[i] = a_alt[i];
+            if (g < G && !(OPT & 4)) {
+#pragma unroll
+              for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][(int64_t)g * 64];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < MB; ++i) a_cur[i] = a_nxt[i];
+          ++g;
+          if (g < G && !no_a) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][(int64_t)g * 64];
+          }
         }
         const float* brow0 = cur + (hp * 8 + half) * W + coff;
         float bv[2][NB];
@@ -318,9 +352,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
               for (int j = 0; j < NB; ++j) bv[(s + 1) & 1][j] = brow0[(s + 1) * 2 * W + 32 * j];
             }
           } else {
-            if (no_b) {
+            if (no_b || (OPT & 8)) {
 #pragma unroll
-              for (int j = 0; j < NB; ++j) bv[s & 1][j] = 0.5f;
+              for (int j = 0; j < NB; ++j) bv[s & 1][j] = 0.5f + 0.001f * (float)(s + j);
             } else {
 #pragma unroll
               for (int j = 0; j < NB; ++j) bv[s & 1][j] = brow0[s * 2 * W + 32 * j];
@@ -344,8 +378,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
       }
     }
     if (!(DBG && (p.ablate & 32))) {
-      if (more) store_chunk((c & 1) ? buf0 : buf1);
-      __syncthreads();
+      if (more && !(OPT & 16)) store_chunk((c & 1) ? buf0 : buf1);
+      if (!(OPT & 32)) __syncthreads();
     }
   }
 
@@ -553,13 +587,13 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
   // whenever there is no output activation or mask, which leaves "acc + bias [/ div]"
   const bool plain = p.up == 0 && p.out_act == OUT_NONE && p.out_mask == nullptr;
   if (plain && p.out_div == 1.f) {
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 1>), dim3((unsigned)blocks),
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 1, 2>), dim3((unsigned)blocks),
                        dim3(256), lds, stream, p);
   } else if (plain) {
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 2>), dim3((unsigned)blocks),
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 2, 2>), dim3((unsigned)blocks),
                        dim3(256), lds, stream, p);
   } else {
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 0>), dim3((unsigned)blocks),
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 0, 2>), dim3((unsigned)blocks),
                        dim3(256), lds, stream, p);
   }
   WETTS_LAUNCH_CHECK();
@@ -588,8 +622,11 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
   }
   // tile selection: fill the chip first, then maximise per-wave register reuse
   const int64_t cols = (int64_t)p.N * p.B;
-  if (p.M >= 128 && cols >= 4096) return launch_cfg<2, 2, 2, 2>(p, stream);
-  if (p.M > 32 && cols >= 8192) return launch_cfg<2, 2, 1, 4>(p, stream);
+  // 1x4 wave tiles (one A fragment feeds four B fragments) measured 2-3 % faster than 2x2 at
+  // every MRF shape (profiles/r01_conv_tileshape_ab.txt): half the A-stream loads per MFMA.
+  if (p.M >= 128 && cols >= 4096) return launch_cfg<1, 4, 4, 1>(p, stream);
+  if (p.M > 32 && cols >= 8192) return launch_cfg<1, 4, 2, 2>(p, stream);
+  if (p.M <= 32 && cols >= 8192 && p.ktaps >= 5) return launch_cfg<1, 4, 1, 4>(p, stream);
   if (p.M <= 32 && cols >= 8192) return launch_cfg<1, 2, 1, 4>(p, stream);
   return launch_cfg<1, 1, 2, 2>(p, stream);
 }

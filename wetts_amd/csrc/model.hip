@@ -2,6 +2,7 @@
 // stream-ordered stage entry points that compose the reference's SynthesizerTrn.infer()
 // (wetts/vits/model/models.py:228-280).  See include/wetts_hip.h for the contract.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -287,6 +288,12 @@ struct wetts_model {
   mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> mrf_events;
   mutable int64_t mrf_launches = 0;
   mutable int32_t mrf_calls = 0;
+  // MRF chains: the n_k ResBlocks of a stage are independent until their sum, so they run on
+  // separate HIP streams (forked from / joined to the caller's stream with events); one chain's
+  // launch tail and prologue/epilogue phases overlap another chain's MFMA work.
+  int mrf_streams = 1;
+  hipStream_t aux_stream[WETTS_MAX_RB_KERNELS] = {};
+  hipEvent_t ev_fork = nullptr, ev_chain[WETTS_MAX_RB_KERNELS] = {};
 
   const float* T(const std::string& name) const {
     auto it = layout.index.find(name);
@@ -527,7 +534,8 @@ static int64_t dec_max_elems(const wetts_config_t* c, int B, int L) {
 }
 
 static int64_t ws_decoder(const wetts_config_t* c, int B, int L) {
-  return 5 * A256(dec_max_elems(c, B, L)) + A256((int64_t)B * c->upsample_initial_channel);
+  return (3 + 3 * (int64_t)c->n_resblock_kernels) * A256(dec_max_elems(c, B, L)) +
+         A256((int64_t)B * c->upsample_initial_channel);
 }
 
 }  // namespace wetts
@@ -595,6 +603,18 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
   e = hipMemcpyAsync(m->blob, blob_dev, (size_t)blob_numel * sizeof(float),
                      hipMemcpyDeviceToDevice, s);
   int32_t r = (e == hipSuccess) ? build_model(m, s) : WETTS_E_HIP;
+  {
+    const char* env = getenv("WETTS_MRF_STREAMS");
+    m->mrf_streams = env ? atoi(env) : cfg->n_resblock_kernels;
+    if (m->mrf_streams < 1) m->mrf_streams = 1;
+    if (m->mrf_streams > cfg->n_resblock_kernels) m->mrf_streams = cfg->n_resblock_kernels;
+    (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
+    for (int j = 0; j < cfg->n_resblock_kernels; ++j) {
+      (void)hipEventCreateWithFlags(&m->ev_chain[j], hipEventDisableTiming);
+      if (j > 0 && j < m->mrf_streams)
+        (void)hipStreamCreateWithFlags(&m->aux_stream[j], hipStreamNonBlocking);
+    }
+  }
   if (r == WETTS_OK) {
     e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
@@ -613,6 +633,11 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
 void wetts_destroy(wetts_model_t* m) {
   if (!m) return;
   for (PackedConv* pc : m->all_packed) free_packed(pc);
+  for (int j = 0; j < WETTS_MAX_RB_KERNELS; ++j) {
+    if (m->aux_stream[j]) (void)hipStreamDestroy(m->aux_stream[j]);
+    if (m->ev_chain[j]) (void)hipEventDestroy(m->ev_chain[j]);
+  }
+  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
   if (m->blob) (void)hipFree(m->blob);
   delete m;
 }
@@ -963,9 +988,10 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
   Bump ws(workspace, workspace_bytes);
   float* bx = ws.take<float>(mx);
   float* bt = ws.take<float>(mx);
-  float* ba = ws.take<float>(mx);
-  float* bb = ws.take<float>(mx);
   float* bs = ws.take<float>(mx);
+  float* chain_buf[WETTS_MAX_RB_KERNELS][3];
+  for (int j = 0; j < c->n_resblock_kernels; ++j)
+    for (int q = 0; q < 3; ++q) chain_buf[j][q] = ws.take<float>(mx);
   float* cond = ws.take<float>((int64_t)B * C0);
   if (!ws.ok) {
     set_error("hifigan: workspace too small (need %lld bytes)",
@@ -1006,11 +1032,8 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
     }
     ch /= 2;
     len *= u;
-    float* xu = bt;                    // upsampled x, input of every resblock of this stage
-    float* fa = ba;                    // resblock running x
-    float* fb = bb;                    // second running buffer
-    float* ft = (x == bx) ? bx : bs;   // conv1 output scratch (old stage input is dead now)
-    float* xsum = (x == bx) ? bs : bx; // MRF accumulator for this stage
+    float* xu = bt;                     // upsampled x, input of every resblock of this stage
+    float* xsum = (x == bx) ? bs : bx;  // MRF accumulator for this stage
     (void)xs;
     if (tm && tm->on) WETTS_HIP_CHECK(hipEventRecord(tm->e0, s));
     hipEvent_t lv0 = nullptr, lv1 = nullptr;
@@ -1019,12 +1042,18 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
       WETTS_HIP_CHECK(hipEventCreate(&lv1));
       WETTS_HIP_CHECK(hipEventRecord(lv0, s));
     }
+    const bool forked = m->mrf_streams > 1;
+    if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_fork, s));
     for (int j = 0; j < nk; ++j) {
       const RB& rb = m->rbs[i * nk + j];
+      hipStream_t sj = (forked && j > 0 && j < m->mrf_streams) ? m->aux_stream[j] : s;
+      if (sj != s) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_fork, 0));
+      float* fa = chain_buf[j][0];
+      float* fb = chain_buf[j][1];
+      float* ft = chain_buf[j][2];
       const float* rx = xu;  // current resblock x
       for (int d = 0; d < nd; ++d) {
         const bool last_d = (d == nd - 1);
-        // where does this unit's output go?
         float* outp;
         int accum = 0;
         float odiv = 1.f;
@@ -1040,7 +1069,9 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           ConvParams p1 = conv_io(rx, ch, len, ft, ch, B);
           p1.in_act = IN_LRELU;
           p1.in_slope = 0.1f;
-          WETTS_TRY(launch_conv(rb.c1[d], p1, s));
+          WETTS_TRY(launch_conv(rb.c1[d], p1, sj));
+          // the running sum is ordered chain j-1 -> chain j
+          if (forked && last_d && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
           ConvParams p2 = conv_io(ft, ch, len, outp, ch, B);
           p2.in_act = IN_LRELU;
           p2.in_slope = 0.1f;
@@ -1049,10 +1080,11 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           p2.r_cs = len;
           p2.accum = accum;
           p2.out_div = odiv;
-          WETTS_TRY(launch_conv(rb.c2[d], p2, s));
+          WETTS_TRY(launch_conv(rb.c2[d], p2, sj));
           if (tm && tm->on) tm->launches += 2;
         } else {
           // x = c(lrelu(x)) + x
+          if (forked && last_d && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
           ConvParams p1 = conv_io(rx, ch, len, outp, ch, B);
           p1.in_act = IN_LRELU;
           p1.in_slope = 0.1f;
@@ -1061,12 +1093,15 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           p1.r_cs = len;
           p1.accum = accum;
           p1.out_div = odiv;
-          WETTS_TRY(launch_conv(rb.c1[d], p1, s));
+          WETTS_TRY(launch_conv(rb.c1[d], p1, sj));
           if (tm && tm->on) tm->launches += 1;
         }
         rx = outp;
       }
+      if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_chain[j], sj));
     }
+    // join: the last chain's final conv already waited for all the others through the sum order
+    if (forked) WETTS_HIP_CHECK(hipStreamWaitEvent(s, m->ev_chain[nk - 1], 0));
     if (m->mrf_timing) {
       WETTS_HIP_CHECK(hipEventRecord(lv1, s));
       m->mrf_events.emplace_back(lv0, lv1);

@@ -263,6 +263,8 @@ class SynthesizerTrn:
         """dec((z * y_mask)[:, :, :L], g) without materialising the masked / sliced copy."""
         lib = self._require()
         B = z.shape[0]
+        if B == 0 or L == 0:  # (z * y_mask)[:, :, :0] -> empty audio, nothing to launch
+            return torch.empty(B, 1, 0, dtype=torch.float32, device=self.device)
         ws, nws = self._workspace(B, 0, L)
         audio = torch.empty(B, 1, L * self.hop_length, dtype=torch.float32, device=self.device)
         _lib.check(lib.wetts_hifigan(self._handle, _lib.ptr(z), z.stride(0), z.stride(1),
