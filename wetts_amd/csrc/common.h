@@ -82,6 +82,7 @@ struct ConvParams {
   float* out;
   int64_t o_bs, o_cs;
   int Tout;
+  int up_shift;          // log2(up) when up is a power of two, else -1
   int up, up_pad;        // up>0: ConvTranspose store  out[row/up][n*up + row%up - up_pad]
   int out_act;           // OutAct
   const float* out_mask; // [B][>=Tout] or null

@@ -440,6 +440,38 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
     return;
   }
+  if (EPI == 3) {
+    // polyphase ConvTranspose1d store (stride a power of two): row = (co, phase),
+    // t = col*up + phase - pad; shifts instead of divisions, 32-bit byte offsets
+    const int sh = p.up_shift, um = p.up - 1;
+    char* obase = reinterpret_cast<char*>(p.out + ob);
+    const unsigned ocs4 = (unsigned)p.o_cs * 4u;
+    float bia[MB][16];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        bia[i][r] = (p.bias && row < p.M) ? p.bias[row >> sh] : 0.f;
+      }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int co = row >> sh, ph = row & um;
+        const unsigned rowoff = (unsigned)co * ocs4;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int col = wcol0 + 32 * j + (lane & 31);
+          const int t = (col << sh) + ph - p.up_pad;
+          if (row < p.M && col < p.N && t >= 0 && t < p.Tout)
+            *reinterpret_cast<float*>(obase + (rowoff + (unsigned)t * 4u)) = acc[i][j][r] + bia[i][r];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MB; ++i) {
     const int mrow0 = mtile * MT + (wm * MB + i) * 32 + 4 * half;
@@ -586,6 +618,13 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
   // epilogue specialisation: residual / running sum are folded into the accumulator init
   // whenever there is no output activation or mask, which leaves "acc + bias [/ div]"
   const bool plain = p.up == 0 && p.out_act == OUT_NONE && p.out_mask == nullptr;
+  if (p.up > 0 && p.up_shift >= 0 && p.out_act == OUT_NONE && !p.out_mask && !p.res && !p.accum &&
+      !p.bias_b && p.out_div == 1.f) {
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 3, 2>), dim3((unsigned)blocks),
+                       dim3(256), lds, stream, p);
+    WETTS_LAUNCH_CHECK();
+    return WETTS_OK;
+  }
   if (plain && p.out_div == 1.f) {
     hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 1, 2>), dim3((unsigned)blocks),
                        dim3(256), lds, stream, p);
@@ -613,6 +652,9 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
   p.nchunks = pc.nchunks;
   p.up = pc.up;
   p.up_pad = pc.up_pad;
+  p.up_shift = -1;
+  for (int q = 0; q < 16; ++q)
+    if (pc.up == (1 << q)) p.up_shift = q;
   WETTS_REQUIRE(pc.wpk != nullptr, "conv weight not packed");
   WETTS_REQUIRE(p.span <= 128, "conv receptive field too wide (span %d > 128)", p.span);
   if (p.up > 0) {
