@@ -75,7 +75,19 @@ def cpu_baseline(cfg, sd, x, lens, sid, n_utts, sr, hop):
                                noise_scale_w=0.8)
     dt = time.perf_counter() - t0
     samples = float(y_mask.sum().item()) * hop
+    one = None
+    try:  # the reference's own setting is ONE thread (inference.py:49-50); time 1 utterance
+        torch.set_num_threads(1)
+        t1 = time.perf_counter()
+        o1, _, ym1, _ = vo.infer(W, cd, xs[:1, :64], torch.tensor([64]), ss[:1], noise_scale=0.667,
+                                 length_scale=1.0, noise_scale_w=0.8)
+        d1 = time.perf_counter() - t1
+        one = {"value": float(ym1.sum().item()) * hop / d1, "cores": 1,
+               "sample": f"1 utterance x 64 phonemes, {d1:.1f} s"}
+    finally:
+        torch.set_num_threads(cores)
     return {"value": samples / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
+            "single_thread": one,
             "sample": f"{n_utts} of the batch's utterances ({int(ls.sum())} phonemes, "
                       f"{int(y_mask.sum().item())} frames), oracle infer() once, {dt:.1f} s",
             "rtf": dt / (samples / sr)}
@@ -89,6 +101,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    if os.environ.get("WETTS_BENCH_SINGLE_DEVICE"):  # dry-run of the N>1 control flow on one GPU
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lib = _lib.load()

@@ -605,7 +605,7 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
   int32_t r = (e == hipSuccess) ? build_model(m, s) : WETTS_E_HIP;
   {
     const char* env = getenv("WETTS_MRF_STREAMS");
-    m->mrf_streams = env ? atoi(env) : cfg->n_resblock_kernels;
+    m->mrf_streams = env ? atoi(env) : 1;  // opt-in: +2 % at cfg 2, but kernels then overlap in profiles
     if (m->mrf_streams < 1) m->mrf_streams = 1;
     if (m->mrf_streams > cfg->n_resblock_kernels) m->mrf_streams = cfg->n_resblock_kernels;
     (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
