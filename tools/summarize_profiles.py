@@ -6,6 +6,7 @@ summaries under profiles/:  <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --s
 import collections
 import csv
 import json
+import re
 import shutil
 import sys
 
@@ -44,7 +45,8 @@ for k in sorted(f, key=lambda k: -sum(f[k])):
         ent["calls_in_stats_run"] = int(stats[k]["Calls"])
     out["kernels"][k] = ent
     # dominant kernel class: the MRF-shaped conv instantiations (plain / mean epilogue)
-    if "conv_mfma_kernel" in k and ("false, 1>" in k or "false, 2>" in k) and "<1, 1, 2, 2" not in k:
+    mm = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), \w+, \w+, (\d+)", k)
+    if mm and mm.group(5) in ("1", "2") and mm.group(1, 2, 3, 4) != ("1", "1", "2", "2"):
         dom["launches"] += n
         dom["fetch_kb"] += sum(f[k])
         dom["write_kb"] += sum(w.get(k, [0]))
