@@ -10,7 +10,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libwetts_hip.so")
 SOURCES = ["conv_mfma.hip", "kernels.hip", "attention.hip", "mas.hip", "model.hip"]
-HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "wetts_hip.h")]
+HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "wetts_hip.h"),
+           os.path.join("..", "..", "include", "wetts_vits_model.hpp"),
+           os.path.join("..", "..", "tests", "native", "vits_model_main.cpp")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -62,6 +64,16 @@ def build(force=False, verbose=True):
     if verbose:
         print("[wetts_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    # native C++ host used by tests/test_gpu_native.py (twin of the reference's VitsModel class)
+    native_src = os.path.join(HERE, "..", "tests", "native", "vits_model_main.cpp")
+    if os.path.exists(native_src):
+        cmd = [hipcc, "-O2", "-std=c++17", "-x", "c++", "-D__HIP_PLATFORM_AMD__",
+               "-I", os.path.join(HERE, "..", "include"), "-I", "/opt/rocm/include", native_src,
+               "-L", LIBDIR, "-lwetts_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+               "-Wl,-rpath," + LIBDIR, "-o", os.path.join(LIBDIR, "vits_model_main")]
+        if verbose:
+            print("[wetts_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     with open(stamp, "w") as f:
         f.write(dig)
     return LIB
