@@ -183,6 +183,12 @@ int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_st
                       const float* g, int32_t B, int32_t L, float* audio, void* workspace,
                       int64_t workspace_bytes, void* stream);
 
+/* Decoder arithmetic: 0 = float32 (default; exact-f32 MFMA, the parity-gated path),
+ * 1 = bfloat16 activations / weights with f32 accumulation (BASELINE.json configs[2]/[4]
+ * precision; the text encoder, duration predictor and flow stay f32).  Weights are re-packed on
+ * first use. */
+int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision);
+
 /* a15 monotonic_align.maximum_path (utils/monotonic_align.py:6-57).  Needs no model.
  *   neg_cent [B,Ty,Tx] float32 (not modified), t_ys / t_xs int32[B] (the mask sums the
  *   reference derives at :16-17), path [B,Ty,Tx] int32 (zero-filled then the 1s written),

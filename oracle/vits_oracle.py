@@ -338,6 +338,60 @@ def hifigan(W, cfg, z, g):
     return torch.tanh(x)
 
 
+def _q(x):
+    """round-to-nearest-even to bfloat16, kept in float32"""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def hifigan_bf16sim(W, cfg, z, g):
+    """Numerics spec of the bf16 decoder mode (wetts_set_decoder_precision(m, 1)): same graph as
+    `hifigan`, with conv weights and every inter-conv activation rounded to bfloat16, f32
+    accumulation, f32 bias / residual / running-sum adds before the single rounding per output."""
+    x = conv1d(W, "dec.conv_pre", z, padding=3)
+    if g is not None:
+        x = x + conv1d(W, "dec.cond", g)
+    x = _q(x)
+    nk = len(cfg["resblock_kernel_sizes"])
+
+    def cw(name):
+        return _q(W[name + ".weight"]), W[name + ".bias"]
+
+    for i, (u, uk) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
+        w, b = cw(f"dec.ups.{i}")
+        x = _q(F.conv_transpose1d(_q(F.leaky_relu(x, LRELU_SLOPE)), w, b, stride=u,
+                                  padding=(uk - u) // 2))
+        xs = None
+        for j, (k, dils) in enumerate(zip(cfg["resblock_kernel_sizes"],
+                                          cfg["resblock_dilation_sizes"])):
+            n = i * nk + j
+            r = x
+            nd = 3 if cfg["resblock"] == 1 else 2
+            for d, dil in enumerate(dils[:nd]):
+                last = d == nd - 1
+                if cfg["resblock"] == 1:
+                    w1, b1 = cw(f"dec.resblocks.{n}.convs1.{d}")
+                    t = _q(F.conv1d(_q(F.leaky_relu(r, LRELU_SLOPE)), w1, b1, dilation=dil,
+                                    padding=(k * dil - dil) // 2))
+                    w2, b2 = cw(f"dec.resblocks.{n}.convs2.{d}")
+                    y = F.conv1d(_q(F.leaky_relu(t, LRELU_SLOPE)), w2, b2, padding=(k - 1) // 2) + r
+                else:
+                    w1, b1 = cw(f"dec.resblocks.{n}.convs.{d}")
+                    y = F.conv1d(_q(F.leaky_relu(r, LRELU_SLOPE)), w1, b1, dilation=dil,
+                                 padding=(k * dil - dil) // 2) + r
+                if last:
+                    if xs is not None:
+                        y = y + xs
+                    if j == nk - 1:
+                        y = y / nk
+                    xs = _q(y)
+                else:
+                    r = _q(y)
+        x = xs
+    x = F.leaky_relu(x)
+    x = F.conv1d(x, W["dec.conv_post.weight"], None, padding=3)
+    return torch.tanh(x)
+
+
 # ------------------------------------------------------------------------------------------------
 # infer  (model/models.py:228-280)
 # ------------------------------------------------------------------------------------------------

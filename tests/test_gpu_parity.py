@@ -153,3 +153,30 @@ def test_product_path_fails_loudly_without_device_weights():
     net = SynthesizerTrn(10, 513, 32, n_speakers=0, **config.MODEL_CONFIGS["tiny"])
     with pytest.raises(_lib.WettsError):
         net.infer(torch.zeros(1, 3, dtype=torch.long), torch.tensor([3]))
+
+
+@pytest.mark.parametrize("name", ["v1_b2", "v3_b2"])
+def test_hifigan_bf16_mode_matches_its_numerics_spec(name):
+    """bf16 decoder (configs[2]/[4] precision): against oracle.hifigan_bf16sim (same rounding
+    points) and, loosely, against the f32 oracle.  Tolerances: rel RMS 1e-2 vs the bf16 spec
+    (f32-accumulation order can flip an occasional bf16 rounding), 6e-2 vs f32."""
+    from oracle import vits_oracle as vo
+    case = util.load_case(name)
+    net, cfg, W = _model(case)
+    cd = util.cfg_dict(cfg)
+    z = util.t(case["z"]) * util.t(case["y_mask"])
+    sid = util.t(case["sid"])
+    g = torch.nn.functional.embedding(sid, W["emb_g.weight"]).unsqueeze(-1)
+    with torch.no_grad():
+        spec = vo.hifigan_bf16sim(W, cd, z, g).numpy()
+        f32 = vo.hifigan(W, cd, z, g).numpy()
+    net.set_decoder_dtype(torch.bfloat16)
+    got = net.hifigan(z.cuda(), g[:, :, 0].cuda()).cpu().numpy()
+    net.set_decoder_dtype(torch.float32)
+    back = net.hifigan(z.cuda(), g[:, :, 0].cuda()).cpu().numpy()
+    r_spec, r_f32 = util.rel_rms(got, spec), util.rel_rms(got, f32)
+    print(name, "bf16 vs spec", r_spec, "bf16 vs f32", r_f32, "spec vs f32", util.rel_rms(spec, f32))
+    assert got.shape == f32.shape and np.isfinite(got).all()
+    assert r_spec < 1e-2
+    assert r_f32 < 6e-2
+    assert util.rms(back - f32) < ABS_RMS_OURS  # switching back restores the exact-f32 path

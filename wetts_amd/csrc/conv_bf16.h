@@ -1,0 +1,43 @@
+// bf16 decoder path declarations (conv_bf16.hip).
+#pragma once
+#include "common.h"
+
+namespace wetts {
+
+struct PackedConvB {
+  unsigned short* wpk = nullptr;  // device, [ceil(M/128)*4][G][KS][64][8] bf16
+  const float* bias = nullptr;    // f32
+  int M = 0, Cin = 0, Cout = 0, ktaps = 0, dil = 1, pad = 0, up = 0, up_pad = 0;
+  int off_lo = 0, span = 0, nchunks = 0, CKB = 64;
+};
+
+struct ConvBParams {
+  const unsigned short* x;  // [B][Tin][Cin] bf16, channel-last
+  int64_t x_bs;             // batch stride in elements
+  int Cin, Tin;
+  int in_act;
+  float in_slope;
+  const unsigned short* wpk;
+  const float* bias;
+  int M, N, ktaps, dil, pad, off_lo, span, nchunks;
+  unsigned short* out;  // [B][Tout][cout]
+  int64_t o_bs;
+  int cout, Tout;
+  int up, up_pad;
+  const unsigned short* res;  // [B][Tout][cout] or null
+  int64_t r_bs;
+  int accum;
+  float out_div;
+  int B;
+};
+
+int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
+                              int dil, int pad, int transposed, int up, hipStream_t stream,
+                              PackedConvB* out);
+void free_packed_bf16(PackedConvB* pc);
+int32_t launch_conv_bf16(const PackedConvB& pc, ConvBParams p, hipStream_t stream);
+int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, hipStream_t s);
+int32_t k_conv_post_bf16(const unsigned short* x, const float* w, int k, int B, int C, int T,
+                         float* out, hipStream_t s);
+
+}  // namespace wetts

@@ -1,0 +1,427 @@
+// bf16 HiFi-GAN decoder path (BASELINE.json configs[2] / [4] precision): implicit-GEMM Conv1d /
+// polyphase ConvTranspose1d on v_mfma_f32_32x32x16_bf16 with f32 accumulation.
+//
+// Layout: activations are CHANNEL-LAST bf16  X[b][t][C]  inside the decoder.  The MFMA B operand
+// wants 8 consecutive K elements per lane; with K ordered (tap, ci) those are 8 consecutive input
+// channels of one time step, i.e. one aligned 16-byte piece of a channel-last row -- so staging is
+// plain 16-byte copies HBM -> registers -> LDS (leaky-relu applied on the way), B fragments are
+// single ds_read_b128, and the epilogue writes 4 consecutive channels (8 bytes) per lane.
+// LDS rows are padded by 16 bytes so the 16-lane groups of ds_read_b128 hit 16 distinct slots.
+//
+// At bf16 the per-conv arithmetic intensity is C*k/2 flop/B: k=3 launches are HBM-bound, k=11 at
+// C>=128 are MFMA-bound (ridge ~400 flop/B) -- see DESIGN.md.
+//
+// Replaces, at reduced precision, the same reference code as conv_mfma.hip:
+// decoders.py:63-82,157-170,205-214 (ups / ResBlock convs / conv_post).
+#include "common.h"
+#include "conv_bf16.h"
+
+namespace wetts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing: [mt32][g = chunk*ktaps + tap][ks][lane][8 bf16]
+//   lane -> row = mt32*32 + (lane&31);  k elements = ci = chunk*CKB + ks*16 + 8*(lane>>5) + e
+// transposed: rows are (phase, co) with co fastest; tap kk = phase + tap*up
+// ------------------------------------------------------------------------------------------
+__global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                 int M, int Cin, int Cout, int k, int ktaps, int up, int transposed,
+                                 int CKB, int64_t total) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int KS = CKB / 16;
+  int e = (int)(idx & 7);
+  int lane = (int)((idx >> 3) & 63);
+  int64_t rest = idx >> 9;
+  int ks = (int)(rest % KS);
+  rest /= KS;
+  const int nchunks = (Cin + CKB - 1) / CKB;
+  const int G = nchunks * ktaps;
+  int g = (int)(rest % G);
+  int mt32 = (int)(rest / G);
+  int chunk = g / ktaps, tap = g % ktaps;
+  int ci = chunk * CKB + ks * 16 + 8 * (lane >> 5) + e;
+  int row = mt32 * 32 + (lane & 31);
+  float v = 0.f;
+  if (row < M && ci < Cin) {
+    if (!transposed) {
+      v = w[((int64_t)row * Cin + ci) * k + tap];
+    } else {
+      int ph = row / Cout, co = row % Cout;
+      int kk = ph + tap * up;
+      if (kk < k) v = w[((int64_t)ci * Cout + co) * k + kk];
+    }
+  }
+  unsigned u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  out[idx] = (unsigned short)(u >> 16);
+}
+
+int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
+                              int dil, int pad, int transposed, int up, hipStream_t stream,
+                              PackedConvB* pc) {
+  pc->Cin = Cin;
+  pc->Cout = Cout;
+  pc->bias = bias_dev;
+  pc->CKB = Cin >= 64 ? 64 : 32;
+  if (!transposed) {
+    pc->M = Cout; pc->ktaps = k; pc->dil = dil; pc->pad = pad; pc->up = 0; pc->up_pad = 0;
+  } else {
+    pc->M = Cout * up; pc->ktaps = cdiv(k, up); pc->dil = -1; pc->pad = 0; pc->up = up;
+    pc->up_pad = pad;
+  }
+  int o0 = -pc->pad, o1 = (pc->ktaps - 1) * pc->dil - pc->pad;
+  pc->off_lo = o0 < o1 ? o0 : o1;
+  pc->span = (o0 < o1 ? o1 : o0) - pc->off_lo;
+  pc->nchunks = cdiv(Cin, pc->CKB);
+  const int G = pc->nchunks * pc->ktaps, KS = pc->CKB / 16;
+  const int mt32 = cdiv(pc->M, 128) * 4;
+  int64_t total = (int64_t)mt32 * G * KS * 64 * 8;
+  WETTS_HIP_CHECK(hipMalloc((void**)&pc->wpk, total * sizeof(unsigned short)));
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     w_dev, pc->wpk, pc->M, Cin, Cout, k, pc->ktaps, up > 0 ? up : 1, transposed,
+                     pc->CKB, total);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+void free_packed_bf16(PackedConvB* pc) {
+  if (pc->wpk) (void)hipFree(pc->wpk);
+  pc->wpk = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// the conv kernel: 4 waves (WM x WN), each wave one 32-row m-block x NB 32-column n-blocks
+// ------------------------------------------------------------------------------------------
+template <int NB, int WM, int WN, int CKB>
+__global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int MT = 32 * WM;
+  constexpr int NT = 32 * NB * WN;
+  constexpr int SEG = CKB / 8;          // 16-byte pieces per staged row
+  constexpr int KS = CKB / 16;          // MFMA k-steps per (chunk, tap) group
+  constexpr int RS = CKB * 2 + 16;      // LDS row stride in bytes (padded)
+  constexpr int MAXU = ((NT + 128) * SEG + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5;
+
+  const int ntiles = (p.N + NT - 1) / NT;
+  const int mtiles = (p.M + MT - 1) / MT;
+  int bid = blockIdx.x;
+  const int ntile = bid % ntiles;
+  bid /= ntiles;
+  const int mtile = bid % mtiles;
+  const int b = bid / mtiles;
+  const int n0 = ntile * NT;
+  const int W = NT + p.span;
+  unsigned char* buf0 = smem_b;
+  unsigned char* buf1 = smem_b + (size_t)W * RS;
+
+  const unsigned short* xb = p.x + (int64_t)b * p.x_bs;
+
+  // staging assignment (chunk independent): unit u = tid + 256*i -> (row, seg)
+  int urow[MAXU];
+  bool uok[MAXU];
+#pragma unroll
+  for (int i = 0; i < MAXU; ++i) {
+    const int u = tid + 256 * i;
+    const int row = u / SEG;
+    const int t = n0 + p.off_lo + row;
+    urow[i] = row;
+    uok[i] = (row < W) && (t >= 0) && (t < p.Tin);
+  }
+  const int useg = tid % SEG;  // 256 % SEG == 0, so the piece index does not depend on i
+  uint4 st[MAXU];
+  auto load_chunk = [&](int c) {
+    const int c0 = c * CKB + useg * 8;
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (uok[i] && c0 < p.Cin)
+        v = *reinterpret_cast<const uint4*>(xb + (int64_t)(n0 + p.off_lo + urow[i]) * p.Cin + c0);
+      st[i] = v;
+    }
+  };
+  const bool lrelu = p.in_act == IN_LRELU;
+  const float slope = p.in_slope;
+  auto act2 = [&](unsigned w) -> unsigned {
+    float a = bf2f((unsigned short)(w & 0xffffu)), c2 = bf2f((unsigned short)(w >> 16));
+    a = a > 0.f ? a : a * slope;
+    c2 = c2 > 0.f ? c2 : c2 * slope;
+    return pack2(a, c2);
+  };
+  auto store_chunk = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+      if (urow[i] < W) {
+        uint4 v = st[i];
+        if (lrelu) {
+          v.x = act2(v.x); v.y = act2(v.y); v.z = act2(v.z); v.w = act2(v.w);
+        }
+        *reinterpret_cast<uint4*>(buf + (size_t)urow[i] * RS + useg * 16) = v;
+      }
+    }
+  };
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // ---- output geometry of this wave ---------------------------------------------------------
+  const int mrow_blk = mtile * MT + wm * 32;  // first row of this wave's m-block (uniform)
+  int ph = 0, co_blk = mrow_blk;              // transposed: rows are (phase, co)
+  if (p.up > 0) {
+    ph = mrow_blk / p.cout;
+    co_blk = mrow_blk - ph * p.cout;
+  }
+  const int wcol0 = n0 + wn * (32 * NB);
+  const bool rows_ok = mrow_blk + 32 <= p.M;
+
+  // residual / running sum folded into the accumulator init (plain convs only)
+  if (p.up == 0 && (p.res || p.accum) && rows_ok) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = wcol0 + 32 * j + (lane & 31);
+      if (t < p.N) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = co_blk + 8 * q + 4 * half;
+          float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+          if (p.res) {
+            uint2 rr = *reinterpret_cast<const uint2*>(p.res + (int64_t)b * p.r_bs +
+                                                       (int64_t)t * p.cout + c);
+            v0 = bf2f((unsigned short)(rr.x & 0xffffu)); v1 = bf2f((unsigned short)(rr.x >> 16));
+            v2 = bf2f((unsigned short)(rr.y & 0xffffu)); v3 = bf2f((unsigned short)(rr.y >> 16));
+          }
+          if (p.accum) {
+            uint2 oo = *reinterpret_cast<const uint2*>(p.out + (int64_t)b * p.o_bs +
+                                                       (int64_t)t * p.cout + c);
+            v0 += bf2f((unsigned short)(oo.x & 0xffffu)); v1 += bf2f((unsigned short)(oo.x >> 16));
+            v2 += bf2f((unsigned short)(oo.y & 0xffffu)); v3 += bf2f((unsigned short)(oo.y >> 16));
+          }
+          acc[j][4 * q + 0] = v0; acc[j][4 * q + 1] = v1;
+          acc[j][4 * q + 2] = v2; acc[j][4 * q + 3] = v3;
+        }
+      }
+    }
+  }
+
+  // ---- A stream ------------------------------------------------------------------------------
+  const int G = p.nchunks * p.ktaps;
+  const int mt32 = mtile * WM + wm;
+  const uint4* abase = reinterpret_cast<const uint4*>(p.wpk) + ((int64_t)mt32 * G * KS) * 64 + lane;
+  uint4 aa[2][KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) aa[0][s] = abase[s * 64];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) aa[1][s] = aa[0][s];
+
+  load_chunk(0);
+  store_chunk(buf0);
+  __syncthreads();
+
+  const int brow0 = wn * (32 * NB) + (lane & 31) - p.pad - p.off_lo;
+  int chunk = 0, tap = 0;
+  for (int g = 0; g < G; g += 2) {
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {  // ping-pong A register sets, statically indexed
+      const int gg = g + par;
+      if (gg < G) {
+        if (gg + 1 < G) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) aa[par ^ 1][s] = abase[((int64_t)(gg + 1) * KS + s) * 64];
+        }
+        if (tap == 0 && chunk + 1 < p.nchunks) load_chunk(chunk + 1);
+        const unsigned char* cur = (chunk & 1) ? buf1 : buf0;
+        const unsigned char* bb = cur + (size_t)(brow0 + tap * p.dil) * RS + half * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const bf16x8 av = __builtin_bit_cast(bf16x8, aa[par][s]);
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const uint4 bw = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bw),
+                                                             acc[j], 0, 0, 0);
+          }
+        }
+        if (++tap == p.ktaps) {
+          tap = 0;
+          if (chunk + 1 < p.nchunks) store_chunk((chunk & 1) ? buf0 : buf1);
+          __syncthreads();
+          ++chunk;
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: + bias, / div, round to bf16, 8-byte channel-last stores ----------------------
+  if (!rows_ok) return;  // M is a multiple of 32 in every decoder conv; guard only
+  float bia[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    bia[r] = p.bias ? p.bias[co_blk + (r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
+  const bool dodiv = p.out_div != 1.f;
+  unsigned short* ob = p.out + (int64_t)b * p.o_bs;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int col = wcol0 + 32 * j + (lane & 31);
+    if (col >= p.N) continue;
+    int t = col;
+    if (p.up > 0) {
+      t = col * p.up + ph - p.up_pad;
+      if (t < 0 || t >= p.Tout) continue;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v0 = acc[j][4 * q + 0] + bia[4 * q + 0];
+      float v1 = acc[j][4 * q + 1] + bia[4 * q + 1];
+      float v2 = acc[j][4 * q + 2] + bia[4 * q + 2];
+      float v3 = acc[j][4 * q + 3] + bia[4 * q + 3];
+      if (dodiv) { v0 = v0 / p.out_div; v1 = v1 / p.out_div; v2 = v2 / p.out_div; v3 = v3 / p.out_div; }
+      uint2 o;
+      o.x = pack2(v0, v1);
+      o.y = pack2(v2, v3);
+      *reinterpret_cast<uint2*>(ob + (int64_t)t * p.cout + co_blk + 8 * q + 4 * half) = o;
+    }
+  }
+}
+
+template <int NB, int WM, int WN, int CKB>
+static int32_t launch_b(const ConvBParams& p, hipStream_t stream) {
+  constexpr int MT = 32 * WM, NT = 32 * NB * WN, RS = CKB * 2 + 16;
+  int64_t blocks = (int64_t)cdiv(p.N, NT) * cdiv(p.M, MT) * p.B;
+  if (blocks <= 0) return WETTS_OK;
+  WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
+  size_t lds = (size_t)2 * (NT + p.span) * RS;
+  hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB>), dim3((unsigned)blocks), dim3(256), lds,
+                     stream, p);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+int32_t launch_conv_bf16(const PackedConvB& pc, ConvBParams p, hipStream_t stream) {
+  p.wpk = pc.wpk;
+  p.bias = pc.bias;
+  p.M = pc.M;
+  p.Cin = pc.Cin;
+  p.cout = pc.Cout;
+  p.ktaps = pc.ktaps;
+  p.dil = pc.dil;
+  p.pad = pc.pad;
+  p.off_lo = pc.off_lo;
+  p.span = pc.span;
+  p.nchunks = pc.nchunks;
+  p.up = pc.up;
+  p.up_pad = pc.up_pad;
+  WETTS_REQUIRE(pc.wpk != nullptr, "bf16 conv weight not packed");
+  WETTS_REQUIRE(p.span <= 128, "conv receptive field too wide");
+  WETTS_REQUIRE(pc.Cout % 32 == 0 && pc.Cin % 8 == 0, "bf16 path needs Cout %% 32 == 0, Cin %% 8 == 0");
+  p.N = p.up > 0 ? p.Tin + p.ktaps - 1 : p.Tout;
+  if (pc.CKB == 64) {
+    if (p.M >= 128) return launch_b<4, 4, 1, 64>(p, stream);
+    return launch_b<4, 2, 2, 64>(p, stream);
+  }
+  if (p.M >= 128) return launch_b<4, 4, 1, 32>(p, stream);
+  if (p.M >= 64) return launch_b<4, 2, 2, 32>(p, stream);
+  return launch_b<4, 1, 4, 32>(p, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// layout / precision boundaries of the bf16 decoder
+// ------------------------------------------------------------------------------------------
+// f32 channel-first [B,C,T] -> bf16 channel-last [B,T,C]
+__global__ void cf32_to_cl16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
+                                    int B, int C, int T) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, c8, t) with t fastest
+  const int C8 = C / 8;
+  int64_t total = (int64_t)B * C8 * T;
+  if (idx >= total) return;
+  int t = (int)(idx % T);
+  int c8 = (int)((idx / T) % C8);
+  int b = (int)(idx / ((int64_t)T * C8));
+  const float* xp = x + ((int64_t)b * C + c8 * 8) * T + t;
+  uint4 o;
+  o.x = pack2(xp[0], xp[(int64_t)T]);
+  o.y = pack2(xp[2 * (int64_t)T], xp[3 * (int64_t)T]);
+  o.z = pack2(xp[4 * (int64_t)T], xp[5 * (int64_t)T]);
+  o.w = pack2(xp[6 * (int64_t)T], xp[7 * (int64_t)T]);
+  *reinterpret_cast<uint4*>(out + ((int64_t)b * T + t) * C + c8 * 8) = o;
+}
+
+int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, hipStream_t s) {
+  WETTS_REQUIRE(C % 8 == 0, "channel count must be a multiple of 8");
+  int64_t n = (int64_t)B * (C / 8) * T;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(cf32_to_cl16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out,
+                     B, C, T);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// conv_post on channel-last bf16: lrelu(0.01) -> Conv1d(C,1,k) -> tanh -> f32 audio [B,T]
+__global__ __launch_bounds__(256) void conv_post_bf16_kernel(const unsigned short* __restrict__ x,
+                                                             const float* __restrict__ w, int k,
+                                                             int B, int C, int T,
+                                                             float* __restrict__ out) {
+  extern __shared__ float wsh[];  // [j][c]
+  for (int i = threadIdx.x; i < C * k; i += blockDim.x) {
+    int c = i / k, j = i % k;
+    wsh[j * C + c] = w[i];
+  }
+  __syncthreads();
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * T) return;
+  const int b = (int)(idx / T), t = (int)(idx % T);
+  const int pad = (k - 1) / 2;
+  float acc = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const int tt = t + j - pad;
+    if (tt < 0 || tt >= T) continue;
+    const unsigned short* row = x + ((int64_t)b * T + tt) * C;
+    for (int c = 0; c < C; c += 8) {
+      const uint4 v = *reinterpret_cast<const uint4*>(row + c);
+      const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float lo = bf2f((unsigned short)(wv[e] & 0xffffu)), hi = bf2f((unsigned short)(wv[e] >> 16));
+        lo = lo > 0.f ? lo : lo * 0.01f;
+        hi = hi > 0.f ? hi : hi * 0.01f;
+        acc += wsh[j * C + c + 2 * e] * lo + wsh[j * C + c + 2 * e + 1] * hi;
+      }
+    }
+  }
+  out[idx] = tanhf(acc);
+}
+
+int32_t k_conv_post_bf16(const unsigned short* x, const float* w, int k, int B, int C, int T,
+                         float* out, hipStream_t s) {
+  WETTS_REQUIRE(C % 8 == 0 && k <= 15, "conv_post bf16: unsupported shape");
+  int64_t n = (int64_t)B * T;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(conv_post_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
+                     (size_t)C * k * 4, s, x, w, k, B, C, T, out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+}  // namespace wetts

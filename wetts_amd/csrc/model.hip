@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "common.h"
+#include "conv_bf16.h"
 #include "kernels.h"
 
 namespace wetts {
@@ -291,6 +292,10 @@ struct wetts_model {
   // MRF chains: the n_k ResBlocks of a stage are independent until their sum, so they run on
   // separate HIP streams (forked from / joined to the caller's stream with events); one chain's
   // launch tail and prologue/epilogue phases overlap another chain's MFMA work.
+  // bf16 decoder (opt-in, wetts_set_decoder_precision): weights packed on first use
+  mutable int dec_precision = 0;  // 0 = f32, 1 = bf16
+  mutable std::vector<PackedConvB> b_ups;
+  mutable std::vector<std::vector<PackedConvB>> b_c1, b_c2;  // per resblock
   int mrf_streams = 1;
   hipStream_t aux_stream[WETTS_MAX_RB_KERNELS] = {};
   hipEvent_t ev_fork = nullptr, ev_chain[WETTS_MAX_RB_KERNELS] = {};
@@ -633,6 +638,9 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
 void wetts_destroy(wetts_model_t* m) {
   if (!m) return;
   for (PackedConv* pc : m->all_packed) free_packed(pc);
+  for (auto& pc : m->b_ups) free_packed_bf16(&pc);
+  for (auto& v : m->b_c1) for (auto& pc : v) free_packed_bf16(&pc);
+  for (auto& v : m->b_c2) for (auto& pc : v) free_packed_bf16(&pc);
   for (int j = 0; j < WETTS_MAX_RB_KERNELS; ++j) {
     if (m->aux_stream[j]) (void)hipStreamDestroy(m->aux_stream[j]);
     if (m->ev_chain[j]) (void)hipEventDestroy(m->ev_chain[j]);
@@ -1123,12 +1131,166 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
 }
 }  // namespace wetts
 
+namespace wetts {
+static int32_t pack_decoder_bf16(const wetts_model* m, hipStream_t s) {
+  if (!m->b_ups.empty()) return WETTS_OK;
+  const wetts_config_t* c = &m->cfg;
+  const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
+  m->b_ups.resize(c->n_upsamples);
+  m->b_c1.assign(c->n_upsamples * nk, std::vector<PackedConvB>(nd));
+  m->b_c2.assign(c->n_upsamples * nk, std::vector<PackedConvB>(c->resblock == 1 ? nd : 0));
+  int ch = c->upsample_initial_channel;
+  for (int i = 0; i < c->n_upsamples; ++i) {
+    const int u = c->upsample_rates[i], uk = c->upsample_kernel_sizes[i];
+    WETTS_TRY(pack_conv_weight_bf16(m->T(S("dec.ups.%d.weight", i)), m->T(S("dec.ups.%d.bias", i)),
+                                    ch / 2, ch, uk, 1, (uk - u) / 2, 1, u, s, &m->b_ups[i]));
+    ch /= 2;
+    for (int j = 0; j < nk; ++j) {
+      const int n = i * nk + j, k = c->resblock_kernel_sizes[j];
+      for (int d = 0; d < nd; ++d) {
+        const int dil = c->resblock_dilation_sizes[j][d];
+        if (c->resblock == 1) {
+          WETTS_TRY(pack_conv_weight_bf16(m->T(S("dec.resblocks.%d.convs1.%d.weight", n, d)),
+                                          m->T(S("dec.resblocks.%d.convs1.%d.bias", n, d)), ch, ch,
+                                          k, dil, (k * dil - dil) / 2, 0, 0, s, &m->b_c1[n][d]));
+          WETTS_TRY(pack_conv_weight_bf16(m->T(S("dec.resblocks.%d.convs2.%d.weight", n, d)),
+                                          m->T(S("dec.resblocks.%d.convs2.%d.bias", n, d)), ch, ch,
+                                          k, 1, (k - 1) / 2, 0, 0, s, &m->b_c2[n][d]));
+        } else {
+          WETTS_TRY(pack_conv_weight_bf16(m->T(S("dec.resblocks.%d.convs.%d.weight", n, d)),
+                                          m->T(S("dec.resblocks.%d.convs.%d.bias", n, d)), ch, ch,
+                                          k, dil, (k * dil - dil) / 2, 0, 0, s, &m->b_c1[n][d]));
+        }
+      }
+    }
+  }
+  return WETTS_OK;
+}
+
+static ConvBParams convb_io(const unsigned short* x, int Cin, int T, unsigned short* out, int Cout,
+                            int Tout, int B) {
+  ConvBParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.x_bs = (int64_t)Cin * T;
+  p.Cin = Cin;
+  p.Tin = T;
+  p.in_act = IN_LRELU;
+  p.in_slope = 0.1f;
+  p.out = out;
+  p.o_bs = (int64_t)Cout * Tout;
+  p.cout = Cout;
+  p.Tout = Tout;
+  p.out_div = 1.f;
+  p.B = B;
+  return p;
+}
+
+// Generator.forward with bf16 channel-last activations between the convs (f32 accumulate):
+// conv_pre (+cond) runs on the f32 kernel, its output is rounded to bf16; conv_post + tanh are f32.
+static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_bs, int64_t z_cs,
+                                const float* y_mask, int64_t mask_stride, const float* g, int B,
+                                int L, float* audio, void* workspace, int64_t workspace_bytes,
+                                hipStream_t s) {
+  const wetts_config_t* c = &m->cfg;
+  const int I = c->inter_channels, C0 = c->upsample_initial_channel;
+  WETTS_TRY(pack_decoder_bf16(m, s));
+  const int64_t mx = dec_max_elems(c, B, L);
+  Bump ws(workspace, workspace_bytes);
+  float* pre = ws.take<float>((int64_t)B * C0 * L);
+  unsigned short* bx = ws.take<unsigned short>(mx);
+  unsigned short* bt = ws.take<unsigned short>(mx);
+  unsigned short* bs = ws.take<unsigned short>(mx);
+  unsigned short* fa = ws.take<unsigned short>(mx);
+  unsigned short* fb = ws.take<unsigned short>(mx);
+  unsigned short* ft = ws.take<unsigned short>(mx);
+  float* cond = ws.take<float>((int64_t)B * C0);
+  if (!ws.ok) {
+    set_error("hifigan(bf16): workspace too small");
+    return WETTS_E_WORKSPACE;
+  }
+  {
+    ConvParams p = conv_io(z, I, L, pre, C0, B);
+    p.x_bs = z_bs;
+    p.x_cs = z_cs;
+    if (y_mask) {
+      p.in_mask = y_mask;
+      p.in_mask_stride = mask_stride;
+    }
+    if (has_g(c) && g) {
+      WETTS_TRY(k_cond_linear(g, m->dec_cond_w, m->dec_cond_b, B, C0, c->gin_channels, cond, s));
+      p.bias_b = cond;
+      p.bias_b_stride = C0;
+    }
+    WETTS_TRY(launch_conv(m->conv_pre, p, s));
+    WETTS_TRY(k_cf32_to_cl16(pre, bx, B, C0, L, s));
+  }
+  int ch = C0, len = L;
+  unsigned short* x = bx;
+  const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
+  for (int i = 0; i < c->n_upsamples; ++i) {
+    const int u = c->upsample_rates[i];
+    {
+      ConvBParams p = convb_io(x, ch, len, bt, ch / 2, len * u, B);
+      WETTS_TRY(launch_conv_bf16(m->b_ups[i], p, s));
+    }
+    ch /= 2;
+    len *= u;
+    unsigned short* xsum = (x == bx) ? bs : bx;
+    for (int j = 0; j < nk; ++j) {
+      const int n = i * nk + j;
+      const unsigned short* rx = bt;
+      for (int d = 0; d < nd; ++d) {
+        const bool last_d = (d == nd - 1);
+        unsigned short* outp = last_d ? xsum : ((rx == fa) ? fb : fa);
+        const int accum = (last_d && j > 0) ? 1 : 0;
+        const float odiv = (last_d && j == nk - 1) ? (float)nk : 1.f;
+        if (c->resblock == 1) {
+          WETTS_TRY(launch_conv_bf16(m->b_c1[n][d], convb_io(rx, ch, len, ft, ch, len, B), s));
+          ConvBParams p2 = convb_io(ft, ch, len, outp, ch, len, B);
+          p2.res = rx;
+          p2.r_bs = (int64_t)ch * len;
+          p2.accum = accum;
+          p2.out_div = odiv;
+          WETTS_TRY(launch_conv_bf16(m->b_c2[n][d], p2, s));
+        } else {
+          ConvBParams p1 = convb_io(rx, ch, len, outp, ch, len, B);
+          p1.res = rx;
+          p1.r_bs = (int64_t)ch * len;
+          p1.accum = accum;
+          p1.out_div = odiv;
+          WETTS_TRY(launch_conv_bf16(m->b_c1[n][d], p1, s));
+        }
+        rx = outp;
+      }
+    }
+    x = xsum;
+  }
+  return k_conv_post_bf16(x, m->conv_post_w, 7, B, ch, len, audio, s);
+}
+}  // namespace wetts
+
+int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision) {
+  WETTS_REQUIRE(m != nullptr, "null model");
+  WETTS_REQUIRE(precision == 0 || precision == 1, "precision must be 0 (f32) or 1 (bf16)");
+  if (precision == 1) {
+    const wetts_config_t* c = &m->cfg;
+    WETTS_REQUIRE((c->upsample_initial_channel >> c->n_upsamples) % 32 == 0,
+                  "bf16 decoder needs every stage width to be a multiple of 32 channels");
+  }
+  m->dec_precision = precision;
+  return WETTS_OK;
+}
+
 int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_stride,
                       int64_t z_channel_stride, const float* y_mask, int64_t mask_stride,
                       const float* g, int32_t B, int32_t L, float* audio, void* workspace,
                       int64_t workspace_bytes, void* stream) {
   WETTS_REQUIRE(m && z && audio, "null argument");
   if (B == 0 || L == 0) return WETTS_OK;
+  if (m->dec_precision == 1)
+    return run_hifigan_bf16(m, z, z_batch_stride, z_channel_stride, y_mask, mask_stride, g, B, L,
+                            audio, workspace, workspace_bytes, (hipStream_t)stream);
   return run_hifigan(m, z, z_batch_stride, z_channel_stride, y_mask, mask_stride, g, B, L, audio,
                      workspace, workspace_bytes, (hipStream_t)stream, nullptr);
 }

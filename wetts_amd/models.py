@@ -90,6 +90,16 @@ class SynthesizerTrn:
     def cuda(self, device=None):
         return self.to("cuda" if device is None else device)
 
+    def set_decoder_dtype(self, dtype):
+        """HiFi-GAN arithmetic: torch.float32 (default, parity-gated) or torch.bfloat16
+        (bf16 activations/weights, f32 accumulation; encoder / duration / flow stay f32)."""
+        prec = {torch.float32: 0, "f32": 0, "fp32": 0, torch.bfloat16: 1, "bf16": 1}[dtype]
+        self._decoder_precision = prec
+        if self._handle is not None:
+            _lib.check(_lib.load().wetts_set_decoder_precision(self._handle, prec),
+                       "set_decoder_precision")
+        return self
+
     def blob_layout(self):
         return checkpoint.blob_layout(self.cfg)
 
@@ -129,6 +139,9 @@ class SynthesizerTrn:
                                   _lib.current_stream_ptr(), C.byref(h))
             _lib.check(rc, "wetts_create")
             self._handle = h
+            if getattr(self, "_decoder_precision", 0):
+                _lib.check(lib.wetts_set_decoder_precision(h, self._decoder_precision),
+                           "set_decoder_precision")
 
     def _destroy(self):
         if self._handle is not None:
