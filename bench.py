@@ -209,20 +209,35 @@ def main():
             traffic, traffic_src = dom["hbm_bytes_per_launch"], os.path.basename(files[-1])
     except Exception:
         pass
-    roofline = {
-        "kernel": "conv_mfma_kernel (MRF ResBlock convs)",
-        "bound": "mfma", "achieved": mrf_tflops, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": mrf_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-        "traffic_unit": "HBM bytes per conv_mfma launch (2*FETCH_SIZE+WRITE_SIZE)*1024, PMC",
-        "traffic_source": traffic_src,
-        "launches": int(nl.value), "avg_launch_ms": ms.value / max(1, nl.value),
-        "flops_per_launch": mrf_flops / max(1, nl.value),
-        "hbm_view": {"achieved": mrf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": mrf_gbs / HBM_PEAK_GBS,
-                     "note": "per-conv algorithmic bytes (SURVEY 8d); fp32 convs are "
-                             "compute-bound (AI 113 flop/B > ridge ~20)"},
-        "mrf_share_of_step": ms.value / (elapsed * 1e3),
-    }
+    if args.decoder_dtype == "bf16":
+        # bf16 activations: per-conv algorithmic bytes are half the f32 figure; k=3 launches are
+        # HBM-bound, k=11 at C>=128 MFMA-bound (ridge ~400 flop/B) -- report both views
+        gbs = 0.5 * mrf_gbs
+        roofline = {
+            "kernel": "conv_bf16_kernel (MRF ResBlock convs, bf16 channel-last)",
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "launches": int(nl.value), "avg_launch_ms": ms.value / max(1, nl.value),
+            "bytes_per_launch": 0.5 * mby.value * padded_frames / max(1, nl.value),
+            "mfma_view": {"achieved": mrf_tflops, "peak": 2500.0, "unit": "TFLOP/s",
+                          "frac": mrf_tflops / 2500.0},
+            "mrf_share_of_step": ms.value / (elapsed * 1e3),
+        }
+    else:
+        roofline = {
+            "kernel": "conv_mfma_kernel (MRF ResBlock convs)",
+            "bound": "mfma", "achieved": mrf_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": mrf_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_unit": "HBM bytes per conv_mfma launch (2*FETCH_SIZE+WRITE_SIZE)*1024, PMC",
+            "traffic_source": traffic_src,
+            "launches": int(nl.value), "avg_launch_ms": ms.value / max(1, nl.value),
+            "flops_per_launch": mrf_flops / max(1, nl.value),
+            "hbm_view": {"achieved": mrf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": mrf_gbs / HBM_PEAK_GBS,
+                         "note": "per-conv algorithmic bytes (SURVEY 8d); fp32 convs are "
+                                 "compute-bound (AI 113 flop/B > ridge ~20)"},
+            "mrf_share_of_step": ms.value / (elapsed * 1e3),
+        }
     out = {
         "metric": "audio samples/sec + RTF @22.05 kHz, VITS-Baker, 1/2/4/8 MI355X",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,

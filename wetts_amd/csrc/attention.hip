@@ -38,21 +38,40 @@ __global__ __launch_bounds__(64) void attn_scores_kernel(
   S[(((int64_t)bh * T) + j) * T + i] = sc;
 }
 
-// softmax over j for every (b,h,i); grid: (ceil(T/64), B*H)
-__global__ __launch_bounds__(64) void attn_softmax_kernel(int T, float* __restrict__ S) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
+// softmax over j for every (b,h,i); block = 16 query lanes x 16 key groups (latency-bound: T is a
+// few hundred, so many short threads); grid: (ceil(T/16), B*H)
+__global__ __launch_bounds__(256) void attn_softmax_kernel(int T, float* __restrict__ S) {
+  constexpr int TL = 16, JG = 16;
+  __shared__ float red[JG][TL + 1];
+  const int il = threadIdx.x % TL, jg = threadIdx.x / TL;
+  const int i = blockIdx.x * TL + il;
   const int bh = blockIdx.y;
-  if (i >= T) return;
-  float* col = S + (int64_t)bh * T * T + i;
+  const bool ok = i < T;
+  float* col = S + (int64_t)bh * T * T + (ok ? i : 0);
+  const int j0 = (T * jg) / JG, j1 = (T * (jg + 1)) / JG;
   float mx = -INFINITY;
-  for (int j = 0; j < T; ++j) mx = fmaxf(mx, col[(int64_t)j * T]);
+  if (ok)
+    for (int j = j0; j < j1; ++j) mx = fmaxf(mx, col[(int64_t)j * T]);
+  red[jg][il] = mx;
+  __syncthreads();
+  mx = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < JG; ++q) mx = fmaxf(mx, red[q][il]);
+  __syncthreads();
   float sm = 0.f;
-  for (int j = 0; j < T; ++j) {
-    float e = expf(col[(int64_t)j * T] - mx);
-    col[(int64_t)j * T] = e;
-    sm += e;
-  }
-  for (int j = 0; j < T; ++j) col[(int64_t)j * T] = col[(int64_t)j * T] / sm;
+  if (ok)
+    for (int j = j0; j < j1; ++j) {
+      float e = expf(col[(int64_t)j * T] - mx);
+      col[(int64_t)j * T] = e;
+      sm += e;
+    }
+  red[jg][il] = sm;
+  __syncthreads();
+  sm = 0.f;
+#pragma unroll
+  for (int q = 0; q < JG; ++q) sm += red[q][il];
+  if (ok)
+    for (int j = j0; j < j1; ++j) col[(int64_t)j * T] = col[(int64_t)j * T] / sm;
 }
 
 // out[b, h*dk+d, i] = sum_j P[j,i] v[d,j] + sum_r P[i+r,i] E_v[r+w][d];  grid (ceil(T/64), dk, B*H)
@@ -87,7 +106,7 @@ int32_t k_rel_attention(const float* q, const float* k, const float* v, const fl
   hipLaunchKernelGGL(attn_scores_kernel, dim3(tb, T, B * n_heads), dim3(64), 0, s, q, k, mask,
                      emb_rel_k, window, n_heads, dk, T, qdiv, scores);
   WETTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_softmax_kernel, dim3(tb, B * n_heads), dim3(64), 0, s, T, scores);
+  hipLaunchKernelGGL(attn_softmax_kernel, dim3(cdiv(T, 16), B * n_heads), dim3(256), 0, s, T, scores);
   WETTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_pv_kernel, dim3(tb, dk, B * n_heads), dim3(64), 0, s, scores, v,
                      emb_rel_v, window, n_heads, dk, T, out);

@@ -55,14 +55,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ a, const float* __restrict__ add, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ res, const float* __restrict__ mask,
     int gelu, int B, int C, int T, float eps, float* __restrict__ out) {
-  __shared__ float red[4][64];
-  const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
-  const int tblocks = (T + 63) / 64;
+  // block = 16 time lanes x 16 channel groups: the tensors here are tiny (B*T columns), so the
+  // kernel is latency-bound and wants many short threads rather than few long ones
+  constexpr int TL = 16, CG = 16;
+  __shared__ float red[CG][TL + 1];
+  const int tl = threadIdx.x % TL, cg = threadIdx.x / TL;
+  const int tblocks = (T + TL - 1) / TL;
   const int b = blockIdx.x / tblocks;
-  const int t = (blockIdx.x % tblocks) * 64 + tl;
+  const int t = (blockIdx.x % tblocks) * TL + tl;
   const bool ok = t < T;
   const int64_t base = (int64_t)b * C * T + t;
-  const int c0 = (C * cg) / 4, c1 = (C * (cg + 1)) / 4;
+  const int c0 = (C * cg) / CG, c1 = (C * (cg + 1)) / CG;
 
   float sum = 0.f;
   if (ok) {
@@ -74,7 +77,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   }
   red[cg][tl] = sum;
   __syncthreads();
-  const float mean = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / (float)C;
+  float tot = 0.f;
+#pragma unroll
+  for (int q = 0; q < CG; ++q) tot += red[q][tl];
+  const float mean = tot / (float)C;
   __syncthreads();
   float sq = 0.f;
   if (ok) {
@@ -87,7 +93,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   }
   red[cg][tl] = sq;
   __syncthreads();
-  const float var = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / (float)C;
+  tot = 0.f;
+#pragma unroll
+  for (int q = 0; q < CG; ++q) tot += red[q][tl];
+  const float var = tot / (float)C;
   const float rstd = 1.f / sqrtf(var + eps);
   if (!ok) return;
   const float mk = mask ? mask[(int64_t)b * T + t] : 1.f;
@@ -105,7 +114,7 @@ int32_t k_layernorm(const float* a, const float* add, const float* gamma, const 
                     const float* res, const float* mask, int gelu, int B, int C, int T, float* out,
                     hipStream_t s) {
   if (B * T == 0) return WETTS_OK;
-  int blocks = B * cdiv(T, 64);
+  int blocks = B * cdiv(T, 16);
   hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, s, a, add, gamma, beta, res,
                      mask, gelu, B, C, T, 1e-5f, out);
   WETTS_LAUNCH_CHECK();

@@ -1237,6 +1237,12 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
     ch /= 2;
     len *= u;
     unsigned short* xsum = (x == bx) ? bs : bx;
+    hipEvent_t lv0 = nullptr, lv1 = nullptr;
+    if (m->mrf_timing) {
+      WETTS_HIP_CHECK(hipEventCreate(&lv0));
+      WETTS_HIP_CHECK(hipEventCreate(&lv1));
+      WETTS_HIP_CHECK(hipEventRecord(lv0, s));
+    }
     for (int j = 0; j < nk; ++j) {
       const int n = i * nk + j;
       const unsigned short* rx = bt;
@@ -1264,8 +1270,14 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
         rx = outp;
       }
     }
+    if (m->mrf_timing) {
+      WETTS_HIP_CHECK(hipEventRecord(lv1, s));
+      m->mrf_events.emplace_back(lv0, lv1);
+      m->mrf_launches += (int64_t)nk * nd * (c->resblock == 1 ? 2 : 1);
+    }
     x = xsum;
   }
+  if (m->mrf_timing) m->mrf_calls += 1;
   return k_conv_post_bf16(x, m->conv_post_w, 7, B, ch, len, audio, s);
 }
 }  // namespace wetts
