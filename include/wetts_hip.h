@@ -184,8 +184,8 @@ int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_st
                       int64_t workspace_bytes, void* stream);
 
 /* Decoder arithmetic: 0 = float32 (default; exact-f32 MFMA, the parity-gated path),
- * 1 = bfloat16 activations / weights with f32 accumulation (BASELINE.json configs[2]/[4]
- * precision; the text encoder, duration predictor and flow stay f32).  Weights are re-packed on
+ * 1 = bfloat16, 2 = IEEE half activations / weights with f32 accumulation (BASELINE.json
+ * configs[2] / configs[4] precision; the text encoder, duration predictor and flow stay f32).  Weights are re-packed on
  * first use. */
 int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision);
 

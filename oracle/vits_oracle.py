@@ -338,9 +338,21 @@ def hifigan(W, cfg, z, g):
     return torch.tanh(x)
 
 
+_QDTYPE = torch.bfloat16
+
+
 def _q(x):
-    """round-to-nearest-even to bfloat16, kept in float32"""
-    return x.to(torch.bfloat16).to(torch.float32)
+    """round-to-nearest-even to the 16-bit storage type (bfloat16 / float16), kept in float32"""
+    return x.to(_QDTYPE).to(torch.float32)
+
+
+def hifigan_16bit_sim(W, cfg, z, g, dtype=torch.bfloat16):
+    global _QDTYPE
+    old, _QDTYPE = _QDTYPE, dtype
+    try:
+        return hifigan_bf16sim(W, cfg, z, g)
+    finally:
+        _QDTYPE = old
 
 
 def hifigan_bf16sim(W, cfg, z, g):

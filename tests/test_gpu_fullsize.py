@@ -116,3 +116,34 @@ def test_empty_and_tiny_inputs():
     o0, *_ = net.infer(torch.tensor([[3, 4]]).cuda(), torch.tensor([2]).cuda(),
                        sid=torch.tensor([0]).cuda(), max_len=0)
     assert o0.shape == (1, 1, 0)
+
+
+@pytest.mark.parametrize("mname,B,n_spk", [("v3", 64, 2), ("stress48k", 4, 1)])
+def test_reduced_precision_decoder_configs(mname, B, n_spk):
+    """BASELINE.json configs[2] (v3, B=64, bf16, speaker path) and configs[4] (builder-defined
+    48 kHz stress shape; reduced precision).  The decoder runs in bf16 (f32 accumulate); the
+    f32 run of the same model on the same noise is the yardstick: identical alignment (the
+    duration path stays f32) and waveform within 3e-2 relative RMS."""
+    net, _ = _net(mname, 256, n_spk)
+    g = torch.Generator().manual_seed(2)
+    Tx = 128 if mname == "v3" else 48
+    x = torch.randint(0, 256, (B, Tx), generator=g)
+    xl = torch.randint(Tx // 2, Tx + 1, (B,), generator=g).long()
+    sid = (torch.arange(B) % n_spk)
+    eps_w = torch.randn(B, 2, Tx, generator=g)
+    o32, attn32, ym32, _ = _run(net, x, xl, sid, eps_w)
+    Ty = ym32.shape[-1]
+    eps_z = torch.randn(B, 192, Ty, generator=g)
+    o32, attn32, ym32, _ = _run(net, x, xl, sid, eps_w, eps_z)
+    net.set_decoder_dtype(torch.bfloat16)
+    o16, attn16, ym16, _ = _run(net, x, xl, sid, eps_w, eps_z)
+    net.set_decoder_dtype(torch.float32)
+    assert torch.equal(attn16, attn32) and torch.equal(ym16, ym32)
+    assert o16.shape == o32.shape and torch.isfinite(o16).all()
+    # compare on valid samples only
+    hop = net.hop_length
+    valid = ym32[:, 0].repeat_interleave(hop, dim=1).bool().cpu().numpy()
+    a, b = o16[:, 0].cpu().numpy()[valid], o32[:, 0].cpu().numpy()[valid]
+    rel = util.rel_rms(a, b)
+    print(mname, "bf16 decoder vs f32: rel rms", rel, "hop", hop)
+    assert rel < 3e-2

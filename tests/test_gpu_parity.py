@@ -156,6 +156,26 @@ def test_product_path_fails_loudly_without_device_weights():
 
 
 @pytest.mark.parametrize("name", ["v1_b2", "v3_b2"])
+def test_hifigan_f16_mode_matches_its_numerics_spec(name):
+    """IEEE-half decoder (configs[4] precision): 11-bit mantissa => ~8x tighter than bf16."""
+    from oracle import vits_oracle as vo
+    case = util.load_case(name)
+    net, cfg, W = _model(case)
+    cd = util.cfg_dict(cfg)
+    z = util.t(case["z"]) * util.t(case["y_mask"])
+    sid = util.t(case["sid"])
+    g = torch.nn.functional.embedding(sid, W["emb_g.weight"]).unsqueeze(-1)
+    with torch.no_grad():
+        spec = vo.hifigan_16bit_sim(W, cd, z, g, torch.float16).numpy()
+        f32 = vo.hifigan(W, cd, z, g).numpy()
+    net.set_decoder_dtype(torch.float16)
+    got = net.hifigan(z.cuda(), g[:, :, 0].cuda()).cpu().numpy()
+    r_spec, r_f32 = util.rel_rms(got, spec), util.rel_rms(got, f32)
+    print(name, "f16 vs spec", r_spec, "f16 vs f32", r_f32)
+    assert np.isfinite(got).all() and r_spec < 2e-3 and r_f32 < 1e-2
+
+
+@pytest.mark.parametrize("name", ["v1_b2", "v3_b2"])
 def test_hifigan_bf16_mode_matches_its_numerics_spec(name):
     """bf16 decoder (configs[2]/[4] precision): against oracle.hifigan_bf16sim (same rounding
     points) and, loosely, against the f32 oracle.  Tolerances: rel RMS 1e-2 vs the bf16 spec

@@ -9,6 +9,7 @@ struct PackedConvB {
   const float* bias = nullptr;    // f32
   int M = 0, Cin = 0, Cout = 0, ktaps = 0, dil = 1, pad = 0, up = 0, up_pad = 0;
   int off_lo = 0, span = 0, nchunks = 0, CKB = 64;
+  int f16 = 0;  // 0: bfloat16 storage, 1: IEEE half
 };
 
 struct ConvBParams {
@@ -32,12 +33,13 @@ struct ConvBParams {
 };
 
 int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
-                              int dil, int pad, int transposed, int up, hipStream_t stream,
+                              int dil, int pad, int transposed, int up, int f16, hipStream_t stream,
                               PackedConvB* out);
 void free_packed_bf16(PackedConvB* pc);
 int32_t launch_conv_bf16(const PackedConvB& pc, ConvBParams p, hipStream_t stream);
-int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, hipStream_t s);
+int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, int f16,
+                       hipStream_t s);
 int32_t k_conv_post_bf16(const unsigned short* x, const float* w, int k, int B, int C, int T,
-                         float* out, hipStream_t s);
+                         float* out, int f16, hipStream_t s);
 
 }  // namespace wetts

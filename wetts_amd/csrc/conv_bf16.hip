@@ -30,6 +30,30 @@ __device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest e
 __device__ __forceinline__ unsigned pack2(float a, float b) {
   return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
 }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// 16-bit storage type selected at compile time: F16 = IEEE half, else bfloat16
+template <bool F16>
+__device__ __forceinline__ float cv_in(unsigned short h) {
+  if (F16) return (float)__builtin_bit_cast(_Float16, h);
+  return bf2f(h);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned short cv_out(float f) {
+  if (F16) return __builtin_bit_cast(unsigned short, (_Float16)f);
+  return f2bf(f);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+  return (unsigned)cv_out<F16>(a) | ((unsigned)cv_out<F16>(b) << 16);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c) {
+  if (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 // ------------------------------------------------------------------------------------------
 // weight packing: [mt32][g = chunk*ktaps + tap][ks][lane][8 bf16]
@@ -38,7 +62,7 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // ------------------------------------------------------------------------------------------
 __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
                                  int M, int Cin, int Cout, int k, int ktaps, int up, int transposed,
-                                 int CKB, int64_t total) {
+                                 int CKB, int f16, int64_t total) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int KS = CKB / 16;
@@ -64,14 +88,13 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __
       if (kk < k) v = w[((int64_t)ci * Cout + co) * k + kk];
     }
   }
-  unsigned u = __float_as_uint(v);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  out[idx] = (unsigned short)(u >> 16);
+  out[idx] = f16 ? cv_out<true>(v) : cv_out<false>(v);
 }
 
 int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
-                              int dil, int pad, int transposed, int up, hipStream_t stream,
+                              int dil, int pad, int transposed, int up, int f16, hipStream_t stream,
                               PackedConvB* pc) {
+  pc->f16 = f16;
   pc->Cin = Cin;
   pc->Cout = Cout;
   pc->bias = bias_dev;
@@ -92,7 +115,7 @@ int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cou
   WETTS_HIP_CHECK(hipMalloc((void**)&pc->wpk, total * sizeof(unsigned short)));
   hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                      w_dev, pc->wpk, pc->M, Cin, Cout, k, pc->ktaps, up > 0 ? up : 1, transposed,
-                     pc->CKB, total);
+                     pc->CKB, f16, total);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -105,7 +128,7 @@ void free_packed_bf16(PackedConvB* pc) {
 // ------------------------------------------------------------------------------------------
 // the conv kernel: 4 waves (WM x WN), each wave one 32-row m-block x NB 32-column n-blocks
 // ------------------------------------------------------------------------------------------
-template <int NB, int WM, int WN, int CKB>
+template <int NB, int WM, int WN, int CKB, bool F16>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int MT = 32 * WM;
@@ -163,10 +186,10 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
   const bool lrelu = p.in_act == IN_LRELU;
   const float slope = p.in_slope;
   auto act2 = [&](unsigned w) -> unsigned {
-    float a = bf2f((unsigned short)(w & 0xffffu)), c2 = bf2f((unsigned short)(w >> 16));
+    float a = cv_in<F16>((unsigned short)(w & 0xffffu)), c2 = cv_in<F16>((unsigned short)(w >> 16));
     a = a > 0.f ? a : a * slope;
     c2 = c2 > 0.f ? c2 : c2 * slope;
-    return pack2(a, c2);
+    return pk2<F16>(a, c2);
   };
   auto store_chunk = [&](unsigned char* buf) {
 #pragma unroll
@@ -210,14 +233,14 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
           if (p.res) {
             uint2 rr = *reinterpret_cast<const uint2*>(p.res + (int64_t)b * p.r_bs +
                                                        (int64_t)t * p.cout + c);
-            v0 = bf2f((unsigned short)(rr.x & 0xffffu)); v1 = bf2f((unsigned short)(rr.x >> 16));
-            v2 = bf2f((unsigned short)(rr.y & 0xffffu)); v3 = bf2f((unsigned short)(rr.y >> 16));
+            v0 = cv_in<F16>((unsigned short)(rr.x & 0xffffu)); v1 = cv_in<F16>((unsigned short)(rr.x >> 16));
+            v2 = cv_in<F16>((unsigned short)(rr.y & 0xffffu)); v3 = cv_in<F16>((unsigned short)(rr.y >> 16));
           }
           if (p.accum) {
             uint2 oo = *reinterpret_cast<const uint2*>(p.out + (int64_t)b * p.o_bs +
                                                        (int64_t)t * p.cout + c);
-            v0 += bf2f((unsigned short)(oo.x & 0xffffu)); v1 += bf2f((unsigned short)(oo.x >> 16));
-            v2 += bf2f((unsigned short)(oo.y & 0xffffu)); v3 += bf2f((unsigned short)(oo.y >> 16));
+            v0 += cv_in<F16>((unsigned short)(oo.x & 0xffffu)); v1 += cv_in<F16>((unsigned short)(oo.x >> 16));
+            v2 += cv_in<F16>((unsigned short)(oo.y & 0xffffu)); v3 += cv_in<F16>((unsigned short)(oo.y >> 16));
           }
           acc[j][4 * q + 0] = v0; acc[j][4 * q + 1] = v1;
           acc[j][4 * q + 2] = v2; acc[j][4 * q + 3] = v3;
@@ -256,12 +279,11 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
         const unsigned char* bb = cur + (size_t)(brow0 + tap * p.dil) * RS + half * 16;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          const bf16x8 av = __builtin_bit_cast(bf16x8, aa[par][s]);
+          const uint4 av = aa[par][s];
 #pragma unroll
           for (int j = 0; j < NB; ++j) {
             const uint4 bw = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bw),
-                                                             acc[j], 0, 0, 0);
+            acc[j] = mfma16<F16>(av, bw, acc[j]);
           }
         }
         if (++tap == p.ktaps) {
@@ -299,22 +321,26 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
       float v3 = acc[j][4 * q + 3] + bia[4 * q + 3];
       if (dodiv) { v0 = v0 / p.out_div; v1 = v1 / p.out_div; v2 = v2 / p.out_div; v3 = v3 / p.out_div; }
       uint2 o;
-      o.x = pack2(v0, v1);
-      o.y = pack2(v2, v3);
+      o.x = pk2<F16>(v0, v1);
+      o.y = pk2<F16>(v2, v3);
       *reinterpret_cast<uint2*>(ob + (int64_t)t * p.cout + co_blk + 8 * q + 4 * half) = o;
     }
   }
 }
 
 template <int NB, int WM, int WN, int CKB>
-static int32_t launch_b(const ConvBParams& p, hipStream_t stream) {
+static int32_t launch_b(const ConvBParams& p, hipStream_t stream, bool f16) {
   constexpr int MT = 32 * WM, NT = 32 * NB * WN, RS = CKB * 2 + 16;
   int64_t blocks = (int64_t)cdiv(p.N, NT) * cdiv(p.M, MT) * p.B;
   if (blocks <= 0) return WETTS_OK;
   WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
   size_t lds = (size_t)2 * (NT + p.span) * RS;
-  hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB>), dim3((unsigned)blocks), dim3(256), lds,
-                     stream, p);
+  if (f16)
+    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true>), dim3((unsigned)blocks), dim3(256),
+                       lds, stream, p);
+  else
+    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false>), dim3((unsigned)blocks),
+                       dim3(256), lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -338,18 +364,19 @@ int32_t launch_conv_bf16(const PackedConvB& pc, ConvBParams p, hipStream_t strea
   WETTS_REQUIRE(pc.Cout % 32 == 0 && pc.Cin % 8 == 0, "bf16 path needs Cout %% 32 == 0, Cin %% 8 == 0");
   p.N = p.up > 0 ? p.Tin + p.ktaps - 1 : p.Tout;
   if (pc.CKB == 64) {
-    if (p.M >= 128) return launch_b<4, 4, 1, 64>(p, stream);
-    return launch_b<4, 2, 2, 64>(p, stream);
+    if (p.M >= 128) return launch_b<4, 4, 1, 64>(p, stream, pc.f16 != 0);
+    return launch_b<4, 2, 2, 64>(p, stream, pc.f16 != 0);
   }
-  if (p.M >= 128) return launch_b<4, 4, 1, 32>(p, stream);
-  if (p.M >= 64) return launch_b<4, 2, 2, 32>(p, stream);
-  return launch_b<4, 1, 4, 32>(p, stream);
+  if (p.M >= 128) return launch_b<4, 4, 1, 32>(p, stream, pc.f16 != 0);
+  if (p.M >= 64) return launch_b<4, 2, 2, 32>(p, stream, pc.f16 != 0);
+  return launch_b<4, 1, 4, 32>(p, stream, pc.f16 != 0);
 }
 
 // ------------------------------------------------------------------------------------------
 // layout / precision boundaries of the bf16 decoder
 // ------------------------------------------------------------------------------------------
 // f32 channel-first [B,C,T] -> bf16 channel-last [B,T,C]
+template <bool F16>
 __global__ void cf32_to_cl16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
                                     int B, int C, int T) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, c8, t) with t fastest
@@ -361,24 +388,30 @@ __global__ void cf32_to_cl16_kernel(const float* __restrict__ x, unsigned short*
   int b = (int)(idx / ((int64_t)T * C8));
   const float* xp = x + ((int64_t)b * C + c8 * 8) * T + t;
   uint4 o;
-  o.x = pack2(xp[0], xp[(int64_t)T]);
-  o.y = pack2(xp[2 * (int64_t)T], xp[3 * (int64_t)T]);
-  o.z = pack2(xp[4 * (int64_t)T], xp[5 * (int64_t)T]);
-  o.w = pack2(xp[6 * (int64_t)T], xp[7 * (int64_t)T]);
+  o.x = pk2<F16>(xp[0], xp[(int64_t)T]);
+  o.y = pk2<F16>(xp[2 * (int64_t)T], xp[3 * (int64_t)T]);
+  o.z = pk2<F16>(xp[4 * (int64_t)T], xp[5 * (int64_t)T]);
+  o.w = pk2<F16>(xp[6 * (int64_t)T], xp[7 * (int64_t)T]);
   *reinterpret_cast<uint4*>(out + ((int64_t)b * T + t) * C + c8 * 8) = o;
 }
 
-int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, hipStream_t s) {
+int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, int f16,
+                       hipStream_t s) {
   WETTS_REQUIRE(C % 8 == 0, "channel count must be a multiple of 8");
   int64_t n = (int64_t)B * (C / 8) * T;
   if (n == 0) return WETTS_OK;
-  hipLaunchKernelGGL(cf32_to_cl16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out,
-                     B, C, T);
+  if (f16)
+    hipLaunchKernelGGL(cf32_to_cl16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       x, out, B, C, T);
+  else
+    hipLaunchKernelGGL(cf32_to_cl16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       s, x, out, B, C, T);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
 
 // conv_post on channel-last bf16: lrelu(0.01) -> Conv1d(C,1,k) -> tanh -> f32 audio [B,T]
+template <bool F16>
 __global__ __launch_bounds__(256) void conv_post_bf16_kernel(const unsigned short* __restrict__ x,
                                                              const float* __restrict__ w, int k,
                                                              int B, int C, int T,
@@ -403,7 +436,7 @@ __global__ __launch_bounds__(256) void conv_post_bf16_kernel(const unsigned shor
       const unsigned wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float lo = bf2f((unsigned short)(wv[e] & 0xffffu)), hi = bf2f((unsigned short)(wv[e] >> 16));
+        float lo = cv_in<F16>((unsigned short)(wv[e] & 0xffffu)), hi = cv_in<F16>((unsigned short)(wv[e] >> 16));
         lo = lo > 0.f ? lo : lo * 0.01f;
         hi = hi > 0.f ? hi : hi * 0.01f;
         acc += wsh[j * C + c + 2 * e] * lo + wsh[j * C + c + 2 * e + 1] * hi;
@@ -414,12 +447,16 @@ __global__ __launch_bounds__(256) void conv_post_bf16_kernel(const unsigned shor
 }
 
 int32_t k_conv_post_bf16(const unsigned short* x, const float* w, int k, int B, int C, int T,
-                         float* out, hipStream_t s) {
+                         float* out, int f16, hipStream_t s) {
   WETTS_REQUIRE(C % 8 == 0 && k <= 15, "conv_post bf16: unsupported shape");
   int64_t n = (int64_t)B * T;
   if (n == 0) return WETTS_OK;
-  hipLaunchKernelGGL(conv_post_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
-                     (size_t)C * k * 4, s, x, w, k, B, C, T, out);
+  if (f16)
+    hipLaunchKernelGGL(conv_post_bf16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256),
+                       (size_t)C * k * 4, s, x, w, k, B, C, T, out);
+  else
+    hipLaunchKernelGGL(conv_post_bf16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256),
+                       (size_t)C * k * 4, s, x, w, k, B, C, T, out);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

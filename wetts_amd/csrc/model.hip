@@ -1133,7 +1133,11 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
 
 namespace wetts {
 static int32_t pack_decoder_bf16(const wetts_model* m, hipStream_t s) {
-  if (!m->b_ups.empty()) return WETTS_OK;
+  const int f16 = m->dec_precision == 2 ? 1 : 0;
+  if (!m->b_ups.empty() && m->b_ups[0].f16 == f16) return WETTS_OK;
+  for (auto& pc : m->b_ups) free_packed_bf16(&pc);
+  for (auto& v : m->b_c1) for (auto& pc : v) free_packed_bf16(&pc);
+  for (auto& v : m->b_c2) for (auto& pc : v) free_packed_bf16(&pc);
   const wetts_config_t* c = &m->cfg;
   const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
   m->b_ups.resize(c->n_upsamples);
@@ -1143,7 +1147,7 @@ static int32_t pack_decoder_bf16(const wetts_model* m, hipStream_t s) {
   for (int i = 0; i < c->n_upsamples; ++i) {
     const int u = c->upsample_rates[i], uk = c->upsample_kernel_sizes[i];
     WETTS_TRY(pack_conv_weight_bf16(m->T(S("dec.ups.%d.weight", i)), m->T(S("dec.ups.%d.bias", i)),
-                                    ch / 2, ch, uk, 1, (uk - u) / 2, 1, u, s, &m->b_ups[i]));
+                                    ch / 2, ch, uk, 1, (uk - u) / 2, 1, u, f16, s, &m->b_ups[i]));
     ch /= 2;
     for (int j = 0; j < nk; ++j) {
       const int n = i * nk + j, k = c->resblock_kernel_sizes[j];
@@ -1152,14 +1156,14 @@ static int32_t pack_decoder_bf16(const wetts_model* m, hipStream_t s) {
         if (c->resblock == 1) {
           WETTS_TRY(pack_conv_weight_bf16(m->T(S("dec.resblocks.%d.convs1.%d.weight", n, d)),
                                           m->T(S("dec.resblocks.%d.convs1.%d.bias", n, d)), ch, ch,
-                                          k, dil, (k * dil - dil) / 2, 0, 0, s, &m->b_c1[n][d]));
+                                          k, dil, (k * dil - dil) / 2, 0, 0, f16, s, &m->b_c1[n][d]));
           WETTS_TRY(pack_conv_weight_bf16(m->T(S("dec.resblocks.%d.convs2.%d.weight", n, d)),
                                           m->T(S("dec.resblocks.%d.convs2.%d.bias", n, d)), ch, ch,
-                                          k, 1, (k - 1) / 2, 0, 0, s, &m->b_c2[n][d]));
+                                          k, 1, (k - 1) / 2, 0, 0, f16, s, &m->b_c2[n][d]));
         } else {
           WETTS_TRY(pack_conv_weight_bf16(m->T(S("dec.resblocks.%d.convs.%d.weight", n, d)),
                                           m->T(S("dec.resblocks.%d.convs.%d.bias", n, d)), ch, ch,
-                                          k, dil, (k * dil - dil) / 2, 0, 0, s, &m->b_c1[n][d]));
+                                          k, dil, (k * dil - dil) / 2, 0, 0, f16, s, &m->b_c1[n][d]));
         }
       }
     }
@@ -1223,7 +1227,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
       p.bias_b_stride = C0;
     }
     WETTS_TRY(launch_conv(m->conv_pre, p, s));
-    WETTS_TRY(k_cf32_to_cl16(pre, bx, B, C0, L, s));
+    WETTS_TRY(k_cf32_to_cl16(pre, bx, B, C0, L, m->dec_precision == 2 ? 1 : 0, s));
   }
   int ch = C0, len = L;
   unsigned short* x = bx;
@@ -1278,14 +1282,14 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
     x = xsum;
   }
   if (m->mrf_timing) m->mrf_calls += 1;
-  return k_conv_post_bf16(x, m->conv_post_w, 7, B, ch, len, audio, s);
+  return k_conv_post_bf16(x, m->conv_post_w, 7, B, ch, len, audio, m->dec_precision == 2 ? 1 : 0, s);
 }
 }  // namespace wetts
 
 int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision) {
   WETTS_REQUIRE(m != nullptr, "null model");
-  WETTS_REQUIRE(precision == 0 || precision == 1, "precision must be 0 (f32) or 1 (bf16)");
-  if (precision == 1) {
+  WETTS_REQUIRE(precision >= 0 && precision <= 2, "precision must be 0 (f32), 1 (bf16) or 2 (f16)");
+  if (precision >= 1) {
     const wetts_config_t* c = &m->cfg;
     WETTS_REQUIRE((c->upsample_initial_channel >> c->n_upsamples) % 32 == 0,
                   "bf16 decoder needs every stage width to be a multiple of 32 channels");
@@ -1300,7 +1304,7 @@ int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_st
                       int64_t workspace_bytes, void* stream) {
   WETTS_REQUIRE(m && z && audio, "null argument");
   if (B == 0 || L == 0) return WETTS_OK;
-  if (m->dec_precision == 1)
+  if (m->dec_precision >= 1)
     return run_hifigan_bf16(m, z, z_batch_stride, z_channel_stride, y_mask, mask_stride, g, B, L,
                             audio, workspace, workspace_bytes, (hipStream_t)stream);
   return run_hifigan(m, z, z_batch_stride, z_channel_stride, y_mask, mask_stride, g, B, L, audio,

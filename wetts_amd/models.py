@@ -91,9 +91,10 @@ class SynthesizerTrn:
         return self.to("cuda" if device is None else device)
 
     def set_decoder_dtype(self, dtype):
-        """HiFi-GAN arithmetic: torch.float32 (default, parity-gated) or torch.bfloat16
-        (bf16 activations/weights, f32 accumulation; encoder / duration / flow stay f32)."""
-        prec = {torch.float32: 0, "f32": 0, "fp32": 0, torch.bfloat16: 1, "bf16": 1}[dtype]
+        """HiFi-GAN arithmetic: torch.float32 (default, parity-gated), torch.bfloat16 or
+        torch.float16 (16-bit activations/weights, f32 accumulation; encoder / duration / flow stay f32)."""
+        prec = {torch.float32: 0, "f32": 0, "fp32": 0, torch.bfloat16: 1, "bf16": 1,
+                torch.float16: 2, "f16": 2, "fp16": 2}[dtype]
         self._decoder_precision = prec
         if self._handle is not None:
             _lib.check(_lib.load().wetts_set_decoder_precision(self._handle, prec),
