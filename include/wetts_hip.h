@@ -186,7 +186,10 @@ int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_st
 /* Decoder arithmetic: 0 = float32 (default; exact-f32 MFMA, the parity-gated path),
  * 1 = bfloat16, 2 = IEEE half activations / weights with f32 accumulation (BASELINE.json
  * configs[2] / configs[4] precision; the text encoder, duration predictor and flow stay f32).  Weights are re-packed on
- * first use. */
+ * first use.  At 16 bit every ResBlock1 (c1, c2) pair with <= 128 channels runs as ONE fused
+ * kernel (intermediate kept in LDS); OR-ing WETTS_DECODER_UNFUSED into `precision` forces the
+ * two-launch form, which is bit-identical (diagnostics / tests). */
+#define WETTS_DECODER_UNFUSED 0x10
 int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision);
 
 /* a15 monotonic_align.maximum_path (utils/monotonic_align.py:6-57).  Needs no model.

@@ -200,3 +200,23 @@ def test_hifigan_bf16_mode_matches_its_numerics_spec(name):
     assert r_spec < 1e-2
     assert r_f32 < 6e-2
     assert util.rms(back - f32) < ABS_RMS_OURS  # switching back restores the exact-f32 path
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("L", [1, 37, 200])
+def test_fused_resblock_pair_bit_identical(dtype, L):
+    """The fused ResBlock1 kernel (resblock16.hip) performs the arithmetic of two conv launches in
+    the same order with the same rounding points: outputs must be EQUAL, including at tile seams
+    (L*hop spans several time tiles), sequence ends (zero padding of c2's input) and L=1."""
+    case = util.load_case("v1_b2")
+    net, cfg, W = _model(case)
+    torch.manual_seed(5)
+    z = torch.randn(2, cfg.inter_channels, L)
+    g = torch.nn.functional.embedding(util.t(case["sid"]), W["emb_g.weight"])
+    net.set_decoder_dtype(dtype, fused=True)
+    a = net.hifigan(z.cuda(), g.cuda()).cpu().numpy()
+    net.set_decoder_dtype(dtype, fused=False)
+    b = net.hifigan(z.cuda(), g.cuda()).cpu().numpy()
+    net.set_decoder_dtype(torch.float32)
+    assert a.shape == b.shape and np.isfinite(a).all()
+    assert np.array_equal(a, b), f"max |diff| {np.abs(a - b).max()}"

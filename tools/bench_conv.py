@@ -17,22 +17,29 @@ for C_, u in [(256, 8), (128, 8), (64, 2), (32, 2)]:
     for k in (3, 7, 11):
         shapes.append((C_, k, 1, L, 1 | 2))   # c2-style: lrelu + residual
         shapes.append((C_, k, 5, L, 1))       # c1-style: lrelu, dilation 5
+extra = int(os.environ.get("WETTS_CONV_FLAGS", "0"), 0)  # 16: bf16 decoder kernel, 32: f16
+esz = 2 if extra & 48 else 4
+pair = os.environ.get("WETTS_PAIR") == "1"  # ResBlock1 (c1 dil d, c2 dil 1) pairs: variants 32 / 16
+if pair:
+    shapes = [(c, k, d, L_, 1 | 2) for (c, k, _, L_, fl) in shapes if fl == 3 for d in (1, 3, 5)]
 only = os.environ.get("WETTS_SHAPES")
 if only:
     keep = {tuple(int(v) for v in it.split(":")) for it in only.split(",")}
     shapes = [sh for sh in shapes if (sh[0], sh[1]) in keep]
-print(f"{'shape':34s}" + "".join(f"  v{v:#x}: ms / TF/s   " for v in variants))
+print(f"{'shape':34s}" + "".join(f"  v{v:#06x}: ms TF/s GB/s  " for v in variants))
 for (ch, k, d, L, fl) in shapes:
     row = f"C={ch:3d} k={k:2d} d={d} L={L:6d} fl={fl}      "
     ref = None
     for v in variants:
         ms, cs = C.c_double(), C.c_double()
-        rc = lib.wetts_bench_conv(ch, ch, k, d, B, L, fl, v, 5, C.byref(ms), C.byref(cs))
+        rc = lib.wetts_bench_conv(ch, ch, k, d, B, L, fl | extra, v, 5, C.byref(ms), C.byref(cs))
         if rc != 0:
             row += f"  ERR {_lib.last_error()}"
             continue
-        tf = 2.0 * ch * ch * k * L * B / (ms.value * 1e-3) / 1e12
+        tf = (2 if pair else 1) * 2.0 * ch * ch * k * L * B / (ms.value * 1e-3) / 1e12
         same = "" if ref is None else (" =" if abs(cs.value - ref) <= 1e-6 * max(1, abs(ref)) else " !=")
         ref = cs.value if ref is None else ref
-        row += f"  {ms.value:8.3f} {tf:6.1f}{same:3s}"
+        ntens = 5 if pair else (2 + (1 if fl & 2 else 0))  # per-conv algorithmic accounting
+        gbs = ntens * ch * L * B * esz / (ms.value * 1e-3) / 1e9
+        row += f"  {ms.value:7.3f} {tf:6.1f} {gbs:5.0f}{same:3s}"
     print(row, flush=True)

@@ -1,0 +1,71 @@
+// Device-side helpers shared by the 16-bit decoder kernels (conv_bf16.hip, resblock16.hip):
+// storage conversions (bfloat16 / IEEE half <-> f32, round to nearest even) and the 32x32x16 MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wetts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+// 16-bit storage type selected at compile time: F16 = IEEE half, else bfloat16
+template <bool F16>
+__device__ __forceinline__ float cv_in(unsigned short h) {
+  if (F16) return (float)__builtin_bit_cast(_Float16, h);
+  return bf2f(h);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned short cv_out(float f) {
+  if (F16) return __builtin_bit_cast(unsigned short, (_Float16)f);
+  return f2bf(f);
+}
+// two f32 -> one packed dword (a in the low half); bf16 uses v_cvt_pk_bf16_f32 (RNE)
+template <bool F16>
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+  if (F16) {
+    // the values must exist as rounded f32 before the conversion: without this the compiler may
+    // fold the producing add/mul into v_fma_mixlo_f16 in one kernel and not in another, and the
+    // fused / unfused decoder paths would stop being bit-identical
+    asm volatile("" : "+v"(a), "+v"(b));
+    return (unsigned)cv_out<true>(a) | ((unsigned)cv_out<true>(b) << 16);
+  }
+  f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+template <bool F16>
+__device__ __forceinline__ float lo16(unsigned w) {
+  if (F16) return cv_in<true>((unsigned short)(w & 0xffffu));
+  return __uint_as_float(w << 16);
+}
+template <bool F16>
+__device__ __forceinline__ float hi16(unsigned w) {
+  if (F16) return cv_in<true>((unsigned short)(w >> 16));
+  return __uint_as_float(w & 0xffff0000u);
+}
+// leaky-relu of a packed pair, computed in f32 and rounded back (the 16-bit numerics spec)
+template <bool F16>
+__device__ __forceinline__ unsigned lrelu_pk(unsigned w, float slope) {
+  float a = lo16<F16>(w), c = hi16<F16>(w);
+  a = a > 0.f ? a : a * slope;
+  c = c > 0.f ? c : c * slope;
+  return pk2<F16>(a, c);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c) {
+  if (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+}  // namespace wetts

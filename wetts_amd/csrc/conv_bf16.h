@@ -5,7 +5,7 @@
 namespace wetts {
 
 struct PackedConvB {
-  unsigned short* wpk = nullptr;  // device, [ceil(M/128)*4][G][KS][64][8] bf16
+  unsigned short* wpk = nullptr;  // device, [ceil(M/128)*4][G][KS][64][8] 16-bit, m-block rows permuted (pack_bf16_kernel)
   const float* bias = nullptr;    // f32
   int M = 0, Cin = 0, Cout = 0, ktaps = 0, dil = 1, pad = 0, up = 0, up_pad = 0;
   int off_lo = 0, span = 0, nchunks = 0, CKB = 64;
@@ -30,7 +30,27 @@ struct ConvBParams {
   int accum;
   float out_div;
   int B;
+  int variant;  // microbench only: 8 = always allocate two LDS staging buffers
+  int ablate;   // microbench only (DBG instantiation)
 };
+
+// fused ResBlock1 pair (resblock16.hip): out = (x + c2(lrelu(c1(lrelu(x)))) [+ out]) / div
+constexpr int RESPAIR_MAX_SPAN = 64;  // (k-1)*dilation of c1 the fused kernel is sized for
+struct ResPairParams {
+  const unsigned short* x;  // [B][T][C] residual stream, channel-last
+  unsigned short* out;      // [B][T][C] (never aliases x)
+  const unsigned short *wpk1, *wpk2;
+  const float *bias1, *bias2;
+  int T, B;
+  int ktaps, dil;  // c1: ktaps taps at dilation dil; c2: ktaps taps at dilation 1
+  int accum;       // add the previous contents of out (running MRF sum)
+  float out_div;
+  float slope;     // leaky-relu slope in front of both convs
+  int ntiles, nblocks;
+};
+bool resblock_pair16_supported(const PackedConvB& c1, const PackedConvB& c2);
+int32_t launch_resblock_pair16(const PackedConvB& c1, const PackedConvB& c2, ResPairParams p,
+                               hipStream_t stream);
 
 int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
                               int dil, int pad, int transposed, int up, int f16, hipStream_t stream,

@@ -13,47 +13,13 @@
 //
 // Replaces, at reduced precision, the same reference code as conv_mfma.hip:
 // decoders.py:63-82,157-170,205-214 (ups / ResBlock convs / conv_post).
+#include <stdlib.h>
+
 #include "common.h"
 #include "conv_bf16.h"
+#include "conv16_dev.h"
 
 namespace wetts {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ unsigned pack2(float a, float b) {
-  return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
-}
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// 16-bit storage type selected at compile time: F16 = IEEE half, else bfloat16
-template <bool F16>
-__device__ __forceinline__ float cv_in(unsigned short h) {
-  if (F16) return (float)__builtin_bit_cast(_Float16, h);
-  return bf2f(h);
-}
-template <bool F16>
-__device__ __forceinline__ unsigned short cv_out(float f) {
-  if (F16) return __builtin_bit_cast(unsigned short, (_Float16)f);
-  return f2bf(f);
-}
-template <bool F16>
-__device__ __forceinline__ unsigned pk2(float a, float b) {
-  return (unsigned)cv_out<F16>(a) | ((unsigned)cv_out<F16>(b) << 16);
-}
-template <bool F16>
-__device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c) {
-  if (F16)
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
-                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
-                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 // ------------------------------------------------------------------------------------------
 // weight packing: [mt32][g = chunk*ktaps + tap][ks][lane][8 bf16]
@@ -77,7 +43,10 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __
   int mt32 = (int)(rest / G);
   int chunk = g / ktaps, tap = g % ktaps;
   int ci = chunk * CKB + ks * 16 + 8 * (lane >> 5) + e;
-  int row = mt32 * 32 + (lane & 31);
+  // row permutation: MFMA row rho = 8q+4h+e carries channel 16*(q>>1) + 8h + 4*(q&1) + e of the m-block, so
+  // one lane's 16 accumulator rows are two runs of 8 consecutive channels (16-byte stores)
+  const int rho = lane & 31, q = rho >> 3, h = (rho >> 2) & 1;
+  int row = mt32 * 32 + 16 * (q >> 1) + 8 * h + 4 * (q & 1) + (rho & 3);
   float v = 0.f;
   if (row < M && ci < Cin) {
     if (!transposed) {
@@ -128,7 +97,7 @@ void free_packed_bf16(PackedConvB* pc) {
 // ------------------------------------------------------------------------------------------
 // the conv kernel: 4 waves (WM x WN), each wave one 32-row m-block x NB 32-column n-blocks
 // ------------------------------------------------------------------------------------------
-template <int NB, int WM, int WN, int CKB, bool F16>
+template <int NB, int WM, int WN, int CKB, bool F16, bool DBG>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int MT = 32 * WM;
@@ -140,6 +109,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
 
+  const int ab = DBG ? p.ablate : 0;  // microbench ablation bits (DBG instantiation only)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,10 +140,11 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
     const int t = n0 + p.off_lo + row;
     urow[i] = row;
     uok[i] = (row < W) && (t >= 0) && (t < p.Tin);
+    if (DBG && (ab & 32)) uok[i] = false;
   }
   const int useg = tid % SEG;  // 256 % SEG == 0, so the piece index does not depend on i
-  uint4 st[MAXU];
-  auto load_chunk = [&](int c) {
+  uint4 st0[MAXU];
+  auto load_chunk = [&](int c, uint4* st) {
     const int c0 = c * CKB + useg * 8;
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) {
@@ -185,19 +156,14 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
   };
   const bool lrelu = p.in_act == IN_LRELU;
   const float slope = p.in_slope;
-  auto act2 = [&](unsigned w) -> unsigned {
-    float a = cv_in<F16>((unsigned short)(w & 0xffffu)), c2 = cv_in<F16>((unsigned short)(w >> 16));
-    a = a > 0.f ? a : a * slope;
-    c2 = c2 > 0.f ? c2 : c2 * slope;
-    return pk2<F16>(a, c2);
-  };
-  auto store_chunk = [&](unsigned char* buf) {
+  auto store_chunk = [&](unsigned char* buf, const uint4* st) {
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) {
       if (urow[i] < W) {
         uint4 v = st[i];
         if (lrelu) {
-          v.x = act2(v.x); v.y = act2(v.y); v.z = act2(v.z); v.w = act2(v.w);
+          v.x = lrelu_pk<F16>(v.x, slope); v.y = lrelu_pk<F16>(v.y, slope);
+          v.z = lrelu_pk<F16>(v.z, slope); v.w = lrelu_pk<F16>(v.w, slope);
         }
         *reinterpret_cast<uint4*>(buf + (size_t)urow[i] * RS + useg * 16) = v;
       }
@@ -221,29 +187,39 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
   const bool rows_ok = mrow_blk + 32 <= p.M;
 
   // residual / running sum folded into the accumulator init (plain convs only)
-  if (p.up == 0 && (p.res || p.accum) && rows_ok) {
+  if (p.up == 0 && (p.res || p.accum) && rows_ok && !(DBG && (ab & 2))) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int t = wcol0 + 32 * j + (lane & 31);
       if (t < p.N) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c = co_blk + 8 * q + 4 * half;
-          float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        for (int i = 0; i < 2; ++i) {
+          const int c = co_blk + 16 * i + 8 * half;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = 0.f;
           if (p.res) {
-            uint2 rr = *reinterpret_cast<const uint2*>(p.res + (int64_t)b * p.r_bs +
+            uint4 rr = *reinterpret_cast<const uint4*>(p.res + (int64_t)b * p.r_bs +
                                                        (int64_t)t * p.cout + c);
-            v0 = cv_in<F16>((unsigned short)(rr.x & 0xffffu)); v1 = cv_in<F16>((unsigned short)(rr.x >> 16));
-            v2 = cv_in<F16>((unsigned short)(rr.y & 0xffffu)); v3 = cv_in<F16>((unsigned short)(rr.y >> 16));
+            const unsigned w4[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] = cv_in<F16>((unsigned short)(w4[e] & 0xffffu));
+              v[2 * e + 1] = cv_in<F16>((unsigned short)(w4[e] >> 16));
+            }
           }
           if (p.accum) {
-            uint2 oo = *reinterpret_cast<const uint2*>(p.out + (int64_t)b * p.o_bs +
+            uint4 oo = *reinterpret_cast<const uint4*>(p.out + (int64_t)b * p.o_bs +
                                                        (int64_t)t * p.cout + c);
-            v0 += cv_in<F16>((unsigned short)(oo.x & 0xffffu)); v1 += cv_in<F16>((unsigned short)(oo.x >> 16));
-            v2 += cv_in<F16>((unsigned short)(oo.y & 0xffffu)); v3 += cv_in<F16>((unsigned short)(oo.y >> 16));
+            const unsigned w4[4] = {oo.x, oo.y, oo.z, oo.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] += cv_in<F16>((unsigned short)(w4[e] & 0xffffu));
+              v[2 * e + 1] += cv_in<F16>((unsigned short)(w4[e] >> 16));
+            }
           }
-          acc[j][4 * q + 0] = v0; acc[j][4 * q + 1] = v1;
-          acc[j][4 * q + 2] = v2; acc[j][4 * q + 3] = v3;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[j][8 * i + e] = v[e];
         }
       }
     }
@@ -259,8 +235,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
 #pragma unroll
   for (int s = 0; s < KS; ++s) aa[1][s] = aa[0][s];
 
-  load_chunk(0);
-  store_chunk(buf0);
+  load_chunk(0, st0);
+  store_chunk(buf0, st0);
   __syncthreads();
 
   const int brow0 = wn * (32 * NB) + (lane & 31) - p.pad - p.off_lo;
@@ -270,25 +246,27 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
     for (int par = 0; par < 2; ++par) {  // ping-pong A register sets, statically indexed
       const int gg = g + par;
       if (gg < G) {
-        if (gg + 1 < G) {
+        if (gg + 1 < G && !(DBG && (ab & 4))) {
 #pragma unroll
           for (int s = 0; s < KS; ++s) aa[par ^ 1][s] = abase[((int64_t)(gg + 1) * KS + s) * 64];
         }
-        if (tap == 0 && chunk + 1 < p.nchunks) load_chunk(chunk + 1);
+        if (tap == 0 && chunk + 1 < p.nchunks && !(DBG && (ab & 8))) load_chunk(chunk + 1, st0);
         const unsigned char* cur = (chunk & 1) ? buf1 : buf0;
         const unsigned char* bb = cur + (size_t)(brow0 + tap * p.dil) * RS + half * 16;
+        if (!(DBG && (ab & 16))) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const uint4 av = aa[par][s];
+          for (int s = 0; s < KS; ++s) {
+            const uint4 av = aa[par][s];
 #pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            const uint4 bw = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
-            acc[j] = mfma16<F16>(av, bw, acc[j]);
+            for (int j = 0; j < NB; ++j) {
+              const uint4 bw = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
+              acc[j] = mfma16<F16>(av, bw, acc[j]);
+            }
           }
         }
         if (++tap == p.ktaps) {
           tap = 0;
-          if (chunk + 1 < p.nchunks) store_chunk((chunk & 1) ? buf0 : buf1);
+          if (chunk + 1 < p.nchunks) store_chunk((chunk & 1) ? buf0 : buf1, st0);
           __syncthreads();
           ++chunk;
         }
@@ -296,14 +274,16 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
     }
   }
 
-  // ---- epilogue: + bias, / div, round to bf16, 8-byte channel-last stores ----------------------
+  // ---- epilogue: + bias, / div, round to 16 bit, channel-last stores ---------------------------
   if (!rows_ok) return;  // M is a multiple of 32 in every decoder conv; guard only
+  const bool dodiv = p.out_div != 1.f;
+  unsigned short* ob = p.out + (int64_t)b * p.o_bs;
+  const bool nostore = DBG && (ab & 1);
+  // lane rows = two runs of 8 consecutive channels (see pack_bf16_kernel) -> 16-byte stores
   float bia[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r)
-    bia[r] = p.bias ? p.bias[co_blk + (r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
-  const bool dodiv = p.out_div != 1.f;
-  unsigned short* ob = p.out + (int64_t)b * p.o_bs;
+    bia[r] = p.bias ? p.bias[co_blk + 16 * (r >> 3) + 8 * half + (r & 7)] : 0.f;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int col = wcol0 + 32 * j + (lane & 31);
@@ -314,16 +294,18 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
       if (t < 0 || t >= p.Tout) continue;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float v0 = acc[j][4 * q + 0] + bia[4 * q + 0];
-      float v1 = acc[j][4 * q + 1] + bia[4 * q + 1];
-      float v2 = acc[j][4 * q + 2] + bia[4 * q + 2];
-      float v3 = acc[j][4 * q + 3] + bia[4 * q + 3];
-      if (dodiv) { v0 = v0 / p.out_div; v1 = v1 / p.out_div; v2 = v2 / p.out_div; v3 = v3 / p.out_div; }
-      uint2 o;
-      o.x = pk2<F16>(v0, v1);
-      o.y = pk2<F16>(v2, v3);
-      *reinterpret_cast<uint2*>(ob + (int64_t)t * p.cout + co_blk + 8 * q + 4 * half) = o;
+    for (int i = 0; i < 2; ++i) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = acc[j][8 * i + e] + bia[8 * i + e];
+        if (dodiv) v[e] = v[e] / p.out_div;
+      }
+      uint4 o;
+      o.x = pk2<F16>(v[0], v[1]); o.y = pk2<F16>(v[2], v[3]);
+      o.z = pk2<F16>(v[4], v[5]); o.w = pk2<F16>(v[6], v[7]);
+      if (nostore && v[0] != 1.2345e30f) continue;
+      *reinterpret_cast<uint4*>(ob + (int64_t)t * p.cout + co_blk + 16 * i + 8 * half) = o;
     }
   }
 }
@@ -334,13 +316,16 @@ static int32_t launch_b(const ConvBParams& p, hipStream_t stream, bool f16) {
   int64_t blocks = (int64_t)cdiv(p.N, NT) * cdiv(p.M, MT) * p.B;
   if (blocks <= 0) return WETTS_OK;
   WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
-  size_t lds = (size_t)2 * (NT + p.span) * RS;
-  if (f16)
-    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true>), dim3((unsigned)blocks), dim3(256),
-                       lds, stream, p);
+  // one staging buffer is enough when the whole reduction is a single channel chunk
+  const int nbuf = (p.nchunks > 1 || (p.variant & 8)) ? 2 : 1;
+  size_t lds = (size_t)nbuf * (NT + p.span) * RS;
+  const dim3 grid((unsigned)blocks), blk(256);
+  if (p.ablate)  // microbench instrumentation (bf16 storage only)
+    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, true>), grid, blk, lds, stream, p);
+  else if (f16)
+    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, false>), grid, blk, lds, stream, p);
   else
-    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false>), dim3((unsigned)blocks),
-                       dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, false>), grid, blk, lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

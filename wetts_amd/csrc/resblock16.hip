@@ -1,0 +1,288 @@
+// Fused ResBlock1 pair for the 16-bit decoder:   out = (x + c2(lrelu(c1(lrelu(x)))) [+ out]) / div
+// (reference decoders.py:157-170, one (c1, c2) iteration of ResBlock1.forward) in ONE kernel.
+//
+// Unfused, a pair moves five tensors through HBM (x in, ft out, ft in, x again as the residual,
+// out) and the 16-bit convs at C <= 128 are then memory/latency bound (profiles/r01_conv16_*).
+// Here the block keeps the intermediate ft in LDS:
+//
+//   1. stage lrelu(x) for times [n0-h2-h1, n0-h2-h1 + NTC + 2*h1) as channel-last rows in LDS
+//      (h1 = (k-1)/2*d is c1's halo, h2 = (k-1)/2 is c2's; ALL C channels of a row, C <= 128)
+//   2. c1 on MFMA for the NTC columns t = n0-h2 .. (A fragments stream from L2, B from LDS)
+//   3. barrier; ft = lrelu(round16(c1 + b1)) is written over the x tile (zero outside [0,T):
+//      c2 pads ITS input with zeros); barrier
+//   4. c2 on MFMA for columns t' = n0 .. n0+NTC, accumulator initialised with the raw residual x
+//      (+ the running MRF sum); columns >= NTO = NTC - 2*h2 see a truncated ft window and are
+//      discarded, so consecutive blocks advance by NTO
+//   5. + b2, / div, round, 16-byte channel-last stores
+//
+// HBM traffic per pair: x once (+ halo, mostly L2 hits), the residual re-read (L2 hit) and out
+// once -- 2 tensor passes instead of 5.  Arithmetic (operation order, rounding points) is exactly
+// that of two conv_bf16_kernel launches, so the fused and unfused paths agree bit for bit
+// (tests/test_gpu_parity.py::test_fused_resblock_pair_bit_identical).
+#include "common.h"
+#include "conv_bf16.h"
+#include "conv16_dev.h"
+
+namespace wetts {
+
+template <int C, bool F16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void resblock_pair16_kernel(const ResPairParams p) {
+  constexpr int WM = C / 32, WN = 4 / WM, NB = 4;
+  constexpr int NTC = 32 * NB * WN;            // columns computed per conv
+  constexpr int CKB = C >= 64 ? 64 : 32;       // K chunk of the packed weights (pack_bf16_kernel)
+  constexpr int NCH = C / CKB, KS = CKB / 16;
+  constexpr int SEG = C / 8;                   // 16-byte pieces per row
+  constexpr int RS = C * 2 + 16;               // padded LDS row stride (bytes)
+  constexpr int MAXU = ((NTC + RESPAIR_MAX_SPAN) * SEG + 255) / 256;
+  static_assert(256 % SEG == 0, "piece index must not depend on the unit");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5;
+
+  const int h2 = (p.ktaps - 1) / 2, h1 = h2 * p.dil;
+  const int NTO = NTC - 2 * h2;
+  // XCD-aware tile order: the 8 XCDs take blocks round-robin, so give each XCD a contiguous run
+  // of time tiles (neighbours share their halo rows through that XCD's L2)
+  int bid = blockIdx.x;
+  {
+    const int per = (p.nblocks + 7) >> 3;
+    bid = (bid & 7) * per + (bid >> 3);
+    if (bid >= p.nblocks) return;
+  }
+  const int ntile = bid % p.ntiles;
+  const int b = bid / p.ntiles;
+  const int n0 = ntile * NTO;
+  const int W1 = NTC + 2 * h1;
+  const int tx0 = n0 - h2 - h1;  // time of LDS row 0 of the x tile
+
+  const unsigned short* xb = p.x + (int64_t)b * p.T * C;
+
+  // ---- A streams -----------------------------------------------------------------------------
+  const int G = NCH * p.ktaps;
+  const uint4* abase1 = reinterpret_cast<const uint4*>(p.wpk1) + ((int64_t)wm * G * KS) * 64 + lane;
+  const uint4* abase2 = reinterpret_cast<const uint4*>(p.wpk2) + ((int64_t)wm * G * KS) * 64 + lane;
+  uint4 aa[2][KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) aa[0][s] = abase1[s * 64];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) aa[1][s] = aa[0][s];
+
+  // ---- 1. stage lrelu(x) ---------------------------------------------------------------------
+  {
+    const int useg = tid % SEG;
+    uint4 st[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+      const int row = (tid + 256 * i) / SEG;
+      const int t = tx0 + row;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (row < W1 && t >= 0 && t < p.T)
+        v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + useg * 8);
+      st[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+      const int row = (tid + 256 * i) / SEG;
+      if (row < W1) {
+        uint4 v = st[i];
+        v.x = lrelu_pk<F16>(v.x, p.slope); v.y = lrelu_pk<F16>(v.y, p.slope);
+        v.z = lrelu_pk<F16>(v.z, p.slope); v.w = lrelu_pk<F16>(v.w, p.slope);
+        *reinterpret_cast<uint4*>(smem_r + (size_t)row * RS + useg * 16) = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int co_blk = wm * 32;
+  const int wcol = wn * (32 * NB) + (lane & 31);  // this lane's column of n-block 0
+  const unsigned char* bcol = smem_r + (size_t)wcol * RS + half * 16;
+
+  // one conv over the LDS tile: groups g = chunk*ktaps + tap, ping-pong A registers
+  auto conv_loop = [&](const uint4* abase, int dil) {
+    int chunk = 0, tap = 0;
+    for (int g = 0; g < G; g += 2) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int gg = g + par;
+        if (gg < G) {
+          if (gg + 1 < G) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) aa[par ^ 1][s] = abase[((int64_t)(gg + 1) * KS + s) * 64];
+          }
+          const unsigned char* bb = bcol + (size_t)(tap * dil) * RS + chunk * (CKB * 2);
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            const uint4 av = aa[par][s];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+              const uint4 bw = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
+              acc[j] = mfma16<F16>(av, bw, acc[j]);
+            }
+          }
+          if (++tap == p.ktaps) { tap = 0; ++chunk; }
+        }
+      }
+    }
+  };
+
+  // ---- 2. c1 ---------------------------------------------------------------------------------
+  conv_loop(abase1, p.dil);
+
+  // c2's first A group and the raw residual are requested now; they land during step 3
+#pragma unroll
+  for (int s = 0; s < KS; ++s) aa[0][s] = abase2[s * 64];
+  uint4 rres[NB][2];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int col = wcol + 32 * j;
+    const int t = n0 + col;
+    const bool ok = col < NTO && t < p.T;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (ok) v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + co_blk + 16 * i + 8 * half);
+      rres[j][i] = v;
+    }
+  }
+
+  // ---- 3. ft = lrelu(round16(c1 + b1)) over the x tile ----------------------------------------
+  {
+    float bia[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bia[r] = p.bias1[co_blk + 16 * (r >> 3) + 8 * half + (r & 7)];
+    __syncthreads();  // every wave has finished reading lrelu(x)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int col = wcol + 32 * j;
+      const int t = n0 - h2 + col;
+      const bool inside = t >= 0 && t < p.T;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned r16 = pk2<F16>(acc[j][8 * i + 2 * e] + bia[8 * i + 2 * e],
+                                        acc[j][8 * i + 2 * e + 1] + bia[8 * i + 2 * e + 1]);
+          w[e] = inside ? lrelu_pk<F16>(r16, p.slope) : 0u;
+        }
+        *reinterpret_cast<uint4*>(smem_r + (size_t)col * RS + (co_blk + 16 * i + 8 * half) * 2) =
+            make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- 4. c2, accumulator = residual (+ running sum) -------------------------------------------
+  unsigned short* ob = p.out + (int64_t)b * p.T * C;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int col = wcol + 32 * j;
+    const int t = n0 + col;
+    const bool ok = col < NTO && t < p.T;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned w4[4] = {rres[j][i].x, rres[j][i].y, rres[j][i].z, rres[j][i].w};
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] = lo16<F16>(w4[e]);
+        v[2 * e + 1] = hi16<F16>(w4[e]);
+      }
+      if (p.accum && ok) {
+        const uint4 oo = *reinterpret_cast<const uint4*>(ob + (int64_t)t * C + co_blk + 16 * i + 8 * half);
+        const unsigned o4[4] = {oo.x, oo.y, oo.z, oo.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] += lo16<F16>(o4[e]);
+          v[2 * e + 1] += hi16<F16>(o4[e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[j][8 * i + e] = v[e];
+    }
+  }
+  conv_loop(abase2, 1);
+
+  // ---- 5. epilogue -----------------------------------------------------------------------------
+  float bia[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bia[r] = p.bias2[co_blk + 16 * (r >> 3) + 8 * half + (r & 7)];
+  const bool dodiv = p.out_div != 1.f;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int col = wcol + 32 * j;
+    const int t = n0 + col;
+    if (col >= NTO || t >= p.T) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = acc[j][8 * i + e] + bia[8 * i + e];
+        if (dodiv) v[e] = v[e] / p.out_div;
+      }
+      uint4 o;
+      o.x = pk2<F16>(v[0], v[1]); o.y = pk2<F16>(v[2], v[3]);
+      o.z = pk2<F16>(v[4], v[5]); o.w = pk2<F16>(v[6], v[7]);
+      *reinterpret_cast<uint4*>(ob + (int64_t)t * C + co_blk + 16 * i + 8 * half) = o;
+    }
+  }
+}
+
+template <int C>
+static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream) {
+  constexpr int WM = C / 32, WN = 4 / WM, NTC = 128 * WN, RS = C * 2 + 16;
+  ResPairParams p = p0;
+  const int h2 = (p.ktaps - 1) / 2, h1 = h2 * p.dil;
+  const int NTO = NTC - 2 * h2;
+  p.ntiles = cdiv(p.T, NTO);
+  const int64_t nb = (int64_t)p.ntiles * p.B;
+  if (nb <= 0) return WETTS_OK;
+  WETTS_REQUIRE(nb < (1ll << 30), "resblock grid too large");
+  p.nblocks = (int)nb;
+  const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);
+  const size_t lds = (size_t)(NTC + 2 * h1) * RS;
+  if (f16)
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, true>), dim3(grid), dim3(256), lds, stream, p);
+  else
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, false>), dim3(grid), dim3(256), lds, stream, p);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+bool resblock_pair16_supported(const PackedConvB& c1, const PackedConvB& c2) {
+  const int C = c1.Cin;
+  if (!(C == 32 || C == 64 || C == 128)) return false;
+  if (c1.Cout != C || c2.Cin != C || c2.Cout != C || c1.up || c2.up) return false;
+  if (c1.ktaps != c2.ktaps || (c1.ktaps & 1) == 0 || c2.dil != 1 || c1.f16 != c2.f16) return false;
+  if (c1.pad != (c1.ktaps - 1) / 2 * c1.dil || c2.pad != (c2.ktaps - 1) / 2) return false;
+  return (c1.ktaps - 1) * c1.dil <= RESPAIR_MAX_SPAN;
+}
+
+int32_t launch_resblock_pair16(const PackedConvB& c1, const PackedConvB& c2, ResPairParams p,
+                               hipStream_t stream) {
+  WETTS_REQUIRE(resblock_pair16_supported(c1, c2), "resblock pair shape not supported by the fused kernel");
+  WETTS_REQUIRE(c1.wpk && c2.wpk, "16-bit conv weight not packed");
+  p.wpk1 = c1.wpk; p.bias1 = c1.bias;
+  p.wpk2 = c2.wpk; p.bias2 = c2.bias;
+  p.ktaps = c1.ktaps;
+  p.dil = c1.dil;
+  switch (c1.Cin) {
+    case 32: return launch_pair<32>(p, c1.f16 != 0, stream);
+    case 64: return launch_pair<64>(p, c1.f16 != 0, stream);
+    default: return launch_pair<128>(p, c1.f16 != 0, stream);
+  }
+}
+
+}  // namespace wetts

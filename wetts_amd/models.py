@@ -90,11 +90,15 @@ class SynthesizerTrn:
     def cuda(self, device=None):
         return self.to("cuda" if device is None else device)
 
-    def set_decoder_dtype(self, dtype):
+    def set_decoder_dtype(self, dtype, fused=True):
         """HiFi-GAN arithmetic: torch.float32 (default, parity-gated), torch.bfloat16 or
-        torch.float16 (16-bit activations/weights, f32 accumulation; encoder / duration / flow stay f32)."""
+        torch.float16 (16-bit activations/weights, f32 accumulation; encoder / duration / flow stay f32).
+        `fused=False` runs every ResBlock1 (c1, c2) pair as two conv launches instead of the fused
+        LDS-resident kernel -- bit-identical, for diagnostics."""
         prec = {torch.float32: 0, "f32": 0, "fp32": 0, torch.bfloat16: 1, "bf16": 1,
                 torch.float16: 2, "f16": 2, "fp16": 2}[dtype]
+        if prec and not fused:
+            prec |= 0x10  # WETTS_DECODER_UNFUSED
         self._decoder_precision = prec
         if self._handle is not None:
             _lib.check(_lib.load().wetts_set_decoder_precision(self._handle, prec),
