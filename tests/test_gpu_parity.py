@@ -202,11 +202,12 @@ def test_hifigan_bf16_mode_matches_its_numerics_spec(name):
     assert util.rms(back - f32) < ABS_RMS_OURS  # switching back restores the exact-f32 path
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("L", [1, 37, 200])
 def test_fused_resblock_pair_bit_identical(dtype, L):
-    """The fused ResBlock1 kernel (resblock16.hip) performs the arithmetic of two conv launches in
-    the same order with the same rounding points: outputs must be EQUAL, including at tile seams
+    """The fused ResBlock1 kernels (resblock32.hip at f32, resblock16.hip at 16 bit) perform the
+    arithmetic of two conv launches in the same order with the same rounding points: outputs must
+    be EQUAL, including at tile seams
     (L*hop spans several time tiles), sequence ends (zero padding of c2's input) and L=1."""
     case = util.load_case("v1_b2")
     net, cfg, W = _model(case)

@@ -45,16 +45,25 @@ for k in sorted(f, key=lambda k: -sum(f[k])):
         ent["calls_in_stats_run"] = int(stats[k]["Calls"])
     out["kernels"][k] = ent
     # dominant kernel class: the MRF-shaped conv instantiations (plain / mean epilogue)
+    # plus the fused f32 ResBlock pair kernel that replaces two of them
     mm = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), \w+, \w+, (\d+)", k)
-    if mm and mm.group(5) in ("1", "2") and mm.group(1, 2, 3, 4) != ("1", "1", "2", "2"):
+    is_dom = (mm and mm.group(5) in ("1", "2") and mm.group(1, 2, 3, 4) != ("1", "1", "2", "2")) \
+        or "resblock_pair32_kernel" in k
+    if is_dom:
         dom["launches"] += n
         dom["fetch_kb"] += sum(f[k])
         dom["write_kb"] += sum(w.get(k, [0]))
+        if k in stats:
+            dom["stat_calls"] = dom.get("stat_calls", 0) + int(stats[k]["Calls"])
+            dom["stat_ns"] = dom.get("stat_ns", 0.0) + float(stats[k]["TotalDurationNs"])
 out["dominant_conv_mfma"] = {
     "launches": dom["launches"],
     "hbm_bytes_per_launch": (2 * dom["fetch_kb"] + dom["write_kb"]) * 1024 / max(1, dom["launches"]),
     "raw_fetch_bytes_per_launch": dom["fetch_kb"] * 1024 / max(1, dom["launches"]),
     "write_bytes_per_launch": dom["write_kb"] * 1024 / max(1, dom["launches"]),
+    # rocprofv3 --stats view of the same class (compare with bench.py roofline.avg_launch_ms)
+    "rocprof_avg_duration_ms": dom.get("stat_ns", 0.0) / max(1, dom.get("stat_calls", 0)) / 1e6,
+    "rocprof_calls": dom.get("stat_calls", 0),
 }
 json.dump(out, open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)
 print(json.dumps(out["dominant_conv_mfma"], indent=1))

@@ -47,6 +47,8 @@ struct ResPairParams {
   float out_div;
   float slope;     // leaky-relu slope in front of both convs
   int ntiles, nblocks;
+  int ablate;      // microbench only (DBG instantiation): 1 no stores, 2 no residual loads, 4 no A
+                   // loads, 8 no x loads, 16 no MFMA / B reads, 32 no lrelu in staging
 };
 bool resblock_pair16_supported(const PackedConvB& c1, const PackedConvB& c2);
 int32_t launch_resblock_pair16(const PackedConvB& c1, const PackedConvB& c2, ResPairParams p,

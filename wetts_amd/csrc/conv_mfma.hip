@@ -317,16 +317,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
           if (hp == 0) {
 #pragma unroll
             for (int i = 0; i < MB; ++i) a_cur[i] = a_nxt[i];
-            if (g < G && !(OPT & 4)) {
+            // unconditional (group G exists: next m-block / zero tail): a conditional load makes
+            // the compiler's waitcnt insertion assume it may not be pending and emit vmcnt(0)
+            if (!(OPT & 4)) {
 #pragma unroll
               for (int i = 0; i < MB; ++i) a_alt[i] = abase[i][(int64_t)g * 64];
+              __builtin_amdgcn_sched_barrier(0);  // keep the prefetch a whole group ahead of its use
             }
           } else {
 #pragma unroll
             for (int i = 0; i < MB; ++i) a_cur[i] = a_alt[i];
-            if (g < G && !(OPT & 4)) {
+            if (!(OPT & 4)) {
 #pragma unroll
               for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][(int64_t)g * 64];
+              __builtin_amdgcn_sched_barrier(0);
             }
           }
         } else {

@@ -11,6 +11,7 @@
 
 #include "common.h"
 #include "conv_bf16.h"
+#include "resblock32.h"
 #include "kernels.h"
 
 namespace wetts {
@@ -295,6 +296,8 @@ struct wetts_model {
   // bf16 decoder (opt-in, wetts_set_decoder_precision): weights packed on first use
   mutable int dec_precision = 0;  // 0 = f32, 1 = bf16, 2 = f16
   mutable int dec_unfused = 0;    // diagnostic: run ResBlock1 pairs as two conv launches
+  int fuse32_lds = 160 * 1024;    // largest f32 pair tile run fused (WETTS_FUSE32_LDS, bytes)
+  int fuse32_kmax128 = 11;        // C>=128 pairs with this many taps or more stay unfused
   mutable std::vector<PackedConvB> b_ups;
   mutable std::vector<std::vector<PackedConvB>> b_c1, b_c2;  // per resblock
   int mrf_streams = 1;
@@ -614,6 +617,10 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     m->mrf_streams = env ? atoi(env) : 1;  // opt-in: +2 % at cfg 2, but kernels then overlap in profiles
     if (m->mrf_streams < 1) m->mrf_streams = 1;
     if (m->mrf_streams > cfg->n_resblock_kernels) m->mrf_streams = cfg->n_resblock_kernels;
+    const char* fl = getenv("WETTS_FUSE32_LDS");  // experiment knob: f32 pair tiles above this run unfused
+    if (fl) m->fuse32_lds = atoi(fl);
+    const char* fk = getenv("WETTS_FUSE32_KMAX128");
+    if (fk) m->fuse32_kmax128 = atoi(fk);
     (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
     for (int j = 0; j < cfg->n_resblock_kernels; ++j) {
       (void)hipEventCreateWithFlags(&m->ev_chain[j], hipEventDisableTiming);
@@ -1073,7 +1080,28 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
         } else {
           outp = (rx == fa) ? fb : fa;
         }
-        if (c->resblock == 1) {
+        // fused wherever it measures faster (profiles/r01_conv32_fused_pair.txt): everything but
+        // the MFMA-bound C=128, k=11 pairs, whose 2*(k-1)/2 discarded columns per 128 outweigh
+        // the gain
+        const bool fuse32 = c->resblock == 1 && !m->dec_unfused &&
+                            resblock_pair32_supported(rb.c1[d], rb.c2[d], m->fuse32_lds) &&
+                            !(ch >= 128 && rb.c1[d].ktaps >= m->fuse32_kmax128);
+        if (fuse32) {
+          // x = x + c2(lrelu(c1(lrelu(x)))) in one kernel (intermediate in LDS)
+          if (forked && last_d && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
+          ResPair32Params pp;
+          memset(&pp, 0, sizeof(pp));
+          pp.x = rx;
+          pp.out = outp;
+          pp.T = len;
+          pp.B = B;
+          pp.accum = accum;
+          pp.out_div = odiv;
+          pp.slope = 0.1f;
+          WETTS_TRY(launch_resblock_pair32(rb.c1[d], rb.c2[d], pp, sj));
+          if (tm && tm->on) tm->launches += 1;
+          if (m->mrf_timing) m->mrf_launches += 1;
+        } else if (c->resblock == 1) {
           // xt = c1(lrelu(x)); x = c2(lrelu(xt)) + x
           ConvParams p1 = conv_io(rx, ch, len, ft, ch, B);
           p1.in_act = IN_LRELU;
@@ -1091,6 +1119,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           p2.out_div = odiv;
           WETTS_TRY(launch_conv(rb.c2[d], p2, sj));
           if (tm && tm->on) tm->launches += 2;
+          if (m->mrf_timing) m->mrf_launches += 2;
         } else {
           // x = c(lrelu(x)) + x
           if (forked && last_d && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
@@ -1104,6 +1133,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           p1.out_div = odiv;
           WETTS_TRY(launch_conv(rb.c1[d], p1, sj));
           if (tm && tm->on) tm->launches += 1;
+          if (m->mrf_timing) m->mrf_launches += 1;
         }
         rx = outp;
       }
@@ -1114,7 +1144,6 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
     if (m->mrf_timing) {
       WETTS_HIP_CHECK(hipEventRecord(lv1, s));
       m->mrf_events.emplace_back(lv0, lv1);
-      m->mrf_launches += (int64_t)nk * nd * (c->resblock == 1 ? 2 : 1);
     }
     if (tm && tm->on) {
       WETTS_HIP_CHECK(hipEventRecord(tm->e1, s));
@@ -1455,6 +1484,7 @@ static int32_t bench_conv_16bit(int32_t Cin, int32_t Cout, int32_t k, int32_t di
         memset(&pp, 0, sizeof(pp));
         pp.x = x; pp.out = o; pp.T = T; pp.B = B; pp.accum = (flags & 4) ? 1 : 0;
         pp.out_div = (flags & 8) ? 3.f : 1.f; pp.slope = 0.1f;
+        pp.ablate = variant >> 8;
         return launch_resblock_pair16(pc, pc2, pp, s);
       }
       ConvBParams p1;
@@ -1571,6 +1601,63 @@ int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int3
   WETTS_HIP_CHECK(hipMemsetAsync(o, 0, no * 4, s));
   PackedConv pc;
   WETTS_TRY(pack_conv_weight(w, bias, Cout, Cin, k, dil, (k * dil - dil) / 2, 0, 0, s, &pc));
+  if (variant & 48) {  // ResBlock1 pair: 16 = fused kernel, 32 = two conv launches
+    WETTS_REQUIRE(Cin == Cout, "pair bench needs Cin == Cout");
+    PackedConv pc2;
+    float *w2 = nullptr, *ft = nullptr;
+    WETTS_HIP_CHECK(hipMalloc((void**)&w2, nw * 4));
+    WETTS_HIP_CHECK(hipMalloc((void**)&ft, no * 4));
+    WETTS_TRY(fill_pseudo(w2, nw, 5, 1.f / sqrtf((float)Cin * k), s));
+    WETTS_TRY(pack_conv_weight(w2, bias, Cout, Cin, k, 1, (k - 1) / 2, 0, 0, s, &pc2));
+    auto run = [&]() -> int32_t {
+      if (variant & 16) {
+        ResPair32Params pp;
+        memset(&pp, 0, sizeof(pp));
+        pp.x = x; pp.out = o; pp.T = T; pp.B = B; pp.accum = (flags & 4) ? 1 : 0;
+        pp.out_div = (flags & 8) ? 3.f : 1.f; pp.slope = 0.1f;
+        pp.ablate = variant >> 8;
+        return launch_resblock_pair32(pc, pc2, pp, s);
+      }
+      ConvParams p1 = conv_io(x, Cin, T, ft, Cout, B);
+      p1.in_act = IN_LRELU; p1.in_slope = 0.1f;
+      int32_t rc1 = launch_conv(pc, p1, s);
+      if (rc1 != WETTS_OK) return rc1;
+      ConvParams p2 = conv_io(ft, Cin, T, o, Cout, B);
+      p2.in_act = IN_LRELU; p2.in_slope = 0.1f;
+      p2.res = x; p2.r_bs = (int64_t)Cout * T; p2.r_cs = T;
+      p2.accum = (flags & 4) ? 1 : 0;
+      p2.out_div = (flags & 8) ? 3.f : 1.f;
+      return launch_conv(pc2, p2, s);
+    };
+    int32_t rc = WETTS_OK;
+    for (int i = 0; i < 2 && rc == WETTS_OK; ++i) rc = run();
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters && rc == WETTS_OK; ++i) rc = run();
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / iters;
+    if (checksum_out && rc == WETTS_OK) {  // full-tensor hash of ONE application on a known `out`
+      (void)hipMemcpyAsync(o, r, no * 4, hipMemcpyDeviceToDevice, s);
+      rc = run();
+      std::vector<uint32_t> host((size_t)no);
+      (void)hipMemcpy(host.data(), o, host.size() * 4, hipMemcpyDeviceToHost);
+      uint64_t hsh = 1469598103934665603ull;
+      for (size_t i = 0; i < host.size(); ++i) hsh = (hsh ^ host[i]) * 1099511628211ull;
+      *checksum_out = (double)(hsh >> 12);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    free_packed(&pc);
+    free_packed(&pc2);
+    (void)hipFree(x); (void)hipFree(o); (void)hipFree(r); (void)hipFree(w); (void)hipFree(w2);
+    (void)hipFree(ft); (void)hipFree(bias);
+    return rc;
+  }
   ConvParams p = conv_io(x, Cin, T, o, Cout, B);
   if (flags & 1) { p.in_act = IN_LRELU; p.in_slope = 0.1f; }
   if (flags & 2) { p.res = r; p.r_bs = (int64_t)Cout * T; p.r_cs = T; }

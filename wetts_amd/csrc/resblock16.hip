@@ -25,8 +25,12 @@
 
 namespace wetts {
 
-template <int C, bool F16>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void resblock_pair16_kernel(const ResPairParams p) {
+// NR = depth of the A-fragment register ring in (chunk, tap) groups: the fragments of group g+NR-1
+// are requested while group g computes, which has to cover a loaded L2 round trip (~1-2 us);
+// OCC = waves per SIMD the register allocation is held to.
+template <int C, bool F16, int NR, int OCC, bool DBG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
+void resblock_pair16_kernel(const ResPairParams p) {
   constexpr int WM = C / 32, WN = 4 / WM, NB = 4;
   constexpr int NTC = 32 * NB * WN;            // columns computed per conv
   constexpr int CKB = C >= 64 ? 64 : 32;       // K chunk of the packed weights (pack_bf16_kernel)
@@ -38,6 +42,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
 
+  const int ab = DBG ? p.ablate : 0;  // microbench ablation bits
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,11 +71,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int G = NCH * p.ktaps;
   const uint4* abase1 = reinterpret_cast<const uint4*>(p.wpk1) + ((int64_t)wm * G * KS) * 64 + lane;
   const uint4* abase2 = reinterpret_cast<const uint4*>(p.wpk2) + ((int64_t)wm * G * KS) * 64 + lane;
-  uint4 aa[2][KS];
+  uint4 aa[NR][KS];
+  auto a_prologue = [&](const uint4* abase) {  // groups 0 .. NR-2 in flight
 #pragma unroll
-  for (int s = 0; s < KS; ++s) aa[0][s] = abase1[s * 64];
+    for (int r = 0; r < NR - 1; ++r)
 #pragma unroll
-  for (int s = 0; s < KS; ++s) aa[1][s] = aa[0][s];
+      for (int s = 0; s < KS; ++s)
+        aa[r][s] = abase[((int64_t)(r < G ? r : 0) * KS + s) * 64];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) aa[NR - 1][s] = aa[0][s];
+  };
+  a_prologue(abase1);
 
   // ---- 1. stage lrelu(x) ---------------------------------------------------------------------
   {
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const int row = (tid + 256 * i) / SEG;
       const int t = tx0 + row;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (row < W1 && t >= 0 && t < p.T)
+      if (row < W1 && t >= 0 && t < p.T && !(DBG && (ab & 8)))
         v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + useg * 8);
       st[i] = v;
     }
@@ -90,8 +101,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const int row = (tid + 256 * i) / SEG;
       if (row < W1) {
         uint4 v = st[i];
+        if (!(DBG && (ab & 32))) {
         v.x = lrelu_pk<F16>(v.x, p.slope); v.y = lrelu_pk<F16>(v.y, p.slope);
         v.z = lrelu_pk<F16>(v.z, p.slope); v.w = lrelu_pk<F16>(v.w, p.slope);
+        }
         *reinterpret_cast<uint4*>(smem_r + (size_t)row * RS + useg * 16) = v;
       }
     }
@@ -108,30 +121,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int wcol = wn * (32 * NB) + (lane & 31);  // this lane's column of n-block 0
   const unsigned char* bcol = smem_r + (size_t)wcol * RS + half * 16;
 
-  // one conv over the LDS tile: groups g = chunk*ktaps + tap, ping-pong A registers
-  auto conv_loop = [&](const uint4* abase, int dil) {
-    int chunk = 0, tap = 0;
-    for (int g = 0; g < G; g += 2) {
+  // one conv over the LDS tile: groups g = chunk*ktaps + tap, A fragments from the register ring.
+  // The prefetch of group g+NR-1 is issued UNCONDITIONALLY (index clamped to the last group):
+  // a conditional load makes the compiler's s_waitcnt insertion assume it may not be pending, and
+  // the vmcnt it then emits also waits for the load just issued -- i.e. a full L2 round trip per
+  // group.  Straight-line issue gives exact counts (vmcnt((NR-1)*KS) ... ).
+  auto mma_group = [&](const uint4* av, int tap, int chunk, int dil) {
+    const unsigned char* bb = bcol + (size_t)(tap * dil) * RS + chunk * (CKB * 2);
+    if (!(DBG && (ab & 16)))
 #pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        const int gg = g + par;
-        if (gg < G) {
-          if (gg + 1 < G) {
+      for (int s = 0; s < KS; ++s) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) aa[par ^ 1][s] = abase[((int64_t)(gg + 1) * KS + s) * 64];
-          }
-          const unsigned char* bb = bcol + (size_t)(tap * dil) * RS + chunk * (CKB * 2);
-#pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            const uint4 av = aa[par][s];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-              const uint4 bw = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
-              acc[j] = mfma16<F16>(av, bw, acc[j]);
-            }
-          }
-          if (++tap == p.ktaps) { tap = 0; ++chunk; }
+        for (int j = 0; j < NB; ++j) {
+          const uint4 bw = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
+          acc[j] = mfma16<F16>(av[s], bw, acc[j]);
         }
+      }
+  };
+  auto conv_loop = [&](const uint4* abase, int dil) {
+    int chunk = 0, tap = 0, g = 0;
+    for (; g + NR <= G; g += NR) {
+#pragma unroll
+      for (int par = 0; par < NR; ++par) {
+        int gn = g + par + NR - 1;
+        gn = gn < G ? gn : G - 1;
+        if (!(DBG && (ab & 4))) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) aa[(par + NR - 1) % NR][s] = abase[((int64_t)gn * KS + s) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch at the top of its group
+        mma_group(aa[par], tap, chunk, dil);
+        if (++tap == p.ktaps) { tap = 0; ++chunk; }
+      }
+    }
+#pragma unroll
+    for (int par = 0; par < NR - 1; ++par) {  // tail: fewer than NR groups left, all in the ring
+      if (g + par < G) {
+        mma_group(aa[par], tap, chunk, dil);
+        if (++tap == p.ktaps) { tap = 0; ++chunk; }
       }
     }
   };
@@ -139,15 +166,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // ---- 2. c1 ---------------------------------------------------------------------------------
   conv_loop(abase1, p.dil);
 
-  // c2's first A group and the raw residual are requested now; they land during step 3
-#pragma unroll
-  for (int s = 0; s < KS; ++s) aa[0][s] = abase2[s * 64];
+  // c2's first A groups and the raw residual are requested now; they land during step 3
+  a_prologue(abase2);
   uint4 rres[NB][2];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int col = wcol + 32 * j;
     const int t = n0 + col;
-    const bool ok = col < NTO && t < p.T;
+    const bool ok = col < NTO && t < p.T && !(DBG && (ab & 2));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -235,12 +261,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       uint4 o;
       o.x = pk2<F16>(v[0], v[1]); o.y = pk2<F16>(v[2], v[3]);
       o.z = pk2<F16>(v[4], v[5]); o.w = pk2<F16>(v[6], v[7]);
+      if (DBG && (ab & 1) && v[0] != 1.2345e30f) continue;
       *reinterpret_cast<uint4*>(ob + (int64_t)t * C + co_blk + 16 * i + 8 * half) = o;
     }
   }
 }
 
-template <int C>
+template <int C, int NR, int OCC>
 static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream) {
   constexpr int WM = C / 32, WN = 4 / WM, NTC = 128 * WN, RS = C * 2 + 16;
   ResPairParams p = p0;
@@ -253,10 +280,12 @@ static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream
   p.nblocks = (int)nb;
   const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);
   const size_t lds = (size_t)(NTC + 2 * h1) * RS;
-  if (f16)
-    hipLaunchKernelGGL((resblock_pair16_kernel<C, true>), dim3(grid), dim3(256), lds, stream, p);
+  if (p.ablate)  // microbench instrumentation (bf16 storage only)
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, false, NR, OCC, true>), dim3(grid), dim3(256), lds, stream, p);
+  else if (f16)
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, true, NR, OCC, false>), dim3(grid), dim3(256), lds, stream, p);
   else
-    hipLaunchKernelGGL((resblock_pair16_kernel<C, false>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, false, NR, OCC, false>), dim3(grid), dim3(256), lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -278,10 +307,13 @@ int32_t launch_resblock_pair16(const PackedConvB& c1, const PackedConvB& c2, Res
   p.wpk2 = c2.wpk; p.bias2 = c2.bias;
   p.ktaps = c1.ktaps;
   p.dil = c1.dil;
+  const bool h = c1.f16 != 0;
+  // ring depth 2 at 3 waves/SIMD measured best (profiles/r01_conv16_fused_pair.txt: deeper rings
+  // cost occupancy or issue slots and lose 5-15 %)
   switch (c1.Cin) {
-    case 32: return launch_pair<32>(p, c1.f16 != 0, stream);
-    case 64: return launch_pair<64>(p, c1.f16 != 0, stream);
-    default: return launch_pair<128>(p, c1.f16 != 0, stream);
+    case 32: return launch_pair<32, 2, 3>(p, h, stream);
+    case 64: return launch_pair<64, 2, 3>(p, h, stream);
+    default: return launch_pair<128, 2, 3>(p, h, stream);
   }
 }
 

@@ -1,0 +1,29 @@
+// Fused float32 ResBlock1 pair (resblock32.hip): out = (x + c2(lrelu(c1(lrelu(x)))) [+ out]) / div
+#pragma once
+#include "common.h"
+
+namespace wetts {
+
+constexpr int RESPAIR32_MAX_SPAN = 64;  // (k-1)*dilation of c1 the staging loop is sized for
+
+struct ResPair32Params {
+  const float* x;  // [B][C][T] residual stream
+  float* out;      // [B][C][T] (never aliases x)
+  const float *wpk1, *wpk2;  // pack_conv_weight layouts of c1 / c2
+  const float *bias1, *bias2;
+  int T, B;
+  int ktaps, dil;  // c1: ktaps taps at dilation dil; c2: ktaps taps at dilation 1
+  int accum;       // add the previous contents of out (running MRF sum)
+  float out_div;
+  float slope;     // leaky-relu slope in front of both convs
+  int ntiles, nblocks, Wp;  // filled by the launcher
+  int ablate;      // microbench only (DBG instantiation): 1 no stores, 2 no residual loads,
+                   // 4 no A loads, 8 no x loads, 16 no MFMA
+};
+
+// max_lds_bytes: largest x tile the caller accepts (80 KB keeps two blocks per CU)
+bool resblock_pair32_supported(const PackedConv& c1, const PackedConv& c2, int max_lds_bytes);
+int32_t launch_resblock_pair32(const PackedConv& c1, const PackedConv& c2, ResPair32Params p,
+                               hipStream_t stream);
+
+}  // namespace wetts

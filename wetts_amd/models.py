@@ -97,7 +97,7 @@ class SynthesizerTrn:
         LDS-resident kernel -- bit-identical, for diagnostics."""
         prec = {torch.float32: 0, "f32": 0, "fp32": 0, torch.bfloat16: 1, "bf16": 1,
                 torch.float16: 2, "f16": 2, "fp16": 2}[dtype]
-        if prec and not fused:
+        if not fused:
             prec |= 0x10  # WETTS_DECODER_UNFUSED
         self._decoder_precision = prec
         if self._handle is not None:
