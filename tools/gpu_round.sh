@@ -13,3 +13,15 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o r -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_write.log 2>&1
 ls -R $R/gpurun_out/prof_stats $R/gpurun_out/pmc_fetch | head -20
 du -sh $R/gpurun_out
+# 16-bit decoder (BASELINE configs[2]/[4] precision): bench lines + kernel stats
+cd $R
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --decoder-dtype bf16 > gpurun_out/bench_bf16.json 2> gpurun_out/bench_bf16.err
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --decoder-dtype f16 > gpurun_out/bench_f16.json 2> gpurun_out/bench_f16.err
+cat gpurun_out/bench_bf16.json | cut -c1-300
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats_bf16 -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --decoder-dtype bf16 > $R/gpurun_out/prof_stats_bf16.log 2>&1
+cd $R
+# fused-pair microbenchmarks (f32 and bf16): two launches (0x20) vs fused (0x10)
+WETTS_PAIR=1 WETTS_SHAPES=128:3,128:7,128:11,64:3,64:7,64:11,32:3,32:7,32:11 python tools/bench_conv.py 32,16 > gpurun_out/conv32_fused_pair.txt 2>&1
+WETTS_PAIR=1 WETTS_CONV_FLAGS=16 WETTS_SHAPES=128:3,128:7,128:11,64:3,64:7,64:11,32:3,32:7,32:11 python tools/bench_conv.py 32,16 > gpurun_out/conv16_fused_pair.txt 2>&1
+python tools/bench_conv.py 0 > gpurun_out/conv_microbench.txt 2>&1

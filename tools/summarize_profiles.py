@@ -14,6 +14,14 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = "gpurun_out"
 shutil.copy(f"{src}/prof_stats/r_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
 shutil.copy(f"{src}/bench.json", f"profiles/{tag}_bench.json")
+import os
+for a, b in [("bench_bf16.json", "bench_bf16.json"), ("bench_f16.json", "bench_f16.json"),
+             ("prof_stats_bf16/r_kernel_stats.csv", "bf16_kernel_stats.csv"),
+             ("conv32_fused_pair.txt", "conv32_fused_pair.txt"),
+             ("conv16_fused_pair.txt", "conv16_fused_pair.txt"),
+             ("conv_microbench.txt", "conv_microbench.txt")]:
+    if os.path.exists(f"{src}/{a}"):
+        shutil.copy(f"{src}/{a}", f"profiles/{tag}_{b}")
 
 
 def agg(path, ctr):
@@ -44,11 +52,10 @@ for k in sorted(f, key=lambda k: -sum(f[k])):
         ent["avg_duration_ns"] = float(stats[k]["AverageNs"])
         ent["calls_in_stats_run"] = int(stats[k]["Calls"])
     out["kernels"][k] = ent
-    # dominant kernel class: the MRF-shaped conv instantiations (plain / mean epilogue)
-    # plus the fused f32 ResBlock pair kernel that replaces two of them
-    mm = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), \w+, \w+, (\d+)", k)
-    is_dom = (mm and mm.group(5) in ("1", "2") and mm.group(1, 2, 3, 4) != ("1", "1", "2", "2")) \
-        or "resblock_pair32_kernel" in k
+    # dominant kernel class = the MRF ResBlock launches: the fused f32 pair kernel and the tagged
+    # conv_mfma instantiations (OPT bit 64, set only by run_hifigan's ResBlock launches)
+    mm = re.search(r"conv_mfma_kernel<\d+, \d+, \d+, \d+, \w+, \w+, \d+, (\d+)>", k)
+    is_dom = (mm and (int(mm.group(1)) & 64)) or "resblock_pair32_kernel" in k
     if is_dom:
         dom["launches"] += n
         dom["fetch_kb"] += sum(f[k])

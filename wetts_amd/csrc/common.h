@@ -93,6 +93,7 @@ struct ConvParams {
   float out_div;         // final true division (MRF mean: xs / num_kernels), 1 = none
   int B;
   int ablate;            // microbenchmark-only ablation mask (see conv_mfma_kernel DBG)
+  int tag;               // 1: MRF ResBlock launch (separate kernel symbol for profiles)
 };
 
 // Packed weight descriptor held by the model.

@@ -114,7 +114,7 @@ void free_packed(PackedConv* pc) {
 // (acc + bias [+ per-utterance bias]), 2 = plain followed by the MRF mean division.
 // OPT (experiment bits): 1 = stagger the staging-load issue point across co-resident blocks, 2 = ping-pong A registers,
 // compile-time ablations for the microbenchmark: 4 no A loads, 8 no LDS B reads, 16 no staging
-// loads/stores, 32 no per-chunk barrier.
+// loads/stores, 32 no per-chunk barrier; 64 = name tag of the MRF launches (no code change).
 template <int MB, int NB, int WM, int WN, bool PF, bool DBG = false, int EPI = 0, int OPT = 0>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   // DBG instantiations honour p.ablate (microbenchmark only): 1 no MFMA, 2 no staging loads,
@@ -629,7 +629,16 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     WETTS_LAUNCH_CHECK();
     return WETTS_OK;
   }
-  if (plain && p.out_div == 1.f) {
+  if (plain && p.tag) {
+    // MRF ResBlock launches get their own symbol (OPT bit 64 changes nothing but the name) so that
+    // rocprofv3 --stats separates bench.py's dominant-kernel class from the flow / encoder convs
+    if (p.out_div == 1.f)
+      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 1, 2 | 64>),
+                         dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    else
+      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 2, 2 | 64>),
+                         dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  } else if (plain && p.out_div == 1.f) {
     hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 1, 2>), dim3((unsigned)blocks),
                        dim3(256), lds, stream, p);
   } else if (plain) {

@@ -1106,6 +1106,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           ConvParams p1 = conv_io(rx, ch, len, ft, ch, B);
           p1.in_act = IN_LRELU;
           p1.in_slope = 0.1f;
+          p1.tag = 1;
           WETTS_TRY(launch_conv(rb.c1[d], p1, sj));
           // the running sum is ordered chain j-1 -> chain j
           if (forked && last_d && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
@@ -1117,6 +1118,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           p2.r_cs = len;
           p2.accum = accum;
           p2.out_div = odiv;
+          p2.tag = 1;
           WETTS_TRY(launch_conv(rb.c2[d], p2, sj));
           if (tm && tm->on) tm->launches += 2;
           if (m->mrf_timing) m->mrf_launches += 2;
@@ -1131,6 +1133,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           p1.r_cs = len;
           p1.accum = accum;
           p1.out_div = odiv;
+          p1.tag = 1;
           WETTS_TRY(launch_conv(rb.c1[d], p1, sj));
           if (tm && tm->on) tm->launches += 1;
           if (m->mrf_timing) m->mrf_launches += 1;
