@@ -168,3 +168,21 @@ def test_ragged_and_degenerate_batches():
     assert np.array_equal(y_mask.cpu().numpy(), ref["y_mask"].numpy())
     assert np.array_equal(attn.cpu().numpy(), ref["attn"].numpy())
     assert util.rms(o.cpu().numpy() - ref["o"].numpy()) < 1e-4
+
+
+def test_graphed_stream_decoder_equals_plain():
+    """HIP-graph replay of the decoder windows (session.GraphedDecoder) is the same kernels in the
+    same order: every streamed piece must EQUAL the un-graphed one, and repeated replays of one
+    window shape with different inputs must not leak state."""
+    from wetts_amd.session import DecoderSession, stream_decode
+    net, case, cfg, *_ = _model("tiny_sdp_b3")
+    torch.manual_seed(3)
+    z = torch.randn(1, 131, cfg.inter_channels).numpy()
+    sid = np.array([min(1, int(case["n_speakers"]) - 1)], dtype=np.int64)
+    plain, graphed = DecoderSession(net), DecoderSession(net, use_graph=True)
+    for rep in range(2):
+        zz = z * (1.0 + rep)
+        a = np.concatenate(list(stream_decode(plain, zz, sid, chunk_size=40, pad_size=10)))
+        b = np.concatenate(list(stream_decode(graphed, zz, sid, chunk_size=40, pad_size=10)))
+        assert a.shape == b.shape == (131 * net.hop_length,)
+        assert np.array_equal(a, b)

@@ -298,6 +298,7 @@ struct wetts_model {
   mutable int dec_unfused = 0;    // diagnostic: run ResBlock1 pairs as two conv launches
   int fuse32_lds = 160 * 1024;    // largest f32 pair tile run fused (WETTS_FUSE32_LDS, bytes)
   int fuse32_kmax128 = 11;        // C>=128 pairs with this many taps or more stay unfused
+  int fuse_min_blocks = 128;      // fused pair kernels need this many tiles (else: small unfused tiles)
   mutable std::vector<PackedConvB> b_ups;
   mutable std::vector<std::vector<PackedConvB>> b_c1, b_c2;  // per resblock
   int mrf_streams = 1;
@@ -621,6 +622,8 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     if (fl) m->fuse32_lds = atoi(fl);
     const char* fk = getenv("WETTS_FUSE32_KMAX128");
     if (fk) m->fuse32_kmax128 = atoi(fk);
+    const char* fm = getenv("WETTS_FUSE_MIN_BLOCKS");
+    if (fm) m->fuse_min_blocks = atoi(fm);
     (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
     for (int j = 0; j < cfg->n_resblock_kernels; ++j) {
       (void)hipEventCreateWithFlags(&m->ev_chain[j], hipEventDisableTiming);
@@ -994,6 +997,13 @@ struct DecTiming {
   bool on = false;
 };
 
+// output columns per block of the fused ResBlock pair kernels (resblock32.hip / resblock16.hip)
+static int pair_nto(int C, int ktaps) {
+  const int wm = C >= 128 ? 4 : (C >= 64 ? 2 : 1);  // m-blocks of 32 rows (C in {32, 64, 128})
+  const int nto = 128 * (4 / wm) - (ktaps - 1);
+  return nto > 0 ? nto : 1;
+}
+
 static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, int64_t z_cs,
                            const float* y_mask, int64_t mask_stride, const float* g, int B, int L,
                            float* audio, void* workspace, int64_t workspace_bytes, hipStream_t s,
@@ -1083,9 +1093,14 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
         // fused wherever it measures faster (profiles/r01_conv32_fused_pair.txt): everything but
         // the MFMA-bound C=128, k=11 pairs, whose 2*(k-1)/2 discarded columns per 128 outweigh
         // the gain
+        // ... and only when the launch has enough time tiles to occupy the chip: a streaming
+        // window (50-60 frames) would be 25 blocks of 150 us each; the small unfused tiles spread
+        // it over 4x as many CUs (tools/bench_stream.py: 3.4 -> 2.8 ms per window)
+        const int pair_tiles = cdiv(len, pair_nto(ch, rb.c1[d].ktaps)) * B;
         const bool fuse32 = c->resblock == 1 && !m->dec_unfused &&
                             resblock_pair32_supported(rb.c1[d], rb.c2[d], m->fuse32_lds) &&
-                            !(ch >= 128 && rb.c1[d].ktaps >= m->fuse32_kmax128);
+                            !(ch >= 128 && rb.c1[d].ktaps >= m->fuse32_kmax128) &&
+                            pair_tiles >= m->fuse_min_blocks;
         if (fuse32) {
           // x = x + c2(lrelu(c1(lrelu(x)))) in one kernel (intermediate in LDS)
           if (forked && last_d && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
@@ -1289,7 +1304,8 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
         const int accum = (last_d && j > 0) ? 1 : 0;
         const float odiv = (last_d && j == nk - 1) ? (float)nk : 1.f;
         if (c->resblock == 1 && !m->dec_unfused &&
-            resblock_pair16_supported(m->b_c1[n][d], m->b_c2[n][d])) {
+            resblock_pair16_supported(m->b_c1[n][d], m->b_c2[n][d]) &&
+            cdiv(len, pair_nto(ch, m->b_c1[n][d].ktaps)) * B >= m->fuse_min_blocks) {
           ResPairParams pp;
           memset(&pp, 0, sizeof(pp));
           pp.x = rx;
@@ -1324,7 +1340,8 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
       m->mrf_events.emplace_back(lv0, lv1);
       int64_t per = (c->resblock == 1) ? 2 : 1;
       if (c->resblock == 1 && !m->dec_unfused &&
-          resblock_pair16_supported(m->b_c1[i * nk][0], m->b_c2[i * nk][0]))
+          resblock_pair16_supported(m->b_c1[i * nk][0], m->b_c2[i * nk][0]) &&
+          cdiv(len, pair_nto(ch, m->b_c1[i * nk][0].ktaps)) * B >= m->fuse_min_blocks)
         per = 1;
       m->mrf_launches += (int64_t)nk * nd * per;
     }

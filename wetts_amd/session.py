@@ -82,8 +82,69 @@ class EncoderSession(_SessionBase):
         return [z.contiguous().cpu().numpy()]
 
 
+class GraphedDecoder:
+    """hipGraph replay of the generator for fixed window shapes.
+
+    The streaming decode loop (vits_model.cc:128-153, inference_onnx.py:37-76) runs the decoder on
+    50-60 frame windows: ~85 kernel launches of a few microseconds each, i.e. launch-bound.  The
+    window shapes repeat (first / middle / last chunk), so each (B, L) is captured once into a HIP
+    graph -- same kernels, same order, bit-identical output -- and replayed with one launch.
+    Buffers the graph reads and writes are owned here (its z window, speaker vector, workspace
+    and audio), because a graph bakes the pointers in."""
+
+    def __init__(self, model: SynthesizerTrn):
+        if model._handle is None:
+            raise RuntimeError("model must have weights loaded and live on a HIP device")
+        self.model = model
+        self._entries = {}
+
+    def _build(self, B, L, has_g):
+        from . import _lib
+        m = self.model
+        lib = _lib.load()
+        dev = m.device
+        e = {"z": torch.zeros(B, m.inter_channels, L, dtype=torch.float32, device=dev),
+             "g": torch.zeros(B, max(1, m.gin_channels), dtype=torch.float32, device=dev) if has_g else None,
+             "audio": torch.empty(B, 1, L * m.hop_length, dtype=torch.float32, device=dev)}
+        nws = int(lib.wetts_workspace_bytes(m._handle, B, 0, L))
+        e["ws"] = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+
+        def launch():
+            _lib.check(lib.wetts_hifigan(m._handle, _lib.ptr(e["z"]), e["z"].stride(0),
+                                         e["z"].stride(1), None, 0, _lib.ptr(e["g"]), B, L,
+                                         _lib.ptr(e["audio"]), _lib.ptr(e["ws"]), nws,
+                                         _lib.current_stream_ptr()), "hifigan")
+
+        launch()  # un-captured first: one-time initialisation must not land in the capture
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            launch()
+        e["graph"] = graph
+        return e
+
+    def __call__(self, z, g=None):
+        """z [B, inter, L] (any strides), g [B, gin] or None -> audio [B, 1, L*hop] (a view of the
+        graph's output buffer: consume or copy it before the next call with the same shape)."""
+        B, _, L = z.shape
+        key = (int(B), int(L), g is not None)
+        e = self._entries.get(key)
+        if e is None:
+            e = self._entries[key] = self._build(int(B), int(L), g is not None)
+        e["z"].copy_(z)
+        if g is not None:
+            e["g"].copy_(g.reshape(B, -1))
+        e["graph"].replay()
+        return e["audio"]
+
+
 class DecoderSession(_SessionBase):
-    """Streaming back half (export_decoder_forward, models.py:360-363): z chunk -> audio."""
+    """Streaming back half (export_decoder_forward, models.py:360-363): z chunk -> audio.
+    `use_graph=True` replays a captured HIP graph per window shape (see GraphedDecoder)."""
+
+    def __init__(self, model, use_graph=False):
+        super().__init__(model)
+        self._graphed = GraphedDecoder(model) if use_graph else None
 
     def get_inputs(self):
         return [_Arg("z", ["B", "L", self.model.inter_channels], "tensor(float)"),
@@ -96,6 +157,9 @@ class DecoderSession(_SessionBase):
         self._check(output_names)
         z = self._dev(feeds["z"], torch.float32)
         sid = self._dev(feeds["sid"], torch.int64)
+        if self._graphed is not None and z.shape[1] > 0:
+            g = self.model._speaker(sid, z.shape[0])
+            return [self._graphed(z.transpose(1, 2), g).cpu().numpy()]
         return [self.model.export_decoder_forward(z, sid).cpu().numpy()]
 
 
