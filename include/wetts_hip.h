@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WETTS_ABI_VERSION 1
+#define WETTS_ABI_VERSION 2
 
 #define WETTS_OK 0
 #define WETTS_E_INVALID (-1)   /* bad argument / unsupported configuration */
@@ -71,7 +71,16 @@ typedef struct wetts_config {
   int32_t flow_kernel_size; /* 5  */
   int32_t sdp_n_flows;      /* 4  (models.py:145-150) */
   int32_t dp_filter_channels; /* 256 (models.py:152-156) */
-  int32_t reserved[8];
+  /* vocoder: 0 = HiFi-GAN Generator (decoders.py:15-88, the fields above), 1 = VocosGenerator
+   * (decoders.py:251-308: ConvNeXt stack + iSTFT head; examples/baker/configs/vocos.json:38-52) */
+  int32_t vocoder_type;
+  int32_t vocos_channels;    /* 512  */
+  int32_t vocos_h_channels;  /* 1536 */
+  int32_t vocos_num_layers;  /* 8    */
+  int32_t istft_n_fft;       /* 1024 (vocos_out_channels = n_fft + 2) */
+  int32_t istft_hop_length;  /* 256  */
+  int32_t istft_win_length;  /* 1024 (must equal n_fft) */
+  int32_t reserved[1];
 } wetts_config_t;
 
 typedef struct wetts_model wetts_model_t; /* opaque */

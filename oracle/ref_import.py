@@ -41,11 +41,31 @@ class _Sub:
         return self
 
 
+class _InverseSpectrogram:
+    """Stand-in for torchaudio.transforms.InverseSpectrogram (torchaudio is not installed): the
+    reference's VocosGenerator (decoders.py:279,304) only constructs it with
+    (n_fft, hop_length, win_length, center) and calls it on a complex spectrogram, which in
+    torchaudio is exactly torch.istft with a hann window, normalized=False, onesided=True,
+    length=None.  This is the ONE non-reference piece in the Vocos golden vectors."""
+
+    def __init__(self, n_fft=400, win_length=None, hop_length=None, center=True, **kw):
+        self.n_fft = n_fft
+        self.win_length = win_length if win_length is not None else n_fft
+        self.hop_length = hop_length if hop_length is not None else self.win_length // 2
+        self.center = center
+
+    def __call__(self, spectrogram, length=None):
+        import torch
+        return torch.istft(spectrogram, self.n_fft, self.hop_length, self.win_length,
+                           window=torch.hann_window(self.win_length), center=self.center,
+                           normalized=False, onesided=True, length=length, return_complex=False)
+
+
 def install_stubs():
     if "torchaudio" not in sys.modules:
         ta = _stub("torchaudio")
         ta.transforms = _stub("torchaudio.transforms",
-                              InverseSpectrogram=_raiser("InverseSpectrogram"),
+                              InverseSpectrogram=_InverseSpectrogram,
                               Spectrogram=_raiser("Spectrogram"),
                               MelSpectrogram=_raiser("MelSpectrogram"),
                               Resample=_raiser("Resample"))

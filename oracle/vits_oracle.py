@@ -338,6 +338,44 @@ def hifigan(W, cfg, z, g):
     return torch.tanh(x)
 
 
+# ------------------------------------------------------------------------------------------------
+# Vocos generator  (model/decoders.py:221-308: ConvNeXtLayer :221-248, VocosGenerator :251-305)
+# ------------------------------------------------------------------------------------------------
+def vocos(W, cfg, z, g):
+    """VocosGenerator.forward.  The iSTFT is torch.istft with the arguments
+    torchaudio.transforms.InverseSpectrogram(n_fft, hop_length, win_length, center=True) passes
+    (hann window, not normalized, one-sided, length=None) -- decoders.py:279,304."""
+    x = F.pad(z, (1, 0), mode="reflect")               # nn.ReflectionPad1d([1, 0])
+    x = conv1d(W, "dec.in_conv", x)
+    if g is not None:
+        x = x + conv1d(W, "dec.cond", g)
+    x = layer_norm_c(x, W["dec.norm_pre.gamma"], W["dec.norm_pre.beta"])
+    C = x.shape[1]
+    for l in range(cfg["vocos_num_layers"]):
+        p = f"dec.layers.{l}"
+        res = x
+        x = F.conv1d(x, W[p + ".dw_conv.weight"], W[p + ".dw_conv.bias"], padding=1, groups=C)
+        x = layer_norm_c(x, W[p + ".norm.gamma"], W[p + ".norm.beta"])
+        x = conv1d(W, p + ".pw_conv1", x)
+        x = F.gelu(x)
+        x = conv1d(W, p + ".pw_conv2", x)
+        x = res + W[p + ".scale"] * x
+    x = layer_norm_c(x, W["dec.norm_post.gamma"], W["dec.norm_post.beta"])
+    x = conv1d(W, "dec.out_conv", x)
+    mag, phase = x.chunk(2, dim=1)
+    mag = mag.exp().clamp_max(max=1e2)
+    spec = mag * (phase.cos() + 1j * phase.sin())
+    n_fft, hop, win = cfg["istft_n_fft"], cfg["istft_hop_length"], cfg["istft_win_length"]
+    o = torch.istft(spec, n_fft, hop, win, window=torch.hann_window(win), center=True,
+                    normalized=False, onesided=True, length=None, return_complex=False)
+    return o.unsqueeze(1)
+
+
+def decoder(W, cfg, z, g):
+    """self.dec(z, g): the generator the config selects (models.py:102-128)."""
+    return vocos(W, cfg, z, g) if cfg.get("vocoder_type", 0) == 1 else hifigan(W, cfg, z, g)
+
+
 _QDTYPE = torch.bfloat16
 
 
@@ -432,7 +470,7 @@ def infer(W, cfg, x_ids, x_lengths, sid=None, noise_scale=1.0, length_scale=1.0,
             eps_z = torch.randn_like(m_e)
         z_p = m_e + eps_z * torch.exp(logs_e) * noise_scale
         z = flow_reverse(W, cfg, z_p, y_mask, g)
-        o = hifigan(W, cfg, (z * y_mask)[:, :, :max_len], g)
+        o = decoder(W, cfg, (z * y_mask)[:, :, :max_len], g)
     if return_stages:
         return dict(x=x, m_p=m_p, logs_p=logs_p, x_mask=x_mask, logw=logw, w_ceil=w_ceil,
                     y_lengths=y_lengths, y_mask=y_mask, attn=attn, f2p=f2p, m_p_exp=m_e,

@@ -34,7 +34,11 @@ CASES = {
     "tiny_sdp_single": ("tiny", 40, 1, 1, 1, [1], 14, 104, (0.667, 1.0, 0.8)),
     "v1_b2": ("v1", 64, 1, 2, 8, [8, 5], 21, 201, (0.667, 1.0, 0.8)),
     "v3_b2": ("v3", 64, 2, 2, 8, [8, 6], 22, 202, (0.667, 1.0, 0.8)),
+    # VocosGenerator (decoders.py:251-308); iSTFT through the documented torch.istft stand-in
+    "tiny_vocos_b2": ("tiny_vocos", 40, 2, 2, 10, [10, 6], 15, 105, (0.667, 1.0, 0.8)),
+    "vocos_b2": ("vocos", 64, 2, 2, 8, [8, 5], 23, 203, (0.667, 1.0, 0.8)),
 }
+ONLY = os.environ.get("WETTS_GOLDEN_ONLY")  # comma-separated case names (default: all)
 
 
 def build_reference(model_name, n_vocab, n_speakers, sd):
@@ -81,6 +85,8 @@ def main():
                          "build container")
     torch.set_num_threads(1)
     for name, (mname, n_vocab, n_spk, B, Tx, lens, wseed, nseed, scales) in CASES.items():
+        if ONLY and name not in ONLY.split(","):
+            continue
         cfg = config.make_config(config.MODEL_CONFIGS[mname], n_vocab, n_spk)
         sd = synth.make_state_dict(cfg, wseed)
         blob = checkpoint.pack_blob(cfg, sd)
@@ -122,6 +128,8 @@ def main():
         print(f"{name}: Ty={Ty} audio={tuple(o.shape)} rms={rms:.4f} ceil_margin={margin:.2e} "
               f"frames/phone={float(y_mask.sum() / x_mask.sum()):.2f}")
 
+    if ONLY:
+        return
     # MAS known-answer vectors from the reference's maximum_path (numba stub => plain Python)
     _, _, _, mas = ref_import.import_reference()
     g = torch.Generator().manual_seed(5)

@@ -23,10 +23,10 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert _lib.load().wetts_abi_version() == 1
+    assert _lib.load().wetts_abi_version() == 2
 
 
-@pytest.mark.parametrize("mname", ["v1", "v2", "v3", "stress48k", "tiny", "tiny_dp"])
+@pytest.mark.parametrize("mname", ["v1", "v2", "v3", "stress48k", "tiny", "tiny_dp", "vocos", "tiny_vocos"])
 def test_blob_layout_is_consistent(mname):
     cfg = config.make_config(config.MODEL_CONFIGS[mname], 100, 4)
     lay = checkpoint.blob_layout(cfg)
@@ -47,7 +47,7 @@ def test_layout_names_and_shapes_match_reference_state_dict():
         pytest.skip("reference not present on this box")
     import contextlib, io
     S, *_ = ref_import.import_reference()
-    for mname, nspk in [("v1", 1), ("v3", 2)]:
+    for mname, nspk in [("v1", 1), ("v3", 2), ("vocos", 2)]:
         with contextlib.redirect_stdout(io.StringIO()):
             net = S(50, 513, 32, n_speakers=nspk, **config.MODEL_CONFIGS[mname])
         ref = {k: tuple(v.shape) for k, v in checkpoint.fold_weight_norm(net.state_dict()).items()}
@@ -98,7 +98,13 @@ def test_config_validation_and_unsupported_options():
     with pytest.raises(NotImplementedError):
         config.make_config(dict(config.MODEL_CONFIGS["v1"], use_transformer_flows=True), 10, 1)
     with pytest.raises(NotImplementedError):
-        config.make_config(dict(config.MODEL_CONFIGS["v1"], vocoder_type="vocos"), 10, 1)
+        config.make_config(dict(config.MODEL_CONFIGS["v1"], vocoder_type="bigvgan"), 10, 1)
+    vc = config.make_config(dict(config.MODEL_CONFIGS["v1"], vocoder_type="vocos"), 10, 1)
+    assert (vc.vocoder_type, vc.vocos_channels, vc.istft_n_fft, vc.istft_hop_length) == (1, 512, 1024, 256)
+    with pytest.raises(ValueError):  # out channels must be n_fft + 2 (decoders.py:296)
+        config.make_config(dict(config.MODEL_CONFIGS["vocos"], vocos_out_channels=1000), 10, 1)
+    vc.istft_win_length = 512
+    assert _lib.load().wetts_blob_num_tensors(C.byref(vc)) < 0 and "win_length" in _lib.last_error()
     cfg = config.make_config(config.MODEL_CONFIGS["v1"], 10, 1)
     cfg.resblock = 3
     assert _lib.load().wetts_blob_num_tensors(C.byref(cfg)) < 0

@@ -7,7 +7,8 @@ import torch
 from wetts_amd import checkpoint, config, synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-INFER_CASES = ["tiny_sdp_b3", "tiny_dp_b2", "tiny_sdp_nonoise", "tiny_sdp_single", "v1_b2", "v3_b2"]
+INFER_CASES = ["tiny_sdp_b3", "tiny_dp_b2", "tiny_sdp_nonoise", "tiny_sdp_single", "v1_b2", "v3_b2",
+               "tiny_vocos_b2", "vocos_b2"]  # the last two: VocosGenerator (decoders.py:251-308)
 
 
 def load_case(name):
@@ -38,7 +39,9 @@ def cfg_dict(cfg):
         window_size=cfg.window_size, n_speakers=cfg.n_speakers, use_sdp=bool(cfg.use_sdp),
         sdp_n_flows=cfg.sdp_n_flows, flow_n_flows=cfg.flow_n_flows,
         flow_wn_layers=cfg.flow_wn_layers, flow_kernel_size=cfg.flow_kernel_size,
-        resblock=cfg.resblock,
+        resblock=cfg.resblock, vocoder_type=cfg.vocoder_type, vocos_num_layers=cfg.vocos_num_layers,
+        istft_n_fft=cfg.istft_n_fft, istft_hop_length=cfg.istft_hop_length,
+        istft_win_length=cfg.istft_win_length,
         resblock_kernel_sizes=[cfg.resblock_kernel_sizes[j] for j in range(nk)],
         resblock_dilation_sizes=[[cfg.resblock_dilation_sizes[j][i] for i in range(nd)]
                                  for j in range(nk)],

@@ -50,7 +50,14 @@ class Config(C.Structure):
         ("flow_kernel_size", C.c_int32),
         ("sdp_n_flows", C.c_int32),
         ("dp_filter_channels", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("vocoder_type", C.c_int32),
+        ("vocos_channels", C.c_int32),
+        ("vocos_h_channels", C.c_int32),
+        ("vocos_num_layers", C.c_int32),
+        ("istft_n_fft", C.c_int32),
+        ("istft_hop_length", C.c_int32),
+        ("istft_win_length", C.c_int32),
+        ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -119,7 +126,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError => header / library mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.wetts_abi_version() != 1:
+    if lib.wetts_abi_version() != 2:
         raise WettsError("libwetts_hip.so ABI version mismatch")
     _lib = lib
     return lib

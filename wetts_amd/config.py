@@ -85,8 +85,24 @@ MODEL_CONFIGS = {
                     upsample_initial_channel=96, resblock_kernel_sizes=[3, 5],
                     resblock_dilation_sizes=[[1, 2], [2, 6]], use_sdp=False),
 }
+# examples/baker/configs/vocos.json:29-56 (VocosGenerator; the HiFi-GAN fields are carried by the
+# JSON but unused by that vocoder)
+_VOCOS_HIFI_FIELDS = dict(resblock="1", resblock_kernel_sizes=[3, 7, 11],
+                          resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+                          upsample_rates=[8, 8, 2, 2], upsample_initial_channel=512,
+                          upsample_kernel_sizes=[16, 16, 4, 4])
+MODEL_CONFIGS["vocos"] = dict(
+    _COMMON, **_VOCOS_HIFI_FIELDS, vocoder_type="vocos", vocos_channels=512, vocos_h_channels=1536,
+    vocos_out_channels=1026, vocos_num_layers=8,
+    vocos_istft_config=dict(n_fft=1024, hop_length=256, win_length=1024, center=True),
+    use_sdp=False)
+MODEL_CONFIGS["tiny_vocos"] = dict(
+    inter_channels=192, hidden_channels=192, filter_channels=256, n_heads=2, n_layers=2,
+    kernel_size=3, p_dropout=0.1, gin_channels=64, **_VOCOS_HIFI_FIELDS, vocoder_type="vocos",
+    vocos_channels=64, vocos_h_channels=160, vocos_out_channels=66, vocos_num_layers=2,
+    vocos_istft_config=dict(n_fft=64, hop_length=16, win_length=64, center=True), use_sdp=False)
 SAMPLING_RATES = {"v1": 22050, "v2": 22050, "v3": 16000, "stress48k": 48000, "tiny": 22050,
-                  "tiny_dp": 16000}
+                  "tiny_dp": 16000, "vocos": 16000, "tiny_vocos": 16000}
 
 
 def _get(model, key, default=None):
@@ -111,9 +127,26 @@ def make_config(model, n_vocab, n_speakers):
     for k, why in _UNSUPPORTED.items():
         if _get(model, k, False):
             raise NotImplementedError(f"model.{k}=true is not supported: {why}")
-    if _get(model, "vocoder_type", "hifigan") != "hifigan":
-        raise NotImplementedError("only vocoder_type='hifigan' (decoders.py:15-88) is in scope")
+    voc = _get(model, "vocoder_type", "hifigan")
+    if voc not in ("hifigan", "vocos"):
+        raise NotImplementedError(f"vocoder_type={voc!r}: only 'hifigan' (decoders.py:15-88) and "
+                                  "'vocos' (decoders.py:251-308) exist in the reference")
     c = _lib.Config()
+    if voc == "vocos":
+        ic = _get(model, "vocos_istft_config", None) or {}
+        c.vocoder_type = 1
+        c.vocos_channels = int(_get(model, "vocos_channels", 512))
+        c.vocos_h_channels = int(_get(model, "vocos_h_channels", 1536))
+        c.vocos_num_layers = int(_get(model, "vocos_num_layers", 8))
+        c.istft_n_fft = int(_get(ic, "n_fft", 1024))
+        c.istft_hop_length = int(_get(ic, "hop_length", 256))
+        c.istft_win_length = int(_get(ic, "win_length", c.istft_n_fft))
+        if not _get(ic, "center", True):
+            raise NotImplementedError("vocos_istft_config.center=false is not supported")
+        out_ch = int(_get(model, "vocos_out_channels", c.istft_n_fft + 2))
+        if out_ch != c.istft_n_fft + 2:
+            raise ValueError(f"vocos_out_channels={out_ch} must be n_fft + 2 = {c.istft_n_fft + 2} "
+                             "(magnitude and phase of n_fft/2+1 bins, decoders.py:296)")
     c.n_vocab = int(n_vocab)
     c.inter_channels = int(_get(model, "inter_channels"))
     c.hidden_channels = int(_get(model, "hidden_channels"))

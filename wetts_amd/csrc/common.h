@@ -55,7 +55,7 @@ void set_error(const char* fmt, ...);
 constexpr int kConvCK = 16;  // input channels staged per LDS chunk (fixed by the packed layout)
 
 enum InAct { IN_NONE = 0, IN_LRELU = 1 };
-enum OutAct { OUT_NONE = 0, OUT_RELU = 1 };
+enum OutAct { OUT_NONE = 0, OUT_RELU = 1, OUT_GELU = 2 };  // GELU = exact erf form (F.gelu default)
 
 struct ConvParams {
   // input

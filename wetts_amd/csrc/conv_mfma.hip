@@ -497,6 +497,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         if (p.bias) v += p.bias[co];
         if (bb) v += bb[co];
         if (p.out_act == OUT_RELU) v = v > 0.f ? v : 0.f;
+        if (p.out_act == OUT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
         if (omask) v *= omask[t];
         float* dst = p.out + ob + (int64_t)co * p.o_cs + t;
         if (!pre_res) {

@@ -80,6 +80,23 @@ int32_t k_attn_path(const int32_t* frame2phone, int B, int Tx, int Ty, float* at
 int32_t k_audio_to_int16(const float* audio, const int64_t* lengths, int B, int64_t L, int16_t* pcm,
                          hipStream_t s);
 
+// ---- VocosGenerator (decoders.py:251-308) ---------------------------------------------------
+// ReflectionPad1d([1,0]) of (z * y_mask)[:, :, :L]: out [B,C,L+1], out[..,0] = in[..,1]
+int32_t k_vocos_pad(const float* z, int64_t z_bs, int64_t z_cs, const float* mask,
+                    int64_t mask_stride, int B, int C, int L, float* out, hipStream_t s);
+// spec [B, 2*half, F] (log-magnitude rows then phase rows) -> [B, 2*half, F] real rows then
+// imaginary rows of  min(exp(mag), 1e2) * (cos(phase) + i sin(phase))   (decoders.py:297-303)
+int32_t k_vocos_spec(const float* spec, int B, int half, int F, float* ri, hipStream_t s);
+// windowed inverse-rDFT basis as a 1x1 conv weight [n_fft][2*half]: frame[n] = hann[n] * irfft(S)[n]
+int32_t k_istft_basis(int n_fft, float* w, hipStream_t s);
+// overlap-add + window-envelope normalisation + centre trim of torch.istft (center=True):
+// frames [B, n_fft, F] -> audio [B, (F-1)*hop]
+int32_t k_istft_ola(const float* frames, int B, int n_fft, int hop, int F, float* audio,
+                    hipStream_t s);
+// out[r, :] = a[r, :] * scale[r]   (rows x cols), folds ConvNeXtLayer.scale into pw_conv2
+int32_t k_scale_rows(const float* a, const float* scale, int rows, int cols, float* out,
+                     hipStream_t s);
+
 // a5 windowed relative-position attention (attentions.py:235-282), banded form.
 //   qkv: q,k,v [B,H*dk,T];  scores workspace [B,H,T,T];  out [B,H*dk,T]
 int32_t k_rel_attention(const float* q, const float* k, const float* v, const float* mask,

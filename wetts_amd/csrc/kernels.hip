@@ -132,12 +132,12 @@ __global__ void dwconv_kernel(const float* __restrict__ x, const float* __restri
   int c = (int)((idx / T) % C);
   int b = (int)(idx / ((int64_t)T * C));
   const float* xr = x + ((int64_t)b * C + c) * T;
-  const float* mr = mask + (int64_t)b * T;
+  const float* mr = mask ? mask + (int64_t)b * T : nullptr;  // null: no mask (ConvNeXt dw_conv)
   int pad = (k * dil - dil) / 2;
   float acc = bias[c];
   for (int j = 0; j < k; ++j) {
     int tt = t + j * dil - pad;
-    if (tt >= 0 && tt < T) acc += w[c * k + j] * (xr[tt] * mr[tt]);
+    if (tt >= 0 && tt < T) acc += w[c * k + j] * (mr ? xr[tt] * mr[tt] : xr[tt]);
   }
   out[idx] = acc;
 }
@@ -674,6 +674,134 @@ int32_t k_audio_to_int16(const float* audio, const int64_t* lengths, int B, int6
                          hipStream_t s) {
   if (B == 0 || L == 0) return WETTS_OK;
   hipLaunchKernelGGL(audio_to_int16_kernel, dim3(B), dim3(256), 0, s, audio, lengths, L, pcm);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// VocosGenerator pieces (decoders.py:251-308)
+// ---------------------------------------------------------------------------------------------
+__global__ void vocos_pad_kernel(const float* __restrict__ z, int64_t z_bs, int64_t z_cs,
+                                 const float* __restrict__ mask, int64_t mask_stride, int B, int C,
+                                 int L, float* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int F = L + 1;
+  if (idx >= (int64_t)B * C * F) return;
+  const int f = (int)(idx % F);
+  const int c = (int)((idx / F) % C);
+  const int b = (int)(idx / ((int64_t)F * C));
+  const int t = f == 0 ? 1 : f - 1;  // reflect: padded[0] = x[1]
+  float v = z[(int64_t)b * z_bs + (int64_t)c * z_cs + t];
+  if (mask) v *= mask[(int64_t)b * mask_stride + t];
+  out[idx] = v;
+}
+
+int32_t k_vocos_pad(const float* z, int64_t z_bs, int64_t z_cs, const float* mask,
+                    int64_t mask_stride, int B, int C, int L, float* out, hipStream_t s) {
+  int64_t n = (int64_t)B * C * (L + 1);
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(vocos_pad_kernel, grid1d(n, 256), dim3(256), 0, s, z, z_bs, z_cs, mask,
+                     mask_stride, B, C, L, out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+__global__ void vocos_spec_kernel(const float* __restrict__ spec, int B, int half, int F,
+                                  float* __restrict__ ri) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * half * F) return;
+  const int f = (int)(idx % F);
+  const int k = (int)((idx / F) % half);
+  const int b = (int)(idx / ((int64_t)F * half));
+  const int64_t base = (int64_t)b * 2 * half * F;
+  const float lm = spec[base + (int64_t)k * F + f];
+  const float ph = spec[base + (int64_t)(half + k) * F + f];
+  const float mag = fminf(expf(lm), 1e2f);  // mag.exp().clamp_max(1e2)
+  ri[base + (int64_t)k * F + f] = mag * cosf(ph);
+  ri[base + (int64_t)(half + k) * F + f] = mag * sinf(ph);
+}
+
+int32_t k_vocos_spec(const float* spec, int B, int half, int F, float* ri, hipStream_t s) {
+  int64_t n = (int64_t)B * half * F;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(vocos_spec_kernel, grid1d(n, 256), dim3(256), 0, s, spec, B, half, F, ri);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// w[n][c]: c < half -> coefficient of Re S[c]; c >= half -> coefficient of Im S[c-half]
+//   irfft: x[n] = (1/N) sum_k a_k (Re S_k cos(2 pi k n / N) - Im S_k sin(2 pi k n / N)),
+//   a_0 = a_{N/2} = 1, else 2; times the periodic hann window (torch.hann_window default)
+__global__ void istft_basis_kernel(int n_fft, float* __restrict__ w) {
+  const int half = n_fft / 2 + 1;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n_fft * 2 * half) return;
+  const int c = (int)(idx % (2 * half));
+  const int n = (int)(idx / (2 * half));
+  const int k = c < half ? c : c - half;
+  const double pi2 = 6.283185307179586476925286766559;
+  const double win = 0.5 - 0.5 * cos(pi2 * n / n_fft);
+  const double a = (k == 0 || k == n_fft / 2) ? 1.0 : 2.0;
+  // reduce k*n mod N before the trig call to keep the argument small
+  const double ang = pi2 * (double)((int64_t)k * n % n_fft) / n_fft;
+  const double v = c < half ? cos(ang) : -sin(ang);
+  w[idx] = (float)(win * a * v / n_fft);
+}
+
+int32_t k_istft_basis(int n_fft, float* w, hipStream_t s) {
+  int64_t n = (int64_t)n_fft * (n_fft + 2);
+  hipLaunchKernelGGL(istft_basis_kernel, grid1d(n, 256), dim3(256), 0, s, n_fft, w);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+__global__ void istft_ola_kernel(const float* __restrict__ frames, int B, int n_fft, int hop, int F,
+                                 float* __restrict__ audio) {
+  const int64_t Ls = (int64_t)(F - 1) * hop;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * Ls) return;
+  const int b = (int)(idx / Ls);
+  const int64_t n = idx % Ls;
+  const int64_t m = n + n_fft / 2;  // position in the un-trimmed overlap-add buffer
+  int64_t f_hi = m / hop;
+  if (f_hi > F - 1) f_hi = F - 1;
+  int64_t f_lo = (m - n_fft + hop) / hop;  // ceil((m - n_fft + 1) / hop) for m - n_fft + 1 > 0
+  if (m - n_fft + 1 <= 0) f_lo = 0;
+  const float* fb = frames + (int64_t)b * n_fft * F;
+  const float pi2 = 6.283185307179586f;
+  float y = 0.f, env = 0.f;
+  for (int64_t f = f_lo; f <= f_hi; ++f) {
+    const int j = (int)(m - f * hop);  // 0 <= j < n_fft
+    y += fb[(int64_t)j * F + f];
+    const float wv = 0.5f - 0.5f * cosf(pi2 * (float)j / (float)n_fft);
+    env += wv * wv;
+  }
+  audio[idx] = y / env;  // torch.istft: y / window_envelope (asserted > 1e-11 there)
+}
+
+int32_t k_istft_ola(const float* frames, int B, int n_fft, int hop, int F, float* audio,
+                    hipStream_t s) {
+  int64_t n = (int64_t)B * (F - 1) * hop;
+  if (n <= 0) return WETTS_OK;
+  hipLaunchKernelGGL(istft_ola_kernel, grid1d(n, 256), dim3(256), 0, s, frames, B, n_fft, hop, F,
+                     audio);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+__global__ void scale_rows_kernel(const float* __restrict__ a, const float* __restrict__ scale,
+                                  int rows, int cols, float* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)rows * cols) return;
+  out[idx] = a[idx] * scale[idx / cols];
+}
+
+int32_t k_scale_rows(const float* a, const float* scale, int rows, int cols, float* out,
+                     hipStream_t s) {
+  int64_t n = (int64_t)rows * cols;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(scale_rows_kernel, grid1d(n, 256), dim3(256), 0, s, a, scale, rows, cols, out);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

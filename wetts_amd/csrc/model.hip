@@ -87,6 +87,14 @@ static int validate_config(const wetts_config_t* c) {
   WETTS_REQUIRE(c->flow_n_flows >= 1 && c->flow_wn_layers >= 1 && c->flow_kernel_size % 2 == 1,
                 "bad flow config");
   WETTS_REQUIRE(c->sdp_n_flows >= 2, "bad sdp_n_flows");
+  WETTS_REQUIRE(c->vocoder_type == 0 || c->vocoder_type == 1, "vocoder_type must be 0 (hifigan) or 1 (vocos)");
+  if (c->vocoder_type == 1) {
+    WETTS_REQUIRE(c->vocos_channels > 0 && c->vocos_h_channels > 0 && c->vocos_num_layers >= 1 &&
+                      c->vocos_num_layers <= 64, "bad vocos channels / layers");
+    WETTS_REQUIRE(c->istft_n_fft >= 4 && c->istft_n_fft % 2 == 0 && c->istft_hop_length >= 1 &&
+                      c->istft_hop_length <= c->istft_n_fft, "bad istft config");
+    WETTS_REQUIRE(c->istft_win_length == c->istft_n_fft, "istft win_length must equal n_fft");
+  }
   return WETTS_OK;
 }
 
@@ -192,6 +200,34 @@ static void build_layout(const wetts_config_t* c, Layout& L) {
     L.add(p + ".post.bias", I / 2);
   }
 
+  if (c->vocoder_type == 1) {  // VocosGenerator (decoders.py:251-284)
+    const int VC = c->vocos_channels, VH = c->vocos_h_channels, VO = c->istft_n_fft + 2;
+    L.add("dec.in_conv.weight", VC, I, 1);
+    L.add("dec.in_conv.bias", VC);
+    if (has_g(c)) {
+      L.add("dec.cond.weight", VC, gin, 1);
+      L.add("dec.cond.bias", VC);
+    }
+    L.add("dec.norm_pre.gamma", VC);
+    L.add("dec.norm_pre.beta", VC);
+    for (int l = 0; l < c->vocos_num_layers; ++l) {
+      std::string p = S("dec.layers.%d", l);
+      L.add(p + ".dw_conv.weight", VC, 1, 3);
+      L.add(p + ".dw_conv.bias", VC);
+      L.add(p + ".norm.gamma", VC);
+      L.add(p + ".norm.beta", VC);
+      L.add(p + ".pw_conv1.weight", VH, VC, 1);
+      L.add(p + ".pw_conv1.bias", VH);
+      L.add(p + ".pw_conv2.weight", VC, VH, 1);
+      L.add(p + ".pw_conv2.bias", VC);
+      L.add(p + ".scale", 1, VC, 1);
+    }
+    L.add("dec.norm_post.gamma", VC);
+    L.add("dec.norm_post.beta", VC);
+    L.add("dec.out_conv.weight", VO, VC, 1);
+    L.add("dec.out_conv.bias", VO);
+    return;
+  }
   const int C0 = c->upsample_initial_channel;
   L.add("dec.conv_pre.weight", C0, I, 7);
   L.add("dec.conv_pre.bias", C0);
@@ -252,6 +288,11 @@ struct RB {
   std::vector<PackedConv> c1, c2;  // c2 empty for ResBlock2
 };
 
+struct ConvNeXt {  // ConvNeXtLayer (decoders.py:221-248); `scale` folded into pw2
+  const float *dw_w, *dw_b, *ng, *nb;
+  PackedConv pw1, pw2;
+};
+
 }  // namespace wetts
 
 using namespace wetts;
@@ -284,6 +325,11 @@ struct wetts_model {
   const float* conv_post_w = nullptr;
   const float *dec_cond_w = nullptr, *dec_cond_b = nullptr;
   int hop = 1;
+  // vocos decoder
+  PackedConv v_in, v_out, v_istft;
+  std::vector<ConvNeXt> v_layers;
+  const float *v_npre_g = nullptr, *v_npre_b = nullptr, *v_npost_g = nullptr, *v_npost_b = nullptr;
+  std::vector<float*> v_owned;  // device buffers built at create (scaled pw2 weights, iSTFT basis)
   // live MRF timing (wetts_set_mrf_timing): event pairs recorded around each stage's ResBlock
   // launches, resolved lazily by wetts_read_mrf_timing so the timed region is not perturbed.
   mutable bool mrf_timing = false;
@@ -354,6 +400,54 @@ static int32_t load_dds(wetts_model* m, const std::string& p, int C, hipStream_t
     WETTS_TRY(pack(m, p + S(".convs_1x1.%d.weight", i), p + S(".convs_1x1.%d.bias", i), C, C, 1, 1,
                    0, 0, 0, s, &d->c1x1[i]));
   }
+  return WETTS_OK;
+}
+
+// VocosGenerator weights (decoders.py:251-284): 1x1 convs packed for the MFMA conv kernel,
+// ConvNeXtLayer.scale folded into pw_conv2 (scale * (W u + b) = (scale W) u + scale b), and the
+// iSTFT head expressed as one more 1x1 conv whose weight is the windowed inverse-rDFT basis.
+static int32_t build_vocos(wetts_model* m, hipStream_t s) {
+  const wetts_config_t* c = &m->cfg;
+  const int I = c->inter_channels, VC = c->vocos_channels, VH = c->vocos_h_channels;
+  const int NF = c->istft_n_fft, VO = NF + 2;
+  WETTS_TRY(pack(m, "dec.in_conv.weight", "dec.in_conv.bias", VC, I, 1, 1, 0, 0, 0, s, &m->v_in));
+  m->dec_cond_w = m->T("dec.cond.weight");
+  m->dec_cond_b = m->T("dec.cond.bias");
+  m->v_npre_g = m->T("dec.norm_pre.gamma");
+  m->v_npre_b = m->T("dec.norm_pre.beta");
+  m->v_npost_g = m->T("dec.norm_post.gamma");
+  m->v_npost_b = m->T("dec.norm_post.beta");
+  m->v_layers.resize(c->vocos_num_layers);
+  for (int l = 0; l < c->vocos_num_layers; ++l) {
+    ConvNeXt& cn = m->v_layers[l];
+    std::string p = S("dec.layers.%d", l);
+    cn.dw_w = m->T(p + ".dw_conv.weight");
+    cn.dw_b = m->T(p + ".dw_conv.bias");
+    cn.ng = m->T(p + ".norm.gamma");
+    cn.nb = m->T(p + ".norm.beta");
+    WETTS_TRY(pack(m, p + ".pw_conv1.weight", p + ".pw_conv1.bias", VH, VC, 1, 1, 0, 0, 0, s, &cn.pw1));
+    const float* w2 = m->T(p + ".pw_conv2.weight");
+    const float* b2 = m->T(p + ".pw_conv2.bias");
+    const float* sc = m->T(p + ".scale");
+    WETTS_REQUIRE(w2 && b2 && sc, "vocos layer %d tensors missing", l);
+    float *w2s = nullptr, *b2s = nullptr;
+    WETTS_HIP_CHECK(hipMalloc((void**)&w2s, (size_t)VC * VH * sizeof(float)));
+    m->v_owned.push_back(w2s);
+    WETTS_HIP_CHECK(hipMalloc((void**)&b2s, (size_t)VC * sizeof(float)));
+    m->v_owned.push_back(b2s);
+    WETTS_TRY(k_scale_rows(w2, sc, VC, VH, w2s, s));
+    WETTS_TRY(k_scale_rows(b2, sc, VC, 1, b2s, s));
+    WETTS_TRY(pack_conv_weight(w2s, b2s, VC, VH, 1, 1, 0, 0, 0, s, &cn.pw2));
+    m->all_packed.push_back(&cn.pw2);
+  }
+  WETTS_TRY(pack(m, "dec.out_conv.weight", "dec.out_conv.bias", VO, VC, 1, 1, 0, 0, 0, s, &m->v_out));
+  float* basis = nullptr;
+  WETTS_HIP_CHECK(hipMalloc((void**)&basis, (size_t)NF * VO * sizeof(float)));
+  m->v_owned.push_back(basis);
+  WETTS_TRY(k_istft_basis(NF, basis, s));
+  WETTS_TRY(pack_conv_weight(basis, nullptr, NF, VO, 1, 1, 0, 0, 0, s, &m->v_istft));
+  m->all_packed.push_back(&m->v_istft);
+  m->hop = c->istft_hop_length;
   return WETTS_OK;
 }
 
@@ -436,6 +530,8 @@ static int32_t build_model(wetts_model* m, hipStream_t s) {
     fw.cond_w = m->T(p + ".enc.cond_layer.weight");
     fw.cond_b = m->T(p + ".enc.cond_layer.bias");
   }
+
+  if (c->vocoder_type == 1) return build_vocos(m, s);
 
   const int C0 = c->upsample_initial_channel;
   WETTS_TRY(pack(m, "dec.conv_pre.weight", "dec.conv_pre.bias", C0, I, 7, 1, 3, 0, 0, s,
@@ -543,7 +639,14 @@ static int64_t dec_max_elems(const wetts_config_t* c, int B, int L) {
   return mx;
 }
 
+static int64_t ws_vocos(const wetts_config_t* c, int B, int L) {
+  const int64_t F = L + 1, VC = c->vocos_channels, VH = c->vocos_h_channels, NF = c->istft_n_fft;
+  return A256(B * c->inter_channels * F) + 3 * A256(B * VC * F) + A256(B * VH * F) +
+         2 * A256(B * (NF + 2) * F) + A256(B * NF * F) + A256(B * VC);
+}
+
 static int64_t ws_decoder(const wetts_config_t* c, int B, int L) {
+  if (c->vocoder_type == 1) return ws_vocos(c, B, L);
   return (3 + 3 * (int64_t)c->n_resblock_kernels) * A256(dec_max_elems(c, B, L)) +
          A256((int64_t)B * c->upsample_initial_channel);
 }
@@ -657,6 +760,7 @@ void wetts_destroy(wetts_model_t* m) {
     if (m->ev_chain[j]) (void)hipEventDestroy(m->ev_chain[j]);
   }
   if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+  for (float* p : m->v_owned) (void)hipFree(p);
   if (m->blob) (void)hipFree(m->blob);
   delete m;
 }
@@ -996,6 +1100,62 @@ struct DecTiming {
   int launches = 0;
   bool on = false;
 };
+
+// VocosGenerator.forward (decoders.py:286-305) on (z * y_mask)[:, :, :L]:
+//   pad -> in_conv (+ cond(g)) -> LN -> 8 x ConvNeXt -> LN -> out_conv -> exp/clamp, cos/sin
+//   -> iSTFT (n_fft, hop, hann, center) = windowed inverse-rDFT GEMM + overlap-add / envelope
+static int32_t run_vocos(const wetts_model* m, const float* z, int64_t z_bs, int64_t z_cs,
+                         const float* y_mask, int64_t mask_stride, const float* g, int B, int L,
+                         float* audio, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+  const wetts_config_t* c = &m->cfg;
+  const int I = c->inter_channels, VC = c->vocos_channels, VH = c->vocos_h_channels;
+  const int NF = c->istft_n_fft, VO = NF + 2, F = L + 1;
+  // nn.ReflectionPad1d([1, 0]) needs at least two frames (PyTorch raises otherwise)
+  WETTS_REQUIRE(L >= 2, "vocos decoder needs at least 2 frames (ReflectionPad1d([1,0]), decoders.py:265)");
+  Bump ws(workspace, workspace_bytes);
+  float* xpad = ws.take<float>((int64_t)B * I * F);
+  float* h = ws.take<float>((int64_t)B * VC * F);
+  float* t1 = ws.take<float>((int64_t)B * VC * F);
+  float* t2 = ws.take<float>((int64_t)B * VC * F);
+  float* u = ws.take<float>((int64_t)B * VH * F);
+  float* spec = ws.take<float>((int64_t)B * VO * F);
+  float* ri = ws.take<float>((int64_t)B * VO * F);
+  float* frames = ws.take<float>((int64_t)B * NF * F);
+  float* cond = ws.take<float>((int64_t)B * VC);
+  if (!ws.ok) {
+    set_error("vocos: workspace too small (need %lld bytes)", (long long)ws_decoder(c, B, L));
+    return WETTS_E_WORKSPACE;
+  }
+  WETTS_TRY(k_vocos_pad(z, z_bs, z_cs, y_mask, mask_stride, B, I, L, xpad, s));
+  {
+    ConvParams p = conv_io(xpad, I, F, t1, VC, B);
+    if (has_g(c) && g) {
+      WETTS_TRY(k_cond_linear(g, m->dec_cond_w, m->dec_cond_b, B, VC, c->gin_channels, cond, s));
+      p.bias_b = cond;
+      p.bias_b_stride = VC;
+    }
+    WETTS_TRY(launch_conv(m->v_in, p, s));
+  }
+  WETTS_TRY(k_layernorm(t1, nullptr, m->v_npre_g, m->v_npre_b, nullptr, nullptr, 0, B, VC, F, h, s));
+  for (const ConvNeXt& cn : m->v_layers) {
+    WETTS_TRY(k_dwconv(h, nullptr, cn.dw_w, cn.dw_b, 3, 1, B, VC, F, t1, s));
+    WETTS_TRY(k_layernorm(t1, nullptr, cn.ng, cn.nb, nullptr, nullptr, 0, B, VC, F, t2, s));
+    ConvParams p1 = conv_io(t2, VC, F, u, VH, B);
+    p1.out_act = OUT_GELU;
+    WETTS_TRY(launch_conv(cn.pw1, p1, s));
+    ConvParams p2 = conv_io(u, VH, F, t1, VC, B);  // x = res + scale * pw2(u)
+    p2.res = h;
+    p2.r_bs = (int64_t)VC * F;
+    p2.r_cs = F;
+    WETTS_TRY(launch_conv(cn.pw2, p2, s));
+    float* sw = h; h = t1; t1 = sw;
+  }
+  WETTS_TRY(k_layernorm(h, nullptr, m->v_npost_g, m->v_npost_b, nullptr, nullptr, 0, B, VC, F, t2, s));
+  WETTS_TRY(launch_conv(m->v_out, conv_io(t2, VC, F, spec, VO, B), s));
+  WETTS_TRY(k_vocos_spec(spec, B, VO / 2, F, ri, s));
+  WETTS_TRY(launch_conv(m->v_istft, conv_io(ri, VO, F, frames, NF, B), s));
+  return k_istft_ola(frames, B, NF, c->istft_hop_length, F, audio, s);
+}
 
 // output columns per block of the fused ResBlock pair kernels (resblock32.hip / resblock16.hip)
 static int pair_nto(int C, int ktaps) {
@@ -1358,6 +1518,8 @@ int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision) {
   precision &= ~WETTS_DECODER_UNFUSED;
   WETTS_REQUIRE(precision >= 0 && precision <= 2, "precision must be 0 (f32), 1 (bf16) or 2 (f16)");
   m->dec_unfused = unfused;
+  WETTS_REQUIRE(precision == 0 || m->cfg.vocoder_type == 0,
+                "the 16-bit decoder mode covers the HiFi-GAN generator only");
   if (precision >= 1) {
     const wetts_config_t* c = &m->cfg;
     WETTS_REQUIRE((c->upsample_initial_channel >> c->n_upsamples) % 32 == 0,
@@ -1373,6 +1535,9 @@ int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_st
                       int64_t workspace_bytes, void* stream) {
   WETTS_REQUIRE(m && z && audio, "null argument");
   if (B == 0 || L == 0) return WETTS_OK;
+  if (m->cfg.vocoder_type == 1)
+    return run_vocos(m, z, z_batch_stride, z_channel_stride, y_mask, mask_stride, g, B, L, audio,
+                     workspace, workspace_bytes, (hipStream_t)stream);
   if (m->dec_precision >= 1)
     return run_hifigan_bf16(m, z, z_batch_stride, z_channel_stride, y_mask, mask_stride, g, B, L,
                             audio, workspace, workspace_bytes, (hipStream_t)stream);
@@ -1385,6 +1550,7 @@ int32_t wetts_profile_hifigan(const wetts_model_t* m, const float* z, int64_t z_
                               float* audio, void* workspace, int64_t workspace_bytes, void* stream,
                               double* mrf_ms, double* total_ms, int32_t* mrf_launches) {
   WETTS_REQUIRE(m && z && audio && mrf_ms && total_ms && mrf_launches, "null argument");
+  WETTS_REQUIRE(m->cfg.vocoder_type == 0, "wetts_profile_hifigan: HiFi-GAN models only");
   hipStream_t s = (hipStream_t)stream;
   DecTiming tm;
   tm.on = true;
@@ -1746,6 +1912,20 @@ int32_t wetts_hifigan_cost(const wetts_config_t* c, double* flops_per_frame,
                            double* bytes_per_frame_perconv, double* mrf_flops_per_frame,
                            double* mrf_bytes_per_frame_perconv) {
   WETTS_TRY(validate_config(c));
+  if (c->vocoder_type == 1) {  // VocosGenerator: all work is per frame; "mrf" = the ConvNeXt stack
+    const double I = c->inter_channels, VC = c->vocos_channels, VH = c->vocos_h_channels;
+    const double NF = c->istft_n_fft, VO = NF + 2, NL = c->vocos_num_layers;
+    const double stack_mac = NL * (3 * VC + 2 * VC * VH);
+    const double stack_el = NL * (2 * VC + 2 * VC + (VC + VH) + (VH + 2 * VC));  // dw, LN, pw1, pw2+res
+    const double mac = I * VC + stack_mac + VC * VO + VO * NF;
+    const double el = (I + VC) + 2 * VC + stack_el + 2 * VC + (VC + VO) + 2 * VO + (VO + NF) +
+                      (NF + c->istft_hop_length);
+    if (flops_per_frame) *flops_per_frame = 2 * mac;
+    if (bytes_per_frame_perconv) *bytes_per_frame_perconv = 4 * el;
+    if (mrf_flops_per_frame) *mrf_flops_per_frame = 2 * stack_mac;
+    if (mrf_bytes_per_frame_perconv) *mrf_bytes_per_frame_perconv = 4 * stack_el;
+    return WETTS_OK;
+  }
   // SURVEY.md §8(d) formulas (per input frame; L = samples per frame at the current stage)
   double mac = 0, elems = 0, mrf_mac = 0, mrf_elems = 0;
   const double C0 = c->upsample_initial_channel, I = c->inter_channels;

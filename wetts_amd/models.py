@@ -57,9 +57,12 @@ class SynthesizerTrn:
                      upsample_kernel_sizes=upsample_kernel_sizes, gin_channels=gin_channels,
                      use_sdp=use_sdp, vocoder_type=vocoder_type, **kwargs)
         self.cfg = _config.make_config(model, n_vocab, n_speakers)
+        self.vocoder_type = vocoder_type
         self.hop_length = 1
         for u in upsample_rates:
             self.hop_length *= int(u)
+        if vocoder_type == "vocos":  # samples per frame = the iSTFT hop (decoders.py:279,304)
+            self.hop_length = int(self.cfg.istft_hop_length)
         self.device = torch.device("cpu")
         self._blob = None      # CPU float32 blob (weights live here until .to(device))
         self._handle = None    # wetts_model_t*

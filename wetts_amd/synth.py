@@ -45,6 +45,10 @@ def _std_for(name, shape, cfg):
         return 0.5 / math.sqrt(shape[1] * shape[2])
     if name == "dec.conv_post.weight":
         return 0.7 / math.sqrt(shape[1] * shape[2])
+    if name.endswith(".scale"):  # ConvNeXtLayer.scale: the reference initialises it to 1/num_layers
+        return 0.0
+    if name == "dec.out_conv.weight":  # log-magnitude / phase head: keep exp() well below its clamp
+        return 0.5 / math.sqrt(shape[1])
     if name.endswith("cond.weight") or name.endswith("cond_layer.weight"):
         return 0.3 / math.sqrt(shape[1])
     if name.endswith("post.weight"):
@@ -70,6 +74,8 @@ def make_state_dict(cfg, seed=0):
             sd[name] = 1.0 + 0.1 * rn(*shape)
         elif name.endswith(".beta") or name.endswith(".bias"):
             sd[name] = 0.05 * rn(*shape)
+        elif name.endswith(".scale"):
+            sd[name] = (1.0 / max(1, cfg.vocos_num_layers)) * (1.0 + 0.2 * rn(*shape))
         elif name == "dp.flows.0.m":
             sd[name] = 0.1 * rn(*shape)
         elif name == "dp.flows.0.logs":
