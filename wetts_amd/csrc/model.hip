@@ -1137,6 +1137,14 @@ static int32_t run_vocos(const wetts_model* m, const float* z, int64_t z_bs, int
     WETTS_TRY(launch_conv(m->v_in, p, s));
   }
   WETTS_TRY(k_layernorm(t1, nullptr, m->v_npre_g, m->v_npre_b, nullptr, nullptr, 0, B, VC, F, h, s));
+  // live timing of the dominant class (the ConvNeXt stack = 99 % of the flops), same mechanism as
+  // the HiFi-GAN MRF events
+  hipEvent_t lv0 = nullptr, lv1 = nullptr;
+  if (m->mrf_timing) {
+    WETTS_HIP_CHECK(hipEventCreate(&lv0));
+    WETTS_HIP_CHECK(hipEventCreate(&lv1));
+    WETTS_HIP_CHECK(hipEventRecord(lv0, s));
+  }
   for (const ConvNeXt& cn : m->v_layers) {
     WETTS_TRY(k_dwconv(h, nullptr, cn.dw_w, cn.dw_b, 3, 1, B, VC, F, t1, s));
     WETTS_TRY(k_layernorm(t1, nullptr, cn.ng, cn.nb, nullptr, nullptr, 0, B, VC, F, t2, s));
@@ -1149,6 +1157,12 @@ static int32_t run_vocos(const wetts_model* m, const float* z, int64_t z_bs, int
     p2.r_cs = F;
     WETTS_TRY(launch_conv(cn.pw2, p2, s));
     float* sw = h; h = t1; t1 = sw;
+  }
+  if (m->mrf_timing) {
+    WETTS_HIP_CHECK(hipEventRecord(lv1, s));
+    m->mrf_events.emplace_back(lv0, lv1);
+    m->mrf_launches += 2 * (int64_t)m->v_layers.size();  // the two pointwise GEMMs per layer
+    m->mrf_calls += 1;
   }
   WETTS_TRY(k_layernorm(h, nullptr, m->v_npost_g, m->v_npost_b, nullptr, nullptr, 0, B, VC, F, t2, s));
   WETTS_TRY(launch_conv(m->v_out, conv_io(t2, VC, F, spec, VO, B), s));
