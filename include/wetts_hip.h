@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WETTS_ABI_VERSION 2
+#define WETTS_ABI_VERSION 3
 
 #define WETTS_OK 0
 #define WETTS_E_INVALID (-1)   /* bad argument / unsupported configuration */
@@ -80,7 +80,9 @@ typedef struct wetts_config {
   int32_t istft_n_fft;       /* 1024 (vocos_out_channels = n_fft + 2) */
   int32_t istft_hop_length;  /* 256  */
   int32_t istft_win_length;  /* 1024 (must equal n_fft) */
-  int32_t reserved[1];
+  /* VITS2 flows (models.py:73-79, flows.py:340-360): 0 = ResidualCouplingLayer, 1 = "pre_conv"
+   * (ResidualCouplingTransformersLayer, flows.py:95-177: 2-layer window-less Encoder on x0) */
+  int32_t transformer_flows;
 } wetts_config_t;
 
 typedef struct wetts_model wetts_model_t; /* opaque */

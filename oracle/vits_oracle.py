@@ -65,21 +65,23 @@ def rel_attention(W, pre, x, attn_mask, n_heads, window):
     v = v.view(b, n_heads, dk, t).transpose(2, 3)
     qs = q / math.sqrt(dk)
     scores = torch.matmul(qs, k.transpose(-2, -1))  # [b,h,t,t]
-    Ek = W[pre + ".emb_rel_k"][0]  # [2w+1, dk] shared across heads
-    Ev = W[pre + ".emb_rel_v"][0]
-    rel = torch.matmul(qs, Ek.t())  # [b,h,t,2w+1]
     idx = torch.arange(t)
-    for r in range(-window, window + 1):
-        i = idx[(idx + r >= 0) & (idx + r < t)]
-        if i.numel():
-            scores[:, :, i, i + r] += rel[:, :, i, r + window]
+    if window is not None:  # window_size=None (the VITS2 flow encoders): plain attention
+        Ek = W[pre + ".emb_rel_k"][0]  # [2w+1, dk] shared across heads
+        Ev = W[pre + ".emb_rel_v"][0]
+        rel = torch.matmul(qs, Ek.t())  # [b,h,t,2w+1]
+        for r in range(-window, window + 1):
+            i = idx[(idx + r >= 0) & (idx + r < t)]
+            if i.numel():
+                scores[:, :, i, i + r] += rel[:, :, i, r + window]
     scores = scores.masked_fill(attn_mask == 0, -1e4)
     p = F.softmax(scores, dim=-1)
     out = torch.matmul(p, v)  # [b,h,t,dk]
-    for r in range(-window, window + 1):
-        i = idx[(idx + r >= 0) & (idx + r < t)]
-        if i.numel():
-            out[:, :, i, :] += p[:, :, i, i + r].unsqueeze(-1) * Ev[r + window]
+    if window is not None:
+        for r in range(-window, window + 1):
+            i = idx[(idx + r >= 0) & (idx + r < t)]
+            if i.numel():
+                out[:, :, i, :] += p[:, :, i, i + r].unsqueeze(-1) * Ev[r + window]
     out = out.transpose(2, 3).contiguous().view(b, d, t)
     return conv1d(W, pre + ".conv_o", out)
 
@@ -93,6 +95,20 @@ def ffn(W, pre, x, x_mask, k):
     return h * x_mask
 
 
+def encoder_stack(W, pre, x, x_mask, n_layers, n_heads, window, k):
+    """attentions.Encoder.forward (attentions.py:70-87), speaker branch off."""
+    attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
+    x = x * x_mask
+    for l in range(n_layers):
+        y = rel_attention(W, f"{pre}.attn_layers.{l}", x, attn_mask, n_heads, window)
+        x = layer_norm_c(x + y, W[f"{pre}.norm_layers_1.{l}.gamma"],
+                         W[f"{pre}.norm_layers_1.{l}.beta"])
+        y = ffn(W, f"{pre}.ffn_layers.{l}", x, x_mask, k)
+        x = layer_norm_c(x + y, W[f"{pre}.norm_layers_2.{l}.gamma"],
+                         W[f"{pre}.norm_layers_2.{l}.beta"])
+    return x * x_mask
+
+
 def text_encoder(W, cfg, x_ids, x_lengths):
     """TextEncoder.forward (encoders.py:47-57) + Encoder.forward (attentions.py:70-87)."""
     H = cfg["hidden_channels"]
@@ -100,17 +116,8 @@ def text_encoder(W, cfg, x_ids, x_lengths):
     x = x.transpose(1, -1)
     x_mask = sequence_mask(x_lengths, x.shape[2]).unsqueeze(1).to(x.dtype)
     x = x * x_mask
-    attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
-    x = x * x_mask
-    for l in range(cfg["n_layers"]):
-        y = rel_attention(W, f"enc_p.encoder.attn_layers.{l}", x, attn_mask, cfg["n_heads"],
-                          cfg["window_size"])
-        x = layer_norm_c(x + y, W[f"enc_p.encoder.norm_layers_1.{l}.gamma"],
-                         W[f"enc_p.encoder.norm_layers_1.{l}.beta"])
-        y = ffn(W, f"enc_p.encoder.ffn_layers.{l}", x, x_mask, cfg["kernel_size"])
-        x = layer_norm_c(x + y, W[f"enc_p.encoder.norm_layers_2.{l}.gamma"],
-                         W[f"enc_p.encoder.norm_layers_2.{l}.beta"])
-    x = x * x_mask
+    x = encoder_stack(W, "enc_p.encoder", x, x_mask, cfg["n_layers"], cfg["n_heads"],
+                      cfg["window_size"], cfg["kernel_size"])
     stats = conv1d(W, "enc_p.proj", x) * x_mask
     m, logs = torch.split(stats, cfg["inter_channels"], dim=1)
     return x, m, logs, x_mask
@@ -292,7 +299,13 @@ def flow_reverse(W, cfg, z_p, y_mask, g):
         x = torch.flip(x, [1])
         pre = f"flow.flows.{2 * f}"
         x0, x1 = x[:, :half], x[:, half:]
-        h = conv1d(W, pre + ".pre", x0) * y_mask
+        if cfg.get("transformer_flows", 0) == 1:
+            # "pre_conv" = ResidualCouplingTransformersLayer (flows.py:95-177): a 2-layer,
+            # 2-head, window-less Encoder on x0 with a residual, ahead of `pre`
+            x0_ = encoder_stack(W, pre + ".pre_transformer", x0 * y_mask, y_mask, 2, 2, None, 3)
+            h = conv1d(W, pre + ".pre", x0_ + x0) * y_mask
+        else:
+            h = conv1d(W, pre + ".pre", x0) * y_mask
         h = wn(W, pre + ".enc", h, y_mask, g, H, cfg["flow_wn_layers"], cfg["flow_kernel_size"])
         m = conv1d(W, pre + ".post", h) * y_mask
         x1 = (x1 - m) * y_mask

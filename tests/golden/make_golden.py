@@ -37,6 +37,9 @@ CASES = {
     # VocosGenerator (decoders.py:251-308); iSTFT through the documented torch.istft stand-in
     "tiny_vocos_b2": ("tiny_vocos", 40, 2, 2, 10, [10, 6], 15, 105, (0.667, 1.0, 0.8)),
     "vocos_b2": ("vocos", 64, 2, 2, 8, [8, 5], 23, 203, (0.667, 1.0, 0.8)),
+    # VITS2 "pre_conv" transformer flows + SDP + Vocos (examples/baker/configs/vits2_vocos_v1.json)
+    "tiny_vits2_vocos_b2": ("tiny_vits2_vocos", 40, 2, 2, 10, [10, 7], 16, 106, (0.667, 1.0, 0.8)),
+    "vits2_vocos_b2": ("vits2_vocos_v1", 64, 1, 2, 8, [8, 6], 24, 204, (0.667, 1.0, 0.8)),
 }
 ONLY = os.environ.get("WETTS_GOLDEN_ONLY")  # comma-separated case names (default: all)
 
@@ -49,8 +52,10 @@ def build_reference(model_name, n_vocab, n_speakers, sd):
     missing, unexpected = net.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected
     # everything the synthetic checkpoint does not carry must be outside the infer() path
+    # (post_transformer: built by ResidualCouplingTransformersLayer but its use is commented out,
+    # flows.py:152-154)
     bad = [k for k in missing if not (k.startswith("enc_q.") or k.startswith("dp.post_")
-                                      or k.startswith("dp.flows.1."))]
+                                      or k.startswith("dp.flows.1.") or ".post_transformer." in k)]
     assert not bad, bad
     return net
 

@@ -23,10 +23,11 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert _lib.load().wetts_abi_version() == 2
+    assert _lib.load().wetts_abi_version() == 3
 
 
-@pytest.mark.parametrize("mname", ["v1", "v2", "v3", "stress48k", "tiny", "tiny_dp", "vocos", "tiny_vocos"])
+@pytest.mark.parametrize("mname", ["v1", "v2", "v3", "stress48k", "tiny", "tiny_dp", "vocos", "tiny_vocos", "vits2_vocos_v1",
+                                   "tiny_vits2_vocos"])
 def test_blob_layout_is_consistent(mname):
     cfg = config.make_config(config.MODEL_CONFIGS[mname], 100, 4)
     lay = checkpoint.blob_layout(cfg)
@@ -47,7 +48,7 @@ def test_layout_names_and_shapes_match_reference_state_dict():
         pytest.skip("reference not present on this box")
     import contextlib, io
     S, *_ = ref_import.import_reference()
-    for mname, nspk in [("v1", 1), ("v3", 2), ("vocos", 2)]:
+    for mname, nspk in [("v1", 1), ("v3", 2), ("vocos", 2), ("vits2_vocos_v1", 1)]:
         with contextlib.redirect_stdout(io.StringIO()):
             net = S(50, 513, 32, n_speakers=nspk, **config.MODEL_CONFIGS[mname])
         ref = {k: tuple(v.shape) for k, v in checkpoint.fold_weight_norm(net.state_dict()).items()}
@@ -58,7 +59,8 @@ def test_layout_names_and_shapes_match_reference_state_dict():
         # and nothing on the infer path is left out
         ours = {n for n, *_ in checkpoint.blob_layout(cfg)}
         skipped = [k for k in ref if k not in ours and not (
-            k.startswith("enc_q.") or k.startswith("dp.post_") or k.startswith("dp.flows.1."))]
+            k.startswith("enc_q.") or k.startswith("dp.post_") or k.startswith("dp.flows.1.")
+            or ".post_transformer." in k)]  # post_transformer: built but unused (flows.py:152-154)
         assert not skipped, skipped
 
 
@@ -96,7 +98,12 @@ def test_pack_blob_roundtrip_and_errors():
 
 def test_config_validation_and_unsupported_options():
     with pytest.raises(NotImplementedError):
-        config.make_config(dict(config.MODEL_CONFIGS["v1"], use_transformer_flows=True), 10, 1)
+        config.make_config(dict(config.MODEL_CONFIGS["v1"], use_transformer_flows=True,
+                                transformer_flow_type="fft"), 10, 1)
+    with pytest.raises(NotImplementedError):
+        config.make_config(dict(config.MODEL_CONFIGS["v1"], use_spk_conditioned_encoder=True), 10, 1)
+    assert config.make_config(dict(config.MODEL_CONFIGS["v1"], use_transformer_flows=True), 10,
+                              1).transformer_flows == 1  # default type "pre_conv"
     with pytest.raises(NotImplementedError):
         config.make_config(dict(config.MODEL_CONFIGS["v1"], vocoder_type="bigvgan"), 10, 1)
     vc = config.make_config(dict(config.MODEL_CONFIGS["v1"], vocoder_type="vocos"), 10, 1)

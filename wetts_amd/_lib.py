@@ -57,7 +57,7 @@ class Config(C.Structure):
         ("istft_n_fft", C.c_int32),
         ("istft_hop_length", C.c_int32),
         ("istft_win_length", C.c_int32),
-        ("reserved", C.c_int32 * 1),
+        ("transformer_flows", C.c_int32),
     ]
 
 
@@ -126,7 +126,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError => header / library mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.wetts_abi_version() != 2:
+    if lib.wetts_abi_version() != 3:
         raise WettsError("libwetts_hip.so ABI version mismatch")
     _lib = lib
     return lib

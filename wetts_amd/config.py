@@ -101,7 +101,16 @@ MODEL_CONFIGS["tiny_vocos"] = dict(
     kernel_size=3, p_dropout=0.1, gin_channels=64, **_VOCOS_HIFI_FIELDS, vocoder_type="vocos",
     vocos_channels=64, vocos_h_channels=160, vocos_out_channels=66, vocos_num_layers=2,
     vocos_istft_config=dict(n_fft=64, hop_length=16, win_length=64, center=True), use_sdp=False)
-SAMPLING_RATES = {"v1": 22050, "v2": 22050, "v3": 16000, "stress48k": 48000, "tiny": 22050,
+# examples/baker/configs/vits2_vocos_v1.json:29-65 -- the config behind the reference's only
+# published numbers (runtime/cpu_triton_stream/README.md): VITS2 "pre_conv" transformer flows,
+# SDP, Vocos head, 24 kHz
+MODEL_CONFIGS["vits2_vocos_v1"] = dict(
+    MODEL_CONFIGS["vocos"], use_transformer_flows=True, transformer_flow_type="pre_conv",
+    use_spk_conditioned_encoder=False, use_sdp=True, gin_channels=256)
+MODEL_CONFIGS["tiny_vits2_vocos"] = dict(
+    MODEL_CONFIGS["tiny_vocos"], use_transformer_flows=True, transformer_flow_type="pre_conv",
+    use_sdp=True)
+SAMPLING_RATES = {"vits2_vocos_v1": 24000, "tiny_vits2_vocos": 24000, "v1": 22050, "v2": 22050, "v3": 16000, "stress48k": 48000, "tiny": 22050,
                   "tiny_dp": 16000, "vocos": 16000, "tiny_vocos": 16000}
 
 
@@ -112,7 +121,6 @@ def _get(model, key, default=None):
 
 
 _UNSUPPORTED = {
-    "use_transformer_flows": "VITS2 transformer flows (flows.py:16-324) are SURVEY §8(f) 'next'",
     "use_spk_conditioned_encoder": "speaker-conditioned encoder (attentions.py:39-48) is 'next'",
 }
 
@@ -132,6 +140,13 @@ def make_config(model, n_vocab, n_speakers):
         raise NotImplementedError(f"vocoder_type={voc!r}: only 'hifigan' (decoders.py:15-88) and "
                                   "'vocos' (decoders.py:251-308) exist in the reference")
     c = _lib.Config()
+    if _get(model, "use_transformer_flows", False):
+        ft = _get(model, "transformer_flow_type", "pre_conv")  # models.py:74-75 default
+        if ft != "pre_conv":
+            raise NotImplementedError(
+                f"transformer_flow_type={ft!r}: only 'pre_conv' (flows.py:95-177, the type the "
+                "reference's vits2 configs use) is implemented")
+        c.transformer_flows = 1
     if voc == "vocos":
         ic = _get(model, "vocos_istft_config", None) or {}
         c.vocoder_type = 1

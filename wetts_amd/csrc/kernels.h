@@ -97,6 +97,13 @@ int32_t k_istft_ola(const float* frames, int B, int n_fft, int hop, int F, float
 int32_t k_scale_rows(const float* a, const float* scale, int rows, int cols, float* out,
                      hipStream_t s);
 
+// VITS2 "pre_conv" flow (flows.py:145-147): x0 = Flip(x)[:, :C/2] = x[:, C-1 .. C/2] copied out
+// in natural order, raw (x0) and masked (x0m = x0 * mask)
+int32_t k_flip_half(const float* x, const float* mask, int B, int C, int T, float* x0, float* x0m,
+                    hipStream_t s);
+// out = a + b (out may alias a)
+int32_t k_add(const float* a, const float* b, int64_t n, float* out, hipStream_t s);
+
 // a5 windowed relative-position attention (attentions.py:235-282), banded form.
 //   qkv: q,k,v [B,H*dk,T];  scores workspace [B,H,T,T];  out [B,H*dk,T]
 int32_t k_rel_attention(const float* q, const float* k, const float* v, const float* mask,

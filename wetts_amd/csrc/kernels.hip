@@ -806,4 +806,40 @@ int32_t k_scale_rows(const float* a, const float* scale, int rows, int cols, flo
   return WETTS_OK;
 }
 
+
+__global__ void flip_half_kernel(const float* __restrict__ x, const float* __restrict__ mask, int B,
+                                 int C, int T, float* __restrict__ x0, float* __restrict__ x0m) {
+  const int half = C / 2;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * half * T) return;
+  const int t = (int)(idx % T);
+  const int c = (int)((idx / T) % half);
+  const int b = (int)(idx / ((int64_t)T * half));
+  const float v = x[((int64_t)b * C + (C - 1 - c)) * T + t];
+  x0[idx] = v;
+  x0m[idx] = v * mask[(int64_t)b * T + t];
+}
+
+int32_t k_flip_half(const float* x, const float* mask, int B, int C, int T, float* x0, float* x0m,
+                    hipStream_t s) {
+  int64_t n = (int64_t)B * (C / 2) * T;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(flip_half_kernel, grid1d(n, 256), dim3(256), 0, s, x, mask, B, C, T, x0, x0m);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                           float* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) out[idx] = a[idx] + b[idx];
+}
+
+int32_t k_add(const float* a, const float* b, int64_t n, float* out, hipStream_t s) {
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(add_kernel, grid1d(n, 256), dim3(256), 0, s, a, b, n, out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
 }  // namespace wetts

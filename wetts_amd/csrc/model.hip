@@ -88,6 +88,10 @@ static int validate_config(const wetts_config_t* c) {
                 "bad flow config");
   WETTS_REQUIRE(c->sdp_n_flows >= 2, "bad sdp_n_flows");
   WETTS_REQUIRE(c->vocoder_type == 0 || c->vocoder_type == 1, "vocoder_type must be 0 (hifigan) or 1 (vocos)");
+  WETTS_REQUIRE(c->transformer_flows == 0 || c->transformer_flows == 1,
+                "transformer_flows must be 0 or 1 (pre_conv)");
+  WETTS_REQUIRE(c->transformer_flows == 0 || (c->inter_channels / 2) % 2 == 0,
+                "pre_conv flows need inter_channels/2 divisible by their 2 heads");
   if (c->vocoder_type == 1) {
     WETTS_REQUIRE(c->vocos_channels > 0 && c->vocos_h_channels > 0 && c->vocos_num_layers >= 1 &&
                       c->vocos_num_layers <= 64, "bad vocos channels / layers");
@@ -183,6 +187,26 @@ static void build_layout(const wetts_config_t* c, Layout& L) {
 
   for (int f = 0; f < c->flow_n_flows; ++f) {
     std::string p = S("flow.flows.%d", 2 * f);
+    if (c->transformer_flows == 1) {
+      // Encoder(half, half, n_heads=2, n_layers=2, kernel_size=3, window_size=None), flows.py:111-119
+      const int Hh = I / 2;
+      for (int l = 0; l < 2; ++l) {
+        std::string a = p + S(".pre_transformer.attn_layers.%d", l);
+        for (const char* n : {"conv_q", "conv_k", "conv_v", "conv_o"}) {
+          L.add(a + "." + n + ".weight", Hh, Hh, 1);
+          L.add(a + "." + n + ".bias", Hh);
+        }
+        L.add(p + S(".pre_transformer.norm_layers_1.%d.gamma", l), Hh);
+        L.add(p + S(".pre_transformer.norm_layers_1.%d.beta", l), Hh);
+        std::string ff = p + S(".pre_transformer.ffn_layers.%d", l);
+        L.add(ff + ".conv_1.weight", Hh, Hh, 3);
+        L.add(ff + ".conv_1.bias", Hh);
+        L.add(ff + ".conv_2.weight", Hh, Hh, 3);
+        L.add(ff + ".conv_2.bias", Hh);
+        L.add(p + S(".pre_transformer.norm_layers_2.%d.gamma", l), Hh);
+        L.add(p + S(".pre_transformer.norm_layers_2.%d.beta", l), Hh);
+      }
+    }
     L.add(p + ".pre.weight", H, I / 2, 1);
     L.add(p + ".pre.bias", H);
     for (int i = 0; i < c->flow_wn_layers; ++i) {
@@ -282,6 +306,7 @@ struct FlowW {
   PackedConv pre, post;
   std::vector<PackedConv> in_layers, res_skip;
   const float *cond_w = nullptr, *cond_b = nullptr;
+  std::vector<EncLayer> pre_tr;  // VITS2 "pre_conv": Encoder on x0 (flows.py:111-119), else empty
 };
 
 struct RB {
@@ -529,6 +554,26 @@ static int32_t build_model(wetts_model* m, hipStream_t s) {
     }
     fw.cond_w = m->T(p + ".enc.cond_layer.weight");
     fw.cond_b = m->T(p + ".enc.cond_layer.bias");
+    if (c->transformer_flows == 1) {
+      const int Hh = I / 2;
+      fw.pre_tr.resize(2);
+      for (int l = 0; l < 2; ++l) {
+        EncLayer& e = fw.pre_tr[l];
+        std::string a = p + S(".pre_transformer.attn_layers.%d", l);
+        e.rel_k = e.rel_v = nullptr;  // window_size=None
+        WETTS_TRY(pack(m, a + ".conv_q.weight", a + ".conv_q.bias", Hh, Hh, 1, 1, 0, 0, 0, s, &e.q));
+        WETTS_TRY(pack(m, a + ".conv_k.weight", a + ".conv_k.bias", Hh, Hh, 1, 1, 0, 0, 0, s, &e.k));
+        WETTS_TRY(pack(m, a + ".conv_v.weight", a + ".conv_v.bias", Hh, Hh, 1, 1, 0, 0, 0, s, &e.v));
+        WETTS_TRY(pack(m, a + ".conv_o.weight", a + ".conv_o.bias", Hh, Hh, 1, 1, 0, 0, 0, s, &e.o));
+        e.n1g = m->T(p + S(".pre_transformer.norm_layers_1.%d.gamma", l));
+        e.n1b = m->T(p + S(".pre_transformer.norm_layers_1.%d.beta", l));
+        e.n2g = m->T(p + S(".pre_transformer.norm_layers_2.%d.gamma", l));
+        e.n2b = m->T(p + S(".pre_transformer.norm_layers_2.%d.beta", l));
+        std::string ff = p + S(".pre_transformer.ffn_layers.%d", l);
+        WETTS_TRY(pack(m, ff + ".conv_1.weight", ff + ".conv_1.bias", Hh, Hh, 3, 1, 1, 0, 0, s, &e.f1));
+        WETTS_TRY(pack(m, ff + ".conv_2.weight", ff + ".conv_2.bias", Hh, Hh, 3, 1, 1, 0, 0, s, &e.f2));
+      }
+    }
   }
 
   if (c->vocoder_type == 1) return build_vocos(m, s);
@@ -624,8 +669,10 @@ static int64_t ws_dp(const wetts_config_t* c, int B, int Tx) {
 
 static int64_t ws_flow(const wetts_config_t* c, int B, int Ty) {
   const int64_t H = c->hidden_channels, I = c->inter_channels;
-  return 2 * A256(B * I * Ty) + 3 * A256(B * H * Ty) + 2 * A256(B * 2 * H * Ty) +
-         A256(B * (I / 2) * Ty) + A256(B * 2 * H * c->flow_wn_layers);
+  int64_t n = 2 * A256(B * I * Ty) + 3 * A256(B * H * Ty) + 2 * A256(B * 2 * H * Ty) +
+              A256(B * (I / 2) * Ty) + A256(B * 2 * H * c->flow_wn_layers);
+  if (c->transformer_flows == 1) n += 9 * A256(B * (I / 2) * Ty) + A256((int64_t)B * 2 * Ty * Ty);
+  return n;
 }
 
 static int64_t dec_max_elems(const wetts_config_t* c, int B, int L) {
@@ -795,6 +842,49 @@ int32_t wetts_speaker_embedding(const wetts_model_t* m, const int64_t* sid, int3
 }
 
 // ---------------------------------------------------------------------------------------------
+namespace wetts {
+// attentions.Encoder.forward (attentions.py:70-87) on xa [B,H,T] in place (x already masked):
+// n x { x = LN1(x + MHA(x)); x = LN2(x + FFN(x)) }, final x * mask fused into the last LayerNorm.
+// window < 0: no relative-position terms (window_size=None).  Scratch: q,k,v,att,y,xb [B,H,T],
+// hid [B,F,T], sc [B,nh,T,T].
+static int32_t run_enc_layers(const std::vector<EncLayer>& layers, float* xa, const float* x_mask,
+                              int B, int H, int F, int nh, int window, int T, float* q, float* k,
+                              float* v, float* att, float* y, float* hid, float* sc, float* xb,
+                              hipStream_t s) {
+  const int dk = H / nh, n = (int)layers.size();
+  for (int l = 0; l < n; ++l) {
+    const EncLayer& e = layers[l];
+    const bool last = (l == n - 1);
+    WETTS_TRY(launch_conv(e.q, conv_io(xa, H, T, q, H, B), s));
+    WETTS_TRY(launch_conv(e.k, conv_io(xa, H, T, k, H, B), s));
+    WETTS_TRY(launch_conv(e.v, conv_io(xa, H, T, v, H, B), s));
+    WETTS_TRY(k_rel_attention(q, k, v, x_mask, e.rel_k, e.rel_v, window, B, nh, dk, T, sc, att, s));
+    WETTS_TRY(launch_conv(e.o, conv_io(att, H, T, y, H, B), s));
+    // x = norm_layers_1(x + y)
+    WETTS_TRY(k_layernorm(xa, y, e.n1g, e.n1b, nullptr, nullptr, 0, B, H, T, xb, s));
+    // FFN: conv_1(pad(x*mask)) -> relu -> conv_2(pad(.*mask)) * mask
+    {
+      ConvParams p = conv_io(xb, H, T, hid, F, B);
+      p.in_mask = x_mask;
+      p.in_mask_stride = T;
+      p.out_act = OUT_RELU;
+      WETTS_TRY(launch_conv(e.f1, p, s));
+    }
+    {
+      ConvParams p = conv_io(hid, F, T, y, H, B);
+      p.in_mask = x_mask;
+      p.in_mask_stride = T;
+      p.out_mask = x_mask;
+      p.out_mask_stride = T;
+      WETTS_TRY(launch_conv(e.f2, p, s));
+    }
+    // x = norm_layers_2(x + y); the final `x = x * x_mask` is fused into the last layer
+    WETTS_TRY(k_layernorm(xb, y, e.n2g, e.n2b, nullptr, last ? x_mask : nullptr, 0, B, H, T, xa, s));
+  }
+  return WETTS_OK;
+}
+}  // namespace wetts
+
 int32_t wetts_text_encoder(const wetts_model_t* m, const int64_t* x, const int64_t* x_lengths,
                            int32_t B, int32_t Tx, float* x_enc, float* stats, float* x_mask,
                            void* workspace, int64_t workspace_bytes, void* stream) {
@@ -803,7 +893,7 @@ int32_t wetts_text_encoder(const wetts_model_t* m, const int64_t* x, const int64
   hipStream_t s = (hipStream_t)stream;
   const wetts_config_t* c = &m->cfg;
   const int H = c->hidden_channels, F = c->filter_channels, I = c->inter_channels;
-  const int nh = c->n_heads, dk = H / nh;
+  const int nh = c->n_heads;
   Bump ws(workspace, workspace_bytes);
   float* q = ws.take<float>((int64_t)B * H * Tx);
   float* k = ws.take<float>((int64_t)B * H * Tx);
@@ -820,37 +910,8 @@ int32_t wetts_text_encoder(const wetts_model_t* m, const int64_t* x, const int64
   // x = emb(x)*sqrt(H), masked (encoders.py:48-53; Encoder.forward x = x * x_mask, attentions.py:72)
   float* xa = x_enc;  // current activations live in xa
   WETTS_TRY(k_embed_mask(x, x_lengths, m->emb, c->n_vocab, B, H, Tx, xa, x_mask, s));
-  for (int l = 0; l < c->n_layers; ++l) {
-    const EncLayer& e = m->enc[l];
-    const bool last = (l == c->n_layers - 1);
-    WETTS_TRY(launch_conv(e.q, conv_io(xa, H, Tx, q, H, B), s));
-    WETTS_TRY(launch_conv(e.k, conv_io(xa, H, Tx, k, H, B), s));
-    WETTS_TRY(launch_conv(e.v, conv_io(xa, H, Tx, v, H, B), s));
-    WETTS_TRY(k_rel_attention(q, k, v, x_mask, e.rel_k, e.rel_v, c->window_size, B, nh, dk, Tx, sc,
-                              att, s));
-    WETTS_TRY(launch_conv(e.o, conv_io(att, H, Tx, y, H, B), s));
-    // x = norm_layers_1(x + y)
-    WETTS_TRY(k_layernorm(xa, y, e.n1g, e.n1b, nullptr, nullptr, 0, B, H, Tx, xb, s));
-    // FFN: conv_1(pad(x*mask)) -> relu -> conv_2(pad(.*mask)) * mask
-    {
-      ConvParams p = conv_io(xb, H, Tx, hid, F, B);
-      p.in_mask = x_mask;
-      p.in_mask_stride = Tx;
-      p.out_act = OUT_RELU;
-      WETTS_TRY(launch_conv(e.f1, p, s));
-    }
-    {
-      ConvParams p = conv_io(hid, F, Tx, y, H, B);
-      p.in_mask = x_mask;
-      p.in_mask_stride = Tx;
-      p.out_mask = x_mask;
-      p.out_mask_stride = Tx;
-      WETTS_TRY(launch_conv(e.f2, p, s));
-    }
-    // x = norm_layers_2(x + y); the final `x = x * x_mask` is fused into the last layer
-    WETTS_TRY(k_layernorm(xb, y, e.n2g, e.n2b, nullptr, last ? x_mask : nullptr, 0, B, H, Tx, xa,
-                          s));
-  }
+  WETTS_TRY(run_enc_layers(m->enc, xa, x_mask, B, H, F, nh, c->window_size, Tx, q, k, v, att, y,
+                           hid, sc, xb, s));
   if (c->n_layers == 0) {
     // Encoder with no layers still masks its input; embed_mask already did.
   }
@@ -1045,6 +1106,15 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
   float* rs = ws.take<float>((int64_t)B * 2 * H * Ty);
   float* mm = ws.take<float>((int64_t)B * (I / 2) * Ty);
   float* gl = ws.take<float>((int64_t)B * 2 * H * NL);
+  float *tx0 = nullptr, *txm = nullptr, *tq = nullptr, *tk = nullptr, *tv = nullptr,
+        *tatt = nullptr, *ty = nullptr, *thid = nullptr, *txb = nullptr, *tsc = nullptr;
+  if (c->transformer_flows == 1) {
+    const int64_t nh2 = (int64_t)B * (I / 2) * Ty;
+    tx0 = ws.take<float>(nh2); txm = ws.take<float>(nh2); tq = ws.take<float>(nh2);
+    tk = ws.take<float>(nh2); tv = ws.take<float>(nh2); tatt = ws.take<float>(nh2);
+    ty = ws.take<float>(nh2); thid = ws.take<float>(nh2); txb = ws.take<float>(nh2);
+    tsc = ws.take<float>((int64_t)B * 2 * Ty * Ty);
+  }
   if (!ws.ok) {
     set_error("flow_reverse: workspace too small");
     return WETTS_E_WORKSPACE;
@@ -1054,7 +1124,20 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
     const FlowW& fw = m->flows[f];
     float* dst = (f == 0) ? z_out : ((cur == xa) ? xb : xa);
     // Flip then ResidualCouplingLayer(reverse): x0 = flipped[:I/2] = cur[I-1 .. I/2]
-    {
+    if (c->transformer_flows == 1) {
+      // VITS2 "pre_conv" (flows.py:145-150): x0_ = pre_transformer(x0 * mask, mask) + x0,
+      // h = pre(x0_) * mask.  x0 is materialised (channel-reversed half) because the encoder
+      // layers work in place.
+      const int Hh = I / 2;
+      WETTS_TRY(k_flip_half(cur, y_mask, B, I, Ty, tx0, txm, s));  // raw x0, and x0 * mask
+      WETTS_TRY(run_enc_layers(fw.pre_tr, txm, y_mask, B, Hh, Hh, 2, -1, Ty, tq, tk, tv, tatt, ty,
+                               thid, tsc, txb, s));
+      WETTS_TRY(k_add(txm, tx0, (int64_t)B * Hh * Ty, txm, s));  // vits2 residual connection
+      ConvParams p = conv_io(txm, Hh, Ty, h, H, B);               // h = pre(x0_) * mask
+      p.out_mask = y_mask;
+      p.out_mask_stride = Ty;
+      WETTS_TRY(launch_conv(fw.pre, p, s));
+    } else {
       ConvParams p = conv_io(cur, I, Ty, h, H, B);  // h = pre(x0) * mask
       p.in_rev_base = I - 1;
       p.out_mask = y_mask;
