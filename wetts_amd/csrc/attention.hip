@@ -96,12 +96,150 @@ __global__ __launch_bounds__(64) void attn_pv_kernel(const float* __restrict__ P
   out[((int64_t)bh * dk + d) * T + i] = acc + rel;
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA path for window-less attention over long sequences (the VITS2 flow encoders run over Ty
+// ~ 800 frames, flows.py:111-119): both contractions on v_mfma_f32_32x32x2_f32 straight from the
+// L2-resident q / k / v (160 KB per head) -- no packing: with S kept transposed the A and B
+// operand loads are stride-1 across lanes.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16a __attribute__((ext_vector_type(16)));
+
+// S[b,h,j,i] = sum_d k[d][j] * (q[d][i] / sqrt(dk)), masked_fill(mask_i * mask_j == 0, -1e4)
+// block = 4 waves = 4 j-blocks of 32 x one i-block of 32;  grid (ceil(T/32), ceil(T/128), B*H)
+__global__ __launch_bounds__(256) void attn_scores_mfma_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ mask,
+    int n_heads, int dk, int T, float qdiv, float* __restrict__ S) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+  const int bh = blockIdx.z, b = bh / n_heads;
+  const int i = blockIdx.x * 32 + (lane & 31);
+  const int jb = (blockIdx.y * 4 + wave) * 32;
+  if (jb >= T) return;
+  const int j = jb + (lane & 31);
+  const float* qb = q + (int64_t)bh * dk * T;
+  const float* kb = k + (int64_t)bh * dk * T;
+  const bool iok = i < T, jok = j < T;
+  f32x16a acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nks = (dk + 1) / 2;
+  const int jcl = jok ? j : 0, icl = iok ? i : 0;
+  for (int k0 = 0; k0 < nks; k0 += 8) {  // loads of 8 k-steps in flight, then their MFMAs
+    float a[8], bq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int d = 2 * (k0 + u) + half;
+      const bool dv = d < dk;
+      const int dc = dv ? d : 0;
+      const float av = kb[(int64_t)dc * T + jcl];
+      const float qv = qb[(int64_t)dc * T + icl];
+      a[u] = (jok && dv) ? av : 0.f;
+      bq[u] = (iok && dv) ? qv / qdiv : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bq[u], acc, 0, 0, 0);
+  }
+  if (!iok) return;
+  const float mi = mask[(int64_t)b * T + i];
+  float* Sb = S + (int64_t)bh * T * T + i;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int jj = jb + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (jj < T) {
+      float sc = acc[r];
+      if (mi * mask[(int64_t)b * T + jj] == 0.f) sc = -1e4f;
+      Sb[(int64_t)jj * T] = sc;
+    }
+  }
+}
+
+// vT[bh][j][d] = v[bh][d][j]
+__global__ void attn_transpose_v_kernel(const float* __restrict__ v, int dk, int T,
+                                        float* __restrict__ vT, int64_t total) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int d = (int)(idx % dk);
+  const int j = (int)((idx / dk) % T);
+  const int64_t bh = idx / ((int64_t)dk * T);
+  vT[idx] = v[(bh * dk + d) * T + j];
+}
+
+// out[bh][d][i] = sum_j vT[j][d] * P[j][i]
+// block = 4 waves = 4 i-blocks of 32 x one d-block of 32;  grid (ceil(T/128), ceil(dk/32), B*H)
+__global__ __launch_bounds__(256) void attn_pv_mfma_kernel(const float* __restrict__ P,
+                                                           const float* __restrict__ vT, int dk,
+                                                           int T, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+  const int bh = blockIdx.z;
+  const int ib = (blockIdx.x * 4 + wave) * 32;
+  if (ib >= T) return;
+  const int i = ib + (lane & 31);
+  const int d = blockIdx.y * 32 + (lane & 31);
+  const bool iok = i < T, dok = d < dk;
+  const float* Pb = P + (int64_t)bh * T * T + (iok ? i : 0);
+  const float* vb = vT + (int64_t)bh * T * dk + (dok ? d : 0);
+  f32x16a acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // 8 k-steps per trip: all 16 loads are issued before the first MFMA (the plain loop exposed one
+  // L2 round trip per k-step), and two accumulators halve the dependent-MFMA chain.  Out-of-range
+  // steps read a clamped address and contribute a zero operand.
+  f32x16a acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+  const int nks = (T + 1) / 2;
+  for (int k0 = 0; k0 < nks; k0 += 8) {
+    float a[8], bp[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = 2 * (k0 + u) + half;
+      const bool jv = j < T;
+      const int jc = jv ? j : 0;
+      const float av = vb[(int64_t)jc * dk];
+      const float bv = Pb[(int64_t)jc * T];
+      a[u] = (dok && jv) ? av : 0.f;
+      bp[u] = (iok && jv) ? bv : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bp[u], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u + 1], bp[u + 1], acc2, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+  if (!iok) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int dd = blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (dd < dk) out[((int64_t)bh * dk + dd) * T + i] = acc[r];
+  }
+}
+
 int32_t k_rel_attention(const float* q, const float* k, const float* v, const float* mask,
                         const float* emb_rel_k, const float* emb_rel_v, int window, int B,
                         int n_heads, int dk, int T, float* scores, float* out, hipStream_t s) {
   if (B * T == 0) return WETTS_OK;
   WETTS_REQUIRE(T <= 65535, "attention length %d too large", T);
   const float qdiv = (float)sqrt((double)dk);
+  if (window < 0) {
+    // window_size=None: no relative-position terms.  `out` doubles as the transposed-v scratch
+    // until the PV kernel overwrites it?  No -- PV reads vT while writing out, so vT lives in the
+    // tail of the score workspace (the caller sizes it B*H*T*T + B*H*dk*T).
+    float* vT = scores + (int64_t)B * n_heads * T * T;
+    hipLaunchKernelGGL(attn_scores_mfma_kernel, dim3(cdiv(T, 32), cdiv(T, 128), B * n_heads),
+                       dim3(256), 0, s, q, k, mask, n_heads, dk, T, qdiv, scores);
+    WETTS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_softmax_kernel, dim3(cdiv(T, 16), B * n_heads), dim3(256), 0, s, T, scores);
+    WETTS_LAUNCH_CHECK();
+    const int64_t nv = (int64_t)B * n_heads * dk * T;
+    hipLaunchKernelGGL(attn_transpose_v_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s,
+                       v, dk, T, vT, nv);
+    WETTS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_pv_mfma_kernel, dim3(cdiv(T, 128), cdiv(dk, 32), B * n_heads),
+                       dim3(256), 0, s, scores, vT, dk, T, out);
+    WETTS_LAUNCH_CHECK();
+    return WETTS_OK;
+  }
   int tb = cdiv(T, 64);
   hipLaunchKernelGGL(attn_scores_kernel, dim3(tb, T, B * n_heads), dim3(64), 0, s, q, k, mask,
                      emb_rel_k, window, n_heads, dk, T, qdiv, scores);

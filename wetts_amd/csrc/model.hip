@@ -671,7 +671,8 @@ static int64_t ws_flow(const wetts_config_t* c, int B, int Ty) {
   const int64_t H = c->hidden_channels, I = c->inter_channels;
   int64_t n = 2 * A256(B * I * Ty) + 3 * A256(B * H * Ty) + 2 * A256(B * 2 * H * Ty) +
               A256(B * (I / 2) * Ty) + A256(B * 2 * H * c->flow_wn_layers);
-  if (c->transformer_flows == 1) n += 9 * A256(B * (I / 2) * Ty) + A256((int64_t)B * 2 * Ty * Ty);
+  if (c->transformer_flows == 1)
+    n += 9 * A256(B * (I / 2) * Ty) + A256((int64_t)B * 2 * Ty * Ty + B * (I / 2) * Ty);
   return n;
 }
 
@@ -1113,7 +1114,7 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
     tx0 = ws.take<float>(nh2); txm = ws.take<float>(nh2); tq = ws.take<float>(nh2);
     tk = ws.take<float>(nh2); tv = ws.take<float>(nh2); tatt = ws.take<float>(nh2);
     ty = ws.take<float>(nh2); thid = ws.take<float>(nh2); txb = ws.take<float>(nh2);
-    tsc = ws.take<float>((int64_t)B * 2 * Ty * Ty);
+    tsc = ws.take<float>((int64_t)B * 2 * Ty * Ty + nh2);  // scores + transposed v (attention.hip)
   }
   if (!ws.ok) {
     set_error("flow_reverse: workspace too small");
