@@ -37,6 +37,7 @@ def med(f, n):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="v1", help="wetts_amd.config.MODEL_CONFIGS key")
     ap.add_argument("--phonemes", type=int, default=64)
     ap.add_argument("--chunk", type=int, default=40)
     ap.add_argument("--pad", type=int, default=10)
@@ -45,7 +46,8 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="one launch per conv (diagnostic)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    net = SynthesizerTrn(256, 513, 32, n_speakers=1, **config.MODEL_CONFIGS["v1"]).to(dev)
+    net = SynthesizerTrn(256, 513, 32, n_speakers=1, **config.MODEL_CONFIGS[args.model]).to(dev)
+    sr = config.SAMPLING_RATES[args.model]
     cfg = net.cfg
     sd = synth.make_state_dict(cfg, seed=0)
     net.load_blob(checkpoint.pack_blob(cfg, sd).to(dev))
@@ -74,7 +76,8 @@ def main():
         return np.concatenate(out)
 
     a0, a1 = stream(dec), stream(decg)  # warm-up (captures the graphs) + equality
-    res = {"phonemes": args.phonemes, "frames": int(L), "audio_s": L * hop / 22050.0,
+    res = {"model": args.model, "sampling_rate": sr, "phonemes": args.phonemes, "frames": int(L),
+           "audio_s": L * hop / float(sr),
            "windows": len(wins), "chunk": args.chunk, "pad": args.pad,
            "graph_equals_plain": bool(np.array_equal(a0, a1)), "samples": int(a0.size)}
     for _ in range(3):
@@ -102,10 +105,10 @@ def main():
         for thr in (1, min(16, os.cpu_count())):  # more threads only oversubscribe this tiny conv
             torch.set_num_threads(thr)
             with torch.no_grad():
-                vo.hifigan(W, cd, zt[:, :, w0[0]:w0[1]], g)
+                vo.decoder(W, cd, zt[:, :, w0[0]:w0[1]], g)
                 t0 = time.perf_counter()
                 for _ in range(3):
-                    vo.hifigan(W, cd, zt[:, :, w0[0]:w0[1]], g)
+                    vo.decoder(W, cd, zt[:, :, w0[0]:w0[1]], g)
                 res[f"cpu_first_window_ms_{thr}thr"] = (time.perf_counter() - t0) / 3 * 1e3
     print(json.dumps(res), flush=True)
 

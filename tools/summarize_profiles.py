@@ -19,7 +19,9 @@ for a, b in [("bench_bf16.json", "bench_bf16.json"), ("bench_f16.json", "bench_f
              ("prof_stats_bf16/r_kernel_stats.csv", "bf16_kernel_stats.csv"),
              ("conv32_fused_pair.txt", "conv32_fused_pair.txt"),
              ("conv16_fused_pair.txt", "conv16_fused_pair.txt"),
-             ("conv_microbench.txt", "conv_microbench.txt")]:
+             ("conv_microbench.txt", "conv_microbench.txt"),
+             ("stream_v1.json", "stream_v1.json"), ("stream_vits2_vocos.json", "stream_vits2_vocos.json"),
+             ("bench_vocos.json", "bench_vocos.json"), ("bench_vits2_vocos.json", "bench_vits2_vocos.json")]:
     if os.path.exists(f"{src}/{a}"):
         shutil.copy(f"{src}/{a}", f"profiles/{tag}_{b}")
 
