@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize("mname", ["v1", "v2", "v3", "stress48k", "tiny", "tiny_dp", "vocos", "tiny_vocos", "vits2_vocos_v1",
-                                   "tiny_vits2_vocos"])
+                                   "tiny_vits2_vocos", "vits2_v1"])
 def test_blob_layout_is_consistent(mname):
     cfg = config.make_config(config.MODEL_CONFIGS[mname], 100, 4)
     lay = checkpoint.blob_layout(cfg)

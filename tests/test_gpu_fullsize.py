@@ -182,3 +182,32 @@ def test_vocos_b16x128_oracle_spot_check_and_stream():
     got = o[:2].cpu().numpy()
     print("vocos full-size abs rms", util.rms(got - ref), "rel", util.rel_rms(got, ref))
     assert util.rms(got - ref) < 1e-4 and util.rel_rms(got, ref) < 2e-3
+
+
+def test_vits2_v1_hifigan_with_transformer_flows_matches_oracle():
+    """examples/baker/configs/vits2_v1.json: VITS2 pre_conv flows in front of the HiFi-GAN v1
+    generator.  Both halves are pinned to the reference separately (vits2_vocos_b2, v1_b2 golden
+    vectors); here the combination runs at B=4 x 24 phonemes against the oracle's infer()."""
+    from oracle import vits_oracle as vo
+    from wetts_amd import checkpoint
+    net, sd = _net("vits2_v1", 80, 1, seed=3)
+    g = torch.Generator().manual_seed(4)
+    B, Tx = 4, 24
+    x = torch.randint(0, 80, (B, Tx), generator=g)
+    xl = torch.tensor([24, 17, 24, 9])
+    sid = torch.zeros(B, dtype=torch.long)
+    eps_w = torch.randn(B, 2, Tx, generator=g)
+    o0, _, ym0, _ = _run(net, x, xl, sid, eps_w)
+    Ty = ym0.shape[-1]
+    eps_z = torch.randn(B, 192, Ty, generator=g)
+    o, attn, ym, (z, z_p, m_p, logs_p) = _run(net, x, xl, sid, eps_w, eps_z)
+    W = checkpoint.fold_weight_norm(sd)
+    with torch.no_grad():
+        ro, rattn, rym, (rz, *_rest) = vo.infer(W, util.cfg_dict(net.cfg), x, xl, sid,
+                                                noise_scale=0.667, length_scale=1.0,
+                                                noise_scale_w=0.8, eps_w=eps_w, eps_z=eps_z)
+    assert torch.equal(ym.cpu(), rym)  # both [B,1,Ty]
+    print("vits2_v1 z rel", util.rel_rms(z.cpu().numpy(), rz.numpy()), "audio abs rms",
+          util.rms(o.cpu().numpy() - ro.numpy()))
+    assert util.rel_rms(z.cpu().numpy(), rz.numpy()) < 2e-4
+    assert util.rms(o.cpu().numpy() - ro.numpy()) < 1e-4

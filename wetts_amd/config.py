@@ -107,10 +107,14 @@ MODEL_CONFIGS["tiny_vocos"] = dict(
 MODEL_CONFIGS["vits2_vocos_v1"] = dict(
     MODEL_CONFIGS["vocos"], use_transformer_flows=True, transformer_flow_type="pre_conv",
     use_spk_conditioned_encoder=False, use_sdp=True, gin_channels=256)
+# examples/baker/configs/vits2_v1.json:29-54: the same flows in front of the HiFi-GAN v1 generator
+MODEL_CONFIGS["vits2_v1"] = dict(
+    MODEL_CONFIGS["v1"], use_transformer_flows=True, transformer_flow_type="pre_conv",
+    use_spk_conditioned_encoder=False, use_sdp=True)
 MODEL_CONFIGS["tiny_vits2_vocos"] = dict(
     MODEL_CONFIGS["tiny_vocos"], use_transformer_flows=True, transformer_flow_type="pre_conv",
     use_sdp=True)
-SAMPLING_RATES = {"vits2_vocos_v1": 24000, "tiny_vits2_vocos": 24000, "v1": 22050, "v2": 22050, "v3": 16000, "stress48k": 48000, "tiny": 22050,
+SAMPLING_RATES = {"vits2_v1": 22050, "vits2_vocos_v1": 24000, "tiny_vits2_vocos": 24000, "v1": 22050, "v2": 22050, "v3": 16000, "stress48k": 48000, "tiny": 22050,
                   "tiny_dp": 16000, "vocos": 16000, "tiny_vocos": 16000}
 
 
