@@ -30,3 +30,7 @@ python tools/bench_stream.py --model v1 > gpurun_out/stream_v1.json 2>/dev/null
 python tools/bench_stream.py --model vits2_vocos_v1 --cpu > gpurun_out/stream_vits2_vocos.json 2>/dev/null
 python bench.py --model vocos --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_vocos.json 2>/dev/null
 python bench.py --model vits2_vocos_v1 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_vits2_vocos.json 2>/dev/null
+# BASELINE configs[2] (v3, B=64, bf16) and configs[4] (builder-defined 48 kHz stress shape, f16)
+python bench.py --model v3 --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --decoder-dtype bf16 > gpurun_out/bench_cfg3_v3_b64_bf16.json 2>/dev/null
+python bench.py --model v3 --batch 64 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_cfg3_v3_b64_f32.json 2>/dev/null
+python bench.py --model stress48k --steps 10 --warmup 3 --no-cpu-baseline --decoder-dtype f16 > gpurun_out/bench_cfg5_stress48k_f16.json 2>/dev/null

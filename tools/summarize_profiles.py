@@ -21,7 +21,9 @@ for a, b in [("bench_bf16.json", "bench_bf16.json"), ("bench_f16.json", "bench_f
              ("conv16_fused_pair.txt", "conv16_fused_pair.txt"),
              ("conv_microbench.txt", "conv_microbench.txt"),
              ("stream_v1.json", "stream_v1.json"), ("stream_vits2_vocos.json", "stream_vits2_vocos.json"),
-             ("bench_vocos.json", "bench_vocos.json"), ("bench_vits2_vocos.json", "bench_vits2_vocos.json")]:
+             ("bench_vocos.json", "bench_vocos.json"), ("bench_vits2_vocos.json", "bench_vits2_vocos.json"),
+             ("bench_cfg3_v3_b64_bf16.json",) * 2, ("bench_cfg3_v3_b64_f32.json",) * 2,
+             ("bench_cfg5_stress48k_f16.json",) * 2]:
     if os.path.exists(f"{src}/{a}"):
         shutil.copy(f"{src}/{a}", f"profiles/{tag}_{b}")
 
