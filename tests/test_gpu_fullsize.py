@@ -211,3 +211,28 @@ def test_vits2_v1_hifigan_with_transformer_flows_matches_oracle():
           util.rms(o.cpu().numpy() - ro.numpy()))
     assert util.rel_rms(z.cpu().numpy(), rz.numpy()) < 2e-4
     assert util.rms(o.cpu().numpy() - ro.numpy()) < 1e-4
+
+
+def test_text_encoder_mfma_attention_matches_oracle_ragged():
+    """Tx >= 64 routes the relative-position attention through the matrix-core kernels
+    (attention.hip: band term from a [2w+1] x T table in the score epilogue, relative-value pass
+    after P.V); the golden cases (Tx <= 12) cover the scalar path.  Ragged lengths exercise the
+    -1e4 masking; Tx = 100 is not a multiple of the 32-wide tiles."""
+    from oracle import vits_oracle as vo
+    from wetts_amd import checkpoint
+    net, sd = _net("v1", 120, 1, seed=5)
+    g = torch.Generator().manual_seed(6)
+    B, Tx = 5, 100
+    x = torch.randint(0, 120, (B, Tx), generator=g)
+    xl = torch.tensor([100, 64, 99, 33, 1])
+    sid = torch.zeros(B, dtype=torch.long)
+    st = net._encode(x.cuda(), xl.cuda(), sid.cuda(), 0.667, 1.0, 0.8,
+                     torch.zeros(B, 2, Tx).cuda(), None)
+    W = checkpoint.fold_weight_norm(sd)
+    with torch.no_grad():
+        rx, rm, rlogs, rmask = vo.text_encoder(W, util.cfg_dict(net.cfg), x, xl)
+    I = net.cfg.inter_channels
+    e_x = util.rel_rms(st["x_enc"].cpu().numpy(), rx.numpy())
+    e_m = util.rel_rms(st["stats"][:, :I].cpu().numpy(), rm.numpy())
+    print("text encoder Tx=100 rel rms", e_x, e_m)
+    assert e_x < 1e-4 and e_m < 1e-4

@@ -106,9 +106,38 @@ typedef float f32x16a __attribute__((ext_vector_type(16)));
 
 // S[b,h,j,i] = sum_d k[d][j] * (q[d][i] / sqrt(dk)), masked_fill(mask_i * mask_j == 0, -1e4)
 // block = 4 waves = 4 j-blocks of 32 x one i-block of 32;  grid (ceil(T/32), ceil(T/128), B*H)
+// rel[bh][r][i] = (q_i / sqrt(dk)) . E_k[r]   for the 2w+1 relative positions (attentions.py:246-252)
+__global__ void attn_relk_kernel(const float* __restrict__ q, const float* __restrict__ emb_rel_k,
+                                 int nrel, int dk, int T, float qdiv, float* __restrict__ rel) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int r = blockIdx.y, bh = blockIdx.z;
+  if (i >= T) return;
+  const float* qb = q + (int64_t)bh * dk * T;
+  const float* er = emb_rel_k + (int64_t)r * dk;
+  float acc = 0.f;
+  for (int d = 0; d < dk; ++d) acc += (qb[(int64_t)d * T + i] / qdiv) * er[d];
+  rel[((int64_t)bh * nrel + r) * T + i] = acc;
+}
+
+// out[bh][d][i] += sum_{|r|<=w} P[i+r][i] * E_v[r+w][d]   (attentions.py:273-279)
+__global__ void attn_relv_add_kernel(const float* __restrict__ P, const float* __restrict__ emb_rel_v,
+                                     int window, int dk, int T, float* __restrict__ out) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int d = blockIdx.y, bh = blockIdx.z;
+  if (i >= T) return;
+  const float* Pc = P + (int64_t)bh * T * T + i;
+  float rel = 0.f;
+  for (int r = -window; r <= window; ++r) {
+    const int j = i + r;
+    if (j >= 0 && j < T) rel += Pc[(int64_t)j * T] * emb_rel_v[(int64_t)(r + window) * dk + d];
+  }
+  out[((int64_t)bh * dk + d) * T + i] += rel;
+}
+
 __global__ __launch_bounds__(256) void attn_scores_mfma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ mask,
-    int n_heads, int dk, int T, float qdiv, float* __restrict__ S) {
+    const float* __restrict__ rel, int window, int n_heads, int dk, int T, float qdiv,
+    float* __restrict__ S) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
   const int bh = blockIdx.z, b = bh / n_heads;
   const int i = blockIdx.x * 32 + (lane & 31);
@@ -146,6 +175,8 @@ __global__ __launch_bounds__(256) void attn_scores_mfma_kernel(
     const int jj = jb + (r & 3) + 8 * (r >> 2) + 4 * half;
     if (jj < T) {
       float sc = acc[r];
+      const int rr = jj - i + window;  // relative-key term inside the band (window >= 0 only)
+      if (rel && rr >= 0 && rr <= 2 * window) sc += rel[((int64_t)bh * (2 * window + 1) + rr) * T + i];
       if (mi * mask[(int64_t)b * T + jj] == 0.f) sc = -1e4f;
       Sb[(int64_t)jj * T] = sc;
     }
@@ -221,13 +252,24 @@ int32_t k_rel_attention(const float* q, const float* k, const float* v, const fl
   if (B * T == 0) return WETTS_OK;
   WETTS_REQUIRE(T <= 65535, "attention length %d too large", T);
   const float qdiv = (float)sqrt((double)dk);
-  if (window < 0) {
-    // window_size=None: no relative-position terms.  `out` doubles as the transposed-v scratch
-    // until the PV kernel overwrites it?  No -- PV reads vT while writing out, so vT lives in the
-    // tail of the score workspace (the caller sizes it B*H*T*T + B*H*dk*T).
+  if (window < 0 || T >= 64) {
+    // Matrix-core path: window-less attention (VITS2 flow encoders) and every relative-position
+    // attention long enough to fill 32x32 tiles.  The relative-key term is a [2w+1] x T table
+    // added inside the band by the score epilogue, the relative-value term a 2w+1-tap pass over
+    // P after the P.V contraction.  Behind the scores the workspace holds the transposed v
+    // (B*H*dk*T floats) and that table (B*H*(2w+1)*T).
     float* vT = scores + (int64_t)B * n_heads * T * T;
+    float* rel = nullptr;
+    const int nrel = 2 * window + 1;
+    if (window >= 0) {
+      rel = vT + (int64_t)B * n_heads * dk * T;
+      hipLaunchKernelGGL(attn_relk_kernel, dim3(cdiv(T, 64), nrel, B * n_heads), dim3(64), 0, s, q,
+                         emb_rel_k, nrel, dk, T, qdiv, rel);
+      WETTS_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(attn_scores_mfma_kernel, dim3(cdiv(T, 32), cdiv(T, 128), B * n_heads),
-                       dim3(256), 0, s, q, k, mask, n_heads, dk, T, qdiv, scores);
+                       dim3(256), 0, s, q, k, mask, rel, window < 0 ? 0 : window, n_heads, dk, T,
+                       qdiv, scores);
     WETTS_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_softmax_kernel, dim3(cdiv(T, 16), B * n_heads), dim3(256), 0, s, T, scores);
     WETTS_LAUNCH_CHECK();
@@ -238,6 +280,11 @@ int32_t k_rel_attention(const float* q, const float* k, const float* v, const fl
     hipLaunchKernelGGL(attn_pv_mfma_kernel, dim3(cdiv(T, 128), cdiv(dk, 32), B * n_heads),
                        dim3(256), 0, s, scores, vT, dk, T, out);
     WETTS_LAUNCH_CHECK();
+    if (window >= 0) {
+      hipLaunchKernelGGL(attn_relv_add_kernel, dim3(cdiv(T, 64), dk, B * n_heads), dim3(64), 0, s,
+                         scores, emb_rel_v, window, dk, T, out);
+      WETTS_LAUNCH_CHECK();
+    }
     return WETTS_OK;
   }
   int tb = cdiv(T, 64);

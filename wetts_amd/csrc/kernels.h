@@ -105,8 +105,8 @@ int32_t k_flip_half(const float* x, const float* mask, int B, int C, int T, floa
 int32_t k_add(const float* a, const float* b, int64_t n, float* out, hipStream_t s);
 
 // a5 windowed relative-position attention (attentions.py:235-282), banded form.
-//   qkv: q,k,v [B,H*dk,T];  scores workspace [B,H,T,T] (+ B*H*dk*T more when window < 0: the
-//   window-less MFMA path keeps a transposed copy of v behind the scores);  out [B,H*dk,T]
+//   qkv: q,k,v [B,H*dk,T];  out [B,H*dk,T];  scores workspace: B*H*T*T + B*H*dk*T (transposed v
+//   of the MFMA path) + B*H*(2*window+1)*T (relative-key table, window >= 0) floats
 int32_t k_rel_attention(const float* q, const float* k, const float* v, const float* mask,
                         const float* emb_rel_k, const float* emb_rel_v, int window, int B,
                         int n_heads, int dk, int T, float* scores, float* out, hipStream_t s);

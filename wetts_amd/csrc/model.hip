@@ -652,7 +652,7 @@ static int64_t ws_encoder(const wetts_config_t* c, int B, int Tx) {
   int64_t n = 0;
   n += 5 * A256(B * H * Tx);          // q,k,v,att,y
   n += A256(B * F * Tx);              // ffn hidden
-  n += A256(B * nh * (int64_t)Tx * Tx);  // scores
+  n += A256(B * nh * (int64_t)Tx * Tx + B * H * Tx + B * nh * (2 * c->window_size + 1) * Tx);  // scores + vT + rel
   n += A256(B * H * Tx);              // x ping
   return n;
 }
@@ -902,7 +902,8 @@ int32_t wetts_text_encoder(const wetts_model_t* m, const int64_t* x, const int64
   float* att = ws.take<float>((int64_t)B * H * Tx);
   float* y = ws.take<float>((int64_t)B * H * Tx);
   float* hid = ws.take<float>((int64_t)B * F * Tx);
-  float* sc = ws.take<float>((int64_t)B * nh * Tx * Tx);
+  float* sc = ws.take<float>((int64_t)B * nh * Tx * Tx + (int64_t)B * H * Tx +
+                             (int64_t)B * nh * (2 * c->window_size + 1) * Tx);  // + vT + rel table
   float* xb = ws.take<float>((int64_t)B * H * Tx);
   if (!ws.ok) {
     set_error("text_encoder: workspace too small (%lld bytes)", (long long)workspace_bytes);
