@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libwetts_hip.so")
-SOURCES = ["conv_mfma.hip", "conv_bf16.hip", "resblock16.hip", "resblock32.hip", "kernels.hip", "attention.hip", "mas.hip", "model.hip"]
+SOURCES = ["conv_mfma.hip", "conv_bf16.hip", "resblock16.hip", "resblock32.hip", "kernels.hip", "attention.hip", "mas.hip", "model.hip", "bench_conv.hip"]
 HEADERS = ["common.h", "kernels.h", "conv_bf16.h", "conv16_dev.h", "resblock32.h", os.path.join("..", "..", "include", "wetts_hip.h"),
            os.path.join("..", "..", "include", "wetts_vits_model.hpp"),
            os.path.join("..", "..", "tests", "native", "vits_model_main.cpp")]

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string>
 
+#include <string.h>
+
 #include "../../include/wetts_hip.h"
 
 namespace wetts {
@@ -95,6 +97,27 @@ struct ConvParams {
   int ablate;            // microbenchmark-only ablation mask (see conv_mfma_kernel DBG)
   int tag;               // 1: MRF ResBlock launch (separate kernel symbol for profiles)
 };
+
+// default-initialised ConvParams for a plain contiguous [B,C,T] -> [B,Cout,T] conv
+inline ConvParams conv_io(const float* x, int Cin, int T, float* out, int Cout, int B) {
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.x_bs = (int64_t)Cin * T;
+  p.x_cs = T;
+  p.Tin = T;
+  p.in_rev_base = -1;
+  p.in_act = IN_NONE;
+  p.in_slope = 0.f;
+  p.out = out;
+  p.o_bs = (int64_t)Cout * T;
+  p.o_cs = T;
+  p.Tout = T;
+  p.out_act = OUT_NONE;
+  p.out_div = 1.f;
+  p.B = B;
+  return p;
+}
 
 // Packed weight descriptor held by the model.
 struct PackedConv {

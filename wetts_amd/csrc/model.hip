@@ -621,26 +621,6 @@ static int32_t build_model(wetts_model* m, hipStream_t s) {
   return WETTS_OK;
 }
 
-// default-initialised ConvParams for a plain contiguous [B,C,T] -> [B,Cout,T] conv
-static ConvParams conv_io(const float* x, int Cin, int T, float* out, int Cout, int B) {
-  ConvParams p;
-  memset(&p, 0, sizeof(p));
-  p.x = x;
-  p.x_bs = (int64_t)Cin * T;
-  p.x_cs = T;
-  p.Tin = T;
-  p.in_rev_base = -1;
-  p.in_act = IN_NONE;
-  p.in_slope = 0.f;
-  p.out = out;
-  p.o_bs = (int64_t)Cout * T;
-  p.o_cs = T;
-  p.Tout = T;
-  p.out_act = OUT_NONE;
-  p.out_div = 1.f;
-  p.B = B;
-  return p;
-}
 
 // ---------------------------------------------------------------------------------------------
 // workspace sizing
@@ -1706,288 +1686,6 @@ int32_t wetts_read_mrf_timing(const wetts_model_t* m, double* mrf_ms, int64_t* c
   return WETTS_OK;
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// conv micro-benchmark (measurement helper, allocates its own buffers; not on the product path)
-// ---------------------------------------------------------------------------------------------
-namespace wetts {
-__global__ void fill_pseudo_kernel(float* p, int64_t n, unsigned seed, float scale) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  unsigned h = (unsigned)i * 2654435761u + seed;
-  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
-  p[i] = ((float)(h & 0xffffff) / 8388608.f - 1.f) * scale;
-}
-static int32_t fill_pseudo(float* p, int64_t n, unsigned seed, float scale, hipStream_t s) {
-  hipLaunchKernelGGL(fill_pseudo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n,
-                     seed, scale);
-  WETTS_LAUNCH_CHECK();
-  return WETTS_OK;
-}
-}  // namespace wetts
-
-// 16-bit decoder conv microbench (flags & 16: bf16, & 32: f16); variant low byte: 1 half-width tiles,
-// 2 two chunks in flight, 4 permuted rows (16-byte epilogue), 8 force two LDS buffers; variant >> 8:
-// ablation bits of the DBG instantiation (1 no stores, 2 no residual loads, 4 no A loads, 8 no
-// staging loads after chunk 0, 16 no MFMA, 32 no staging loads at all, 64 nothing = DBG overhead)
-static int32_t bench_conv_16bit(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int32_t B,
-                                int32_t T, int32_t flags, int32_t variant, int32_t iters,
-                                double* ms_out, double* checksum_out) {
-  hipStream_t s = nullptr;
-  const int f16 = (flags & 32) ? 1 : 0;
-  const int64_t nx = (int64_t)B * Cin * T, no = (int64_t)B * Cout * T, nw = (int64_t)Cout * Cin * k;
-  float *xf = nullptr, *rf = nullptr, *w = nullptr, *bias = nullptr;
-  unsigned short *x = nullptr, *o = nullptr, *r = nullptr;
-  WETTS_HIP_CHECK(hipMalloc((void**)&xf, nx * 4));
-  WETTS_HIP_CHECK(hipMalloc((void**)&rf, no * 4));
-  WETTS_HIP_CHECK(hipMalloc((void**)&x, nx * 2));
-  WETTS_HIP_CHECK(hipMalloc((void**)&o, no * 2));
-  WETTS_HIP_CHECK(hipMalloc((void**)&r, no * 2));
-  WETTS_HIP_CHECK(hipMalloc((void**)&w, nw * 4));
-  WETTS_HIP_CHECK(hipMalloc((void**)&bias, (int64_t)Cout * 4));
-  WETTS_TRY(fill_pseudo(xf, nx, 1, 1.f, s));
-  WETTS_TRY(fill_pseudo(rf, no, 2, 1.f, s));
-  WETTS_TRY(fill_pseudo(w, nw, 3, 1.f / sqrtf((float)Cin * k), s));
-  WETTS_TRY(fill_pseudo(bias, Cout, 4, 0.1f, s));
-  WETTS_TRY(k_cf32_to_cl16(xf, x, B, Cin, T, f16, s));
-  WETTS_TRY(k_cf32_to_cl16(rf, r, B, Cout, T, f16, s));
-  WETTS_HIP_CHECK(hipMemsetAsync(o, 0, no * 2, s));
-  PackedConvB pc;
-  WETTS_TRY(pack_conv_weight_bf16(w, bias, Cout, Cin, k, dil, (k * dil - dil) / 2, 0, 0, f16, s, &pc));
-  if (variant & 48) {  // ResBlock1 pair: 16 = fused kernel, 32 = two conv launches
-    WETTS_REQUIRE(Cin == Cout, "pair bench needs Cin == Cout");
-    PackedConvB pc2;
-    float* w2 = nullptr;
-    unsigned short* ft = nullptr;
-    WETTS_HIP_CHECK(hipMalloc((void**)&w2, nw * 4));
-    WETTS_HIP_CHECK(hipMalloc((void**)&ft, no * 2));
-    WETTS_TRY(fill_pseudo(w2, nw, 5, 1.f / sqrtf((float)Cin * k), s));
-    WETTS_TRY(pack_conv_weight_bf16(w2, bias, Cout, Cin, k, 1, (k - 1) / 2, 0, 0, f16, s, &pc2));
-    auto run = [&]() -> int32_t {
-      if (variant & 16) {
-        ResPairParams pp;
-        memset(&pp, 0, sizeof(pp));
-        pp.x = x; pp.out = o; pp.T = T; pp.B = B; pp.accum = (flags & 4) ? 1 : 0;
-        pp.out_div = (flags & 8) ? 3.f : 1.f; pp.slope = 0.1f;
-        pp.ablate = variant >> 8;
-        return launch_resblock_pair16(pc, pc2, pp, s);
-      }
-      ConvBParams p1;
-      memset(&p1, 0, sizeof(p1));
-      p1.x = x; p1.x_bs = (int64_t)Cin * T; p1.Cin = Cin; p1.Tin = T; p1.in_act = IN_LRELU;
-      p1.in_slope = 0.1f; p1.out = ft; p1.o_bs = p1.x_bs; p1.cout = Cout; p1.Tout = T;
-      p1.out_div = 1.f; p1.B = B;
-      int32_t rc1 = launch_conv_bf16(pc, p1, s);
-      if (rc1 != WETTS_OK) return rc1;
-      ConvBParams p2 = p1;
-      p2.x = ft; p2.out = o; p2.res = x; p2.r_bs = p1.x_bs; p2.accum = (flags & 4) ? 1 : 0;
-      p2.out_div = (flags & 8) ? 3.f : 1.f;
-      return launch_conv_bf16(pc2, p2, s);
-    };
-    int32_t rc = WETTS_OK;
-    for (int i = 0; i < 2 && rc == WETTS_OK; ++i) rc = run();
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, s);
-    for (int i = 0; i < iters && rc == WETTS_OK; ++i) rc = run();
-    (void)hipEventRecord(e1, s);
-    (void)hipEventSynchronize(e1);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    *ms_out = ms / iters;
-    if (checksum_out && rc == WETTS_OK) {
-      // full-tensor fingerprint of ONE application on a known previous `out` (the residual copy)
-      (void)hipMemcpyAsync(o, r, no * 2, hipMemcpyDeviceToDevice, s);
-      rc = run();
-      std::vector<unsigned short> host((size_t)no);
-      (void)hipMemcpy(host.data(), o, host.size() * 2, hipMemcpyDeviceToHost);
-      uint64_t hsh = 1469598103934665603ull;
-      for (size_t i = 0; i < host.size(); ++i) hsh = (hsh ^ host[i]) * 1099511628211ull;
-      *checksum_out = (double)(hsh >> 12);  // 52 bits survive the double
-    }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    free_packed_bf16(&pc);
-    free_packed_bf16(&pc2);
-    (void)hipFree(xf); (void)hipFree(rf); (void)hipFree(x); (void)hipFree(o); (void)hipFree(r);
-    (void)hipFree(w); (void)hipFree(w2); (void)hipFree(ft); (void)hipFree(bias);
-    return rc;
-  }
-  ConvBParams p;
-  memset(&p, 0, sizeof(p));
-  p.x = x; p.x_bs = (int64_t)Cin * T; p.Cin = Cin; p.Tin = T;
-  p.out = o; p.o_bs = (int64_t)Cout * T; p.cout = Cout; p.Tout = T; p.out_div = 1.f; p.B = B;
-  if (flags & 1) { p.in_act = IN_LRELU; p.in_slope = 0.1f; }
-  if (flags & 2) { p.res = r; p.r_bs = (int64_t)Cout * T; }
-  if (flags & 4) p.accum = 1;
-  p.variant = variant & 0xff;
-  p.ablate = variant >> 8;
-  int32_t rc = WETTS_OK;
-  for (int i = 0; i < 2 && rc == WETTS_OK; ++i) rc = launch_conv_bf16(pc, p, s);
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
-  (void)hipEventRecord(e0, s);
-  for (int i = 0; i < iters && rc == WETTS_OK; ++i) rc = launch_conv_bf16(pc, p, s);
-  (void)hipEventRecord(e1, s);
-  (void)hipEventSynchronize(e1);
-  float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, e0, e1);
-  *ms_out = ms / iters;
-  if (checksum_out) {
-    if (p.accum) {  // fingerprint of a single application
-      (void)hipMemsetAsync(o, 0, no * 2, s);
-      rc = launch_conv_bf16(pc, p, s);
-    }
-    std::vector<unsigned short> host((size_t)(no < 65536 ? no : 65536));
-    (void)hipMemcpy(host.data(), o, host.size() * 2, hipMemcpyDeviceToHost);
-    double cs = 0;
-    for (size_t i = 0; i < host.size(); ++i) {
-      float v;
-      if (f16) {
-        _Float16 h;
-        memcpy(&h, &host[i], 2);
-        v = (float)h;
-      } else {
-        unsigned u = (unsigned)host[i] << 16;
-        memcpy(&v, &u, 4);
-      }
-      cs += (double)v * (double)((i % 7) + 1);
-    }
-    *checksum_out = cs;
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  free_packed_bf16(&pc);
-  (void)hipFree(xf); (void)hipFree(rf); (void)hipFree(x); (void)hipFree(o); (void)hipFree(r);
-  (void)hipFree(w); (void)hipFree(bias);
-  return rc;
-}
-
-int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int32_t B, int32_t T,
-                         int32_t flags, int32_t variant, int32_t iters, double* ms_out,
-                         double* checksum_out) {
-  WETTS_REQUIRE(ms_out && Cin > 0 && Cout > 0 && k > 0 && B > 0 && T > 0 && iters > 0,
-                "bad argument");
-  hipStream_t s = nullptr;
-  const int64_t nx = (int64_t)B * Cin * T, no = (int64_t)B * Cout * T, nw = (int64_t)Cout * Cin * k;
-  if (flags & 48) return bench_conv_16bit(Cin, Cout, k, dil, B, T, flags, variant, iters, ms_out, checksum_out);
-  float *x = nullptr, *o = nullptr, *r = nullptr, *w = nullptr, *bias = nullptr;
-  WETTS_HIP_CHECK(hipMalloc((void**)&x, nx * 4));
-  WETTS_HIP_CHECK(hipMalloc((void**)&o, no * 4));
-  WETTS_HIP_CHECK(hipMalloc((void**)&r, no * 4));
-  WETTS_HIP_CHECK(hipMalloc((void**)&w, nw * 4));
-  WETTS_HIP_CHECK(hipMalloc((void**)&bias, (int64_t)Cout * 4));
-  WETTS_TRY(fill_pseudo(x, nx, 1, 1.f, s));
-  WETTS_TRY(fill_pseudo(r, no, 2, 1.f, s));
-  WETTS_TRY(fill_pseudo(w, nw, 3, 1.f / sqrtf((float)Cin * k), s));
-  WETTS_TRY(fill_pseudo(bias, Cout, 4, 0.1f, s));
-  WETTS_HIP_CHECK(hipMemsetAsync(o, 0, no * 4, s));
-  PackedConv pc;
-  WETTS_TRY(pack_conv_weight(w, bias, Cout, Cin, k, dil, (k * dil - dil) / 2, 0, 0, s, &pc));
-  if (variant & 48) {  // ResBlock1 pair: 16 = fused kernel, 32 = two conv launches
-    WETTS_REQUIRE(Cin == Cout, "pair bench needs Cin == Cout");
-    PackedConv pc2;
-    float *w2 = nullptr, *ft = nullptr;
-    WETTS_HIP_CHECK(hipMalloc((void**)&w2, nw * 4));
-    WETTS_HIP_CHECK(hipMalloc((void**)&ft, no * 4));
-    WETTS_TRY(fill_pseudo(w2, nw, 5, 1.f / sqrtf((float)Cin * k), s));
-    WETTS_TRY(pack_conv_weight(w2, bias, Cout, Cin, k, 1, (k - 1) / 2, 0, 0, s, &pc2));
-    auto run = [&]() -> int32_t {
-      if (variant & 16) {
-        ResPair32Params pp;
-        memset(&pp, 0, sizeof(pp));
-        pp.x = x; pp.out = o; pp.T = T; pp.B = B; pp.accum = (flags & 4) ? 1 : 0;
-        pp.out_div = (flags & 8) ? 3.f : 1.f; pp.slope = 0.1f;
-        pp.ablate = variant >> 8;
-        return launch_resblock_pair32(pc, pc2, pp, s);
-      }
-      ConvParams p1 = conv_io(x, Cin, T, ft, Cout, B);
-      p1.in_act = IN_LRELU; p1.in_slope = 0.1f;
-      int32_t rc1 = launch_conv(pc, p1, s);
-      if (rc1 != WETTS_OK) return rc1;
-      ConvParams p2 = conv_io(ft, Cin, T, o, Cout, B);
-      p2.in_act = IN_LRELU; p2.in_slope = 0.1f;
-      p2.res = x; p2.r_bs = (int64_t)Cout * T; p2.r_cs = T;
-      p2.accum = (flags & 4) ? 1 : 0;
-      p2.out_div = (flags & 8) ? 3.f : 1.f;
-      return launch_conv(pc2, p2, s);
-    };
-    int32_t rc = WETTS_OK;
-    for (int i = 0; i < 2 && rc == WETTS_OK; ++i) rc = run();
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, s);
-    for (int i = 0; i < iters && rc == WETTS_OK; ++i) rc = run();
-    (void)hipEventRecord(e1, s);
-    (void)hipEventSynchronize(e1);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    *ms_out = ms / iters;
-    if (checksum_out && rc == WETTS_OK) {  // full-tensor hash of ONE application on a known `out`
-      (void)hipMemcpyAsync(o, r, no * 4, hipMemcpyDeviceToDevice, s);
-      rc = run();
-      std::vector<uint32_t> host((size_t)no);
-      (void)hipMemcpy(host.data(), o, host.size() * 4, hipMemcpyDeviceToHost);
-      uint64_t hsh = 1469598103934665603ull;
-      for (size_t i = 0; i < host.size(); ++i) hsh = (hsh ^ host[i]) * 1099511628211ull;
-      *checksum_out = (double)(hsh >> 12);
-    }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    free_packed(&pc);
-    free_packed(&pc2);
-    (void)hipFree(x); (void)hipFree(o); (void)hipFree(r); (void)hipFree(w); (void)hipFree(w2);
-    (void)hipFree(ft); (void)hipFree(bias);
-    return rc;
-  }
-  ConvParams p = conv_io(x, Cin, T, o, Cout, B);
-  if (flags & 1) { p.in_act = IN_LRELU; p.in_slope = 0.1f; }
-  if (flags & 2) { p.res = r; p.r_bs = (int64_t)Cout * T; p.r_cs = T; }
-  if (flags & 4) { p.accum = 1; }
-  const int saved = conv_variant();
-  set_conv_variant(variant & 0xff);
-  p.ablate = variant >> 8;
-  int32_t rc = WETTS_OK;
-  for (int i = 0; i < 2 && rc == WETTS_OK; ++i) rc = launch_conv(pc, p, s);
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
-  (void)hipEventRecord(e0, s);
-  for (int i = 0; i < iters && rc == WETTS_OK; ++i) rc = launch_conv(pc, p, s);
-  (void)hipEventRecord(e1, s);
-  (void)hipEventSynchronize(e1);
-  float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, e0, e1);
-  *ms_out = ms / iters;
-  set_conv_variant(saved);
-  if (checksum_out) {
-    // cheap order-insensitive fingerprint so variants can be compared for equality
-    std::vector<float> host((size_t)(no < 65536 ? no : 65536));
-    (void)hipMemcpy(host.data(), o, host.size() * 4, hipMemcpyDeviceToHost);
-    double cs = 0;
-    for (size_t i = 0; i < host.size(); ++i) cs += (double)host[i] * (double)((i % 7) + 1);
-    *checksum_out = cs;
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  free_packed(&pc);
-  (void)hipFree(x); (void)hipFree(o); (void)hipFree(r); (void)hipFree(w); (void)hipFree(bias);
-  return rc;
-}
-
-int32_t wetts_bench_mfma_peak(int32_t blocks_per_cu, int32_t nacc, int32_t iters, double* tflops,
-                              double* ms) {
-  WETTS_REQUIRE(tflops && ms && blocks_per_cu > 0 && iters > 0, "bad argument");
-  return bench_mfma_peak(blocks_per_cu, nacc, iters, tflops, ms);
-}
-
-int32_t wetts_set_conv_variant(int32_t v) {
-  set_conv_variant(v);
-  return WETTS_OK;
-}
 
 int32_t wetts_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, int32_t B,
                   int32_t Ty, int32_t Tx, int32_t* path, void* workspace, int64_t workspace_bytes,
