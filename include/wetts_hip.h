@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WETTS_ABI_VERSION 3
+#define WETTS_ABI_VERSION 4
 
 #define WETTS_OK 0
 #define WETTS_E_INVALID (-1)   /* bad argument / unsupported configuration */
@@ -81,8 +81,14 @@ typedef struct wetts_config {
   int32_t istft_hop_length;  /* 256  */
   int32_t istft_win_length;  /* 1024 (must equal n_fft) */
   /* VITS2 flows (models.py:73-79, flows.py:340-360): 0 = ResidualCouplingLayer, 1 = "pre_conv"
-   * (ResidualCouplingTransformersLayer, flows.py:95-177: 2-layer window-less Encoder on x0) */
+   * (ResidualCouplingTransformersLayer, flows.py:95-177: 2-layer window-less Encoder on x0),
+   * 2 = "pre_conv2" (ResidualCouplingTransformersLayer2, flows.py:16-92: 1-layer Encoder on
+   * pre(x0) with the flow's kernel size and the default relative window) */
   int32_t transformer_flows;
+  /* speaker-conditioned text encoder (models.py:87-101, attentions.py:39-48,74-78): at layer 2
+   * x = (x + spk_emb_linear(g)) * x_mask */
+  int32_t use_spk_conditioned_encoder;
+  int32_t reserved[7];
 } wetts_config_t;
 
 typedef struct wetts_model wetts_model_t; /* opaque */
@@ -135,10 +141,11 @@ int32_t wetts_speaker_embedding(const wetts_model_t* m, const int64_t* sid, int3
  * normalization.py:16-19; commons.py:113-117).
  *   x [B,Tx] int64, x_lengths [B] int64
  *   x_enc [B,H,Tx], stats [B,2*inter,Tx] (m_p = channels [0,inter), logs_p = the rest),
- *   x_mask [B,Tx]. */
+ *   x_mask [B,Tx].  g [B,gin] (may be NULL) is only read by speaker-conditioned encoders
+ *   (`enc_p(x, x_lengths, g=g)`, models.py:243). */
 int32_t wetts_text_encoder(const wetts_model_t* m, const int64_t* x, const int64_t* x_lengths,
-                           int32_t B, int32_t Tx, float* x_enc, float* stats, float* x_mask,
-                           void* workspace, int64_t workspace_bytes, void* stream);
+                           const float* g, int32_t B, int32_t Tx, float* x_enc, float* stats,
+                           float* x_mask, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* a8 StochasticDurationPredictor.forward(reverse=True) (duration_predictors.py:213-219,254-263;
  * transforms.py:47-187).  eps_w [B,2,Tx] is the caller's standard-normal draw (the reference

@@ -137,8 +137,8 @@ class VitsModel {
     Check(wetts_speaker_embedding(model_, cfg_.n_speakers > 0 ? d_x + Tx + 1 : nullptr, 1, g_,
                                   nullptr), "speaker_embedding");
     const float* gp = cfg_.n_speakers > 0 ? g_ : nullptr;
-    Check(wetts_text_encoder(model_, d_x, d_x + Tx, 1, Tx, x_enc, stats, x_mask, ws, wsb, nullptr),
-          "text_encoder");
+    Check(wetts_text_encoder(model_, d_x, d_x + Tx, gp, 1, Tx, x_enc, stats, x_mask, ws, wsb,
+                             nullptr), "text_encoder");
     if (cfg_.use_sdp) {
       std::vector<float> h((size_t)2 * Tx);
       Normal(&h);

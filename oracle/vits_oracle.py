@@ -95,11 +95,16 @@ def ffn(W, pre, x, x_mask, k):
     return h * x_mask
 
 
-def encoder_stack(W, pre, x, x_mask, n_layers, n_heads, window, k):
-    """attentions.Encoder.forward (attentions.py:70-87), speaker branch off."""
+def encoder_stack(W, pre, x, x_mask, n_layers, n_heads, window, k, g=None):
+    """attentions.Encoder.forward (attentions.py:70-87); g [B,gin,1] enables the speaker branch
+    at layer cond_layer_idx = 2 (:44-48,74-78)."""
     attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
     x = x * x_mask
     for l in range(n_layers):
+        if g is not None and l == 2:
+            gl = F.linear(g.transpose(1, 2), W[pre + ".spk_emb_linear.weight"],
+                          W[pre + ".spk_emb_linear.bias"]).transpose(1, 2)
+            x = (x + gl) * x_mask
         y = rel_attention(W, f"{pre}.attn_layers.{l}", x, attn_mask, n_heads, window)
         x = layer_norm_c(x + y, W[f"{pre}.norm_layers_1.{l}.gamma"],
                          W[f"{pre}.norm_layers_1.{l}.beta"])
@@ -109,15 +114,17 @@ def encoder_stack(W, pre, x, x_mask, n_layers, n_heads, window, k):
     return x * x_mask
 
 
-def text_encoder(W, cfg, x_ids, x_lengths):
-    """TextEncoder.forward (encoders.py:47-57) + Encoder.forward (attentions.py:70-87)."""
+def text_encoder(W, cfg, x_ids, x_lengths, g=None):
+    """TextEncoder.forward (encoders.py:47-57) + Encoder.forward (attentions.py:70-87); g is only
+    used by speaker-conditioned encoders (models.py:87-101)."""
     H = cfg["hidden_channels"]
     x = F.embedding(x_ids, W["enc_p.emb.weight"]) * math.sqrt(H)
     x = x.transpose(1, -1)
     x_mask = sequence_mask(x_lengths, x.shape[2]).unsqueeze(1).to(x.dtype)
     x = x * x_mask
     x = encoder_stack(W, "enc_p.encoder", x, x_mask, cfg["n_layers"], cfg["n_heads"],
-                      cfg["window_size"], cfg["kernel_size"])
+                      cfg["window_size"], cfg["kernel_size"],
+                      g if cfg.get("use_spk_conditioned_encoder", 0) else None)
     stats = conv1d(W, "enc_p.proj", x) * x_mask
     m, logs = torch.split(stats, cfg["inter_channels"], dim=1)
     return x, m, logs, x_mask
@@ -304,6 +311,12 @@ def flow_reverse(W, cfg, z_p, y_mask, g):
             # 2-head, window-less Encoder on x0 with a residual, ahead of `pre`
             x0_ = encoder_stack(W, pre + ".pre_transformer", x0 * y_mask, y_mask, 2, 2, None, 3)
             h = conv1d(W, pre + ".pre", x0_ + x0) * y_mask
+        elif cfg.get("transformer_flows", 0) == 2:
+            # "pre_conv2" = ResidualCouplingTransformersLayer2 (flows.py:16-92): one Encoder layer
+            # (2 heads, relative window 4, FFN kernel = the flow's kernel size) on pre(x0)
+            h = conv1d(W, pre + ".pre", x0) * y_mask
+            h = h + encoder_stack(W, pre + ".pre_transformer", h * y_mask, y_mask, 1, 2, 4,
+                                  cfg["flow_kernel_size"])
         else:
             h = conv1d(W, pre + ".pre", x0) * y_mask
         h = wn(W, pre + ".enc", h, y_mask, g, H, cfg["flow_wn_layers"], cfg["flow_kernel_size"])
@@ -467,7 +480,7 @@ def infer(W, cfg, x_ids, x_lengths, sid=None, noise_scale=1.0, length_scale=1.0,
         g = None
         if cfg["n_speakers"] > 0:
             g = F.embedding(sid, W["emb_g.weight"]).unsqueeze(-1)
-        x, m_p, logs_p, x_mask = text_encoder(W, cfg, x_ids, x_lengths)
+        x, m_p, logs_p, x_mask = text_encoder(W, cfg, x_ids, x_lengths, g)
         if cfg["use_sdp"]:
             if eps_w is None:
                 eps_w = torch.randn(x.size(0), 2, x.size(2))

@@ -40,6 +40,8 @@ CASES = {
     # VITS2 "pre_conv" transformer flows + SDP + Vocos (examples/baker/configs/vits2_vocos_v1.json)
     "tiny_vits2_vocos_b2": ("tiny_vits2_vocos", 40, 2, 2, 10, [10, 7], 16, 106, (0.667, 1.0, 0.8)),
     "vits2_vocos_b2": ("vits2_vocos_v1", 64, 1, 2, 8, [8, 6], 24, 204, (0.667, 1.0, 0.8)),
+    # the two options no checked-in recipe enables: "pre_conv2" flows + speaker-conditioned encoder
+    "tiny_preconv2_spk_b3": ("tiny_preconv2_spk", 40, 3, 3, 11, [11, 5, 8], 17, 107, (0.667, 1.0, 0.8)),
 }
 ONLY = os.environ.get("WETTS_GOLDEN_ONLY")  # comma-separated case names (default: all)
 

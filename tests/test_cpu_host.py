@@ -23,11 +23,11 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert _lib.load().wetts_abi_version() == 3
+    assert _lib.load().wetts_abi_version() == 4
 
 
 @pytest.mark.parametrize("mname", ["v1", "v2", "v3", "stress48k", "tiny", "tiny_dp", "vocos", "tiny_vocos", "vits2_vocos_v1",
-                                   "tiny_vits2_vocos", "vits2_v1"])
+                                   "tiny_vits2_vocos", "vits2_v1", "tiny_preconv2_spk"])
 def test_blob_layout_is_consistent(mname):
     cfg = config.make_config(config.MODEL_CONFIGS[mname], 100, 4)
     lay = checkpoint.blob_layout(cfg)
@@ -48,7 +48,8 @@ def test_layout_names_and_shapes_match_reference_state_dict():
         pytest.skip("reference not present on this box")
     import contextlib, io
     S, *_ = ref_import.import_reference()
-    for mname, nspk in [("v1", 1), ("v3", 2), ("vocos", 2), ("vits2_vocos_v1", 1)]:
+    for mname, nspk in [("v1", 1), ("v3", 2), ("vocos", 2), ("vits2_vocos_v1", 1),
+                        ("tiny_preconv2_spk", 3)]:
         with contextlib.redirect_stdout(io.StringIO()):
             net = S(50, 513, 32, n_speakers=nspk, **config.MODEL_CONFIGS[mname])
         ref = {k: tuple(v.shape) for k, v in checkpoint.fold_weight_norm(net.state_dict()).items()}
@@ -100,8 +101,12 @@ def test_config_validation_and_unsupported_options():
     with pytest.raises(NotImplementedError):
         config.make_config(dict(config.MODEL_CONFIGS["v1"], use_transformer_flows=True,
                                 transformer_flow_type="fft"), 10, 1)
-    with pytest.raises(NotImplementedError):
-        config.make_config(dict(config.MODEL_CONFIGS["v1"], use_spk_conditioned_encoder=True), 10, 1)
+    sp = config.make_config(dict(config.MODEL_CONFIGS["v1"], use_spk_conditioned_encoder=True,
+                                 use_transformer_flows=True, transformer_flow_type="pre_conv2"), 10, 2)
+    assert sp.use_spk_conditioned_encoder == 1 and sp.transformer_flows == 2
+    # without speakers the reference's enc_gin_channels is 0 (models.py:87-90): option is a no-op
+    assert config.make_config(dict(config.MODEL_CONFIGS["v1"], use_spk_conditioned_encoder=True),
+                              10, 0).use_spk_conditioned_encoder == 0
     assert config.make_config(dict(config.MODEL_CONFIGS["v1"], use_transformer_flows=True), 10,
                               1).transformer_flows == 1  # default type "pre_conv"
     with pytest.raises(NotImplementedError):

@@ -9,7 +9,8 @@ from wetts_amd import checkpoint, config, synth
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 INFER_CASES = ["tiny_sdp_b3", "tiny_dp_b2", "tiny_sdp_nonoise", "tiny_sdp_single", "v1_b2", "v3_b2",
                "tiny_vocos_b2", "vocos_b2",  # VocosGenerator (decoders.py:251-308)
-               "tiny_vits2_vocos_b2", "vits2_vocos_b2"]  # + VITS2 pre_conv flows (flows.py:95-177)
+               "tiny_vits2_vocos_b2", "vits2_vocos_b2",  # + VITS2 pre_conv flows (flows.py:95-177)
+               "tiny_preconv2_spk_b3"]  # pre_conv2 flows (flows.py:16-92) + speaker-conditioned encoder
 
 
 def load_case(name):
@@ -43,6 +44,7 @@ def cfg_dict(cfg):
         resblock=cfg.resblock, vocoder_type=cfg.vocoder_type, vocos_num_layers=cfg.vocos_num_layers,
         istft_n_fft=cfg.istft_n_fft, istft_hop_length=cfg.istft_hop_length,
         istft_win_length=cfg.istft_win_length, transformer_flows=cfg.transformer_flows,
+        use_spk_conditioned_encoder=cfg.use_spk_conditioned_encoder,
         resblock_kernel_sizes=[cfg.resblock_kernel_sizes[j] for j in range(nk)],
         resblock_dilation_sizes=[[cfg.resblock_dilation_sizes[j][i] for i in range(nd)]
                                  for j in range(nk)],

@@ -58,6 +58,8 @@ class Config(C.Structure):
         ("istft_hop_length", C.c_int32),
         ("istft_win_length", C.c_int32),
         ("transformer_flows", C.c_int32),
+        ("use_spk_conditioned_encoder", C.c_int32),
+        ("reserved", C.c_int32 * 7),
     ]
 
 
@@ -80,7 +82,7 @@ SIGNATURES = {
     "wetts_hop_length": (_I32, [_P]),
     "wetts_workspace_bytes": (_I64, [_P, _I32, _I32, _I32]),
     "wetts_speaker_embedding": (_I32, [_P, _P, _I32, _P, _P]),
-    "wetts_text_encoder": (_I32, [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _P]),
+    "wetts_text_encoder": (_I32, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _P]),
     "wetts_duration_sdp": (_I32, [_P, _P, _P, _P, _P, _F, _I32, _I32, _P, _P, _P, _I64, _P]),
     "wetts_duration_dp": (_I32, [_P, _P, _P, _P, _I32, _I32, _P, _P, _I64, _P]),
     "wetts_durations_to_lengths": (_I32, [_P, _P, _F, _I32, _I32, _P, _P, _P, _P]),
@@ -126,7 +128,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError => header / library mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.wetts_abi_version() != 3:
+    if lib.wetts_abi_version() != 4:
         raise WettsError("libwetts_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -111,10 +111,17 @@ MODEL_CONFIGS["vits2_vocos_v1"] = dict(
 MODEL_CONFIGS["vits2_v1"] = dict(
     MODEL_CONFIGS["v1"], use_transformer_flows=True, transformer_flow_type="pre_conv",
     use_spk_conditioned_encoder=False, use_sdp=True)
+# coverage configs for the options no checked-in recipe switches on
+MODEL_CONFIGS["tiny_preconv2_spk"] = dict(
+    inter_channels=192, hidden_channels=192, filter_channels=256, n_heads=2, n_layers=3,
+    kernel_size=3, p_dropout=0.1, gin_channels=64, resblock="1", upsample_rates=[4, 2],
+    upsample_kernel_sizes=[8, 4], upsample_initial_channel=64, resblock_kernel_sizes=[3, 7],
+    resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5]], use_transformer_flows=True,
+    transformer_flow_type="pre_conv2", use_spk_conditioned_encoder=True, use_sdp=True)
 MODEL_CONFIGS["tiny_vits2_vocos"] = dict(
     MODEL_CONFIGS["tiny_vocos"], use_transformer_flows=True, transformer_flow_type="pre_conv",
     use_sdp=True)
-SAMPLING_RATES = {"vits2_v1": 22050, "vits2_vocos_v1": 24000, "tiny_vits2_vocos": 24000, "v1": 22050, "v2": 22050, "v3": 16000, "stress48k": 48000, "tiny": 22050,
+SAMPLING_RATES = {"tiny_preconv2_spk": 22050, "vits2_v1": 22050, "vits2_vocos_v1": 24000, "tiny_vits2_vocos": 24000, "v1": 22050, "v2": 22050, "v3": 16000, "stress48k": 48000, "tiny": 22050,
                   "tiny_dp": 16000, "vocos": 16000, "tiny_vocos": 16000}
 
 
@@ -124,9 +131,7 @@ def _get(model, key, default=None):
     return model[key] if key in model else default
 
 
-_UNSUPPORTED = {
-    "use_spk_conditioned_encoder": "speaker-conditioned encoder (attentions.py:39-48) is 'next'",
-}
+_UNSUPPORTED = {}  # option -> reason; every option of the reference's configs is implemented
 
 
 def make_config(model, n_vocab, n_speakers):
@@ -146,11 +151,16 @@ def make_config(model, n_vocab, n_speakers):
     c = _lib.Config()
     if _get(model, "use_transformer_flows", False):
         ft = _get(model, "transformer_flow_type", "pre_conv")  # models.py:74-75 default
-        if ft != "pre_conv":
+        if ft not in ("pre_conv", "pre_conv2"):
             raise NotImplementedError(
-                f"transformer_flow_type={ft!r}: only 'pre_conv' (flows.py:95-177, the type the "
-                "reference's vits2 configs use) is implemented")
-        c.transformer_flows = 1
+                f"transformer_flow_type={ft!r}: 'pre_conv' (flows.py:95-177, the type the "
+                "reference's vits2 configs use) and 'pre_conv2' (flows.py:16-92) are implemented")
+        c.transformer_flows = 1 if ft == "pre_conv" else 2
+    if _get(model, "use_spk_conditioned_encoder", False) and int(_get(model, "gin_channels", 0)) > 0 \
+            and n_speakers > 0:
+        if int(_get(model, "n_layers")) <= 2:
+            raise ValueError("cond_layer_idx (2) should be less than n_layers (attentions.py:47-48)")
+        c.use_spk_conditioned_encoder = 1
     if voc == "vocos":
         ic = _get(model, "vocos_istft_config", None) or {}
         c.vocoder_type = 1

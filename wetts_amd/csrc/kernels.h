@@ -29,6 +29,9 @@ int32_t k_gather_rows(const int64_t* idx, const float* table, int n_rows, int B,
 
 // x[b,c,t] += v[b,c]
 int32_t k_add_bias_b(float* x, const float* v, int B, int C, int T, hipStream_t s);
+// x[b,c,t] = (x[b,c,t] + v[b,c]) * mask[b,t]   (speaker-conditioned Encoder, attentions.py:74-78)
+int32_t k_add_bias_b_mask(float* x, const float* v, const float* mask, int B, int C, int T,
+                          hipStream_t s);
 // out = a * scale
 int32_t k_scale(const float* a, float scale, int64_t n, float* out, hipStream_t s);
 

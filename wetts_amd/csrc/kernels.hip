@@ -842,4 +842,23 @@ int32_t k_add(const float* a, const float* b, int64_t n, float* out, hipStream_t
   return WETTS_OK;
 }
 
+
+__global__ void add_bias_b_mask_kernel(float* __restrict__ x, const float* __restrict__ v,
+                                       const float* __restrict__ mask, int64_t total, int C, int T) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int t = (int)(idx % T);
+  const int64_t bc = idx / T;
+  x[idx] = (x[idx] + v[bc]) * mask[(bc / C) * T + t];
+}
+
+int32_t k_add_bias_b_mask(float* x, const float* v, const float* mask, int B, int C, int T,
+                          hipStream_t s) {
+  int64_t n = (int64_t)B * C * T;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(add_bias_b_mask_kernel, grid1d(n, 256), dim3(256), 0, s, x, v, mask, n, C, T);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
 }  // namespace wetts

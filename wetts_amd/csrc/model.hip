@@ -88,10 +88,16 @@ static int validate_config(const wetts_config_t* c) {
                 "bad flow config");
   WETTS_REQUIRE(c->sdp_n_flows >= 2, "bad sdp_n_flows");
   WETTS_REQUIRE(c->vocoder_type == 0 || c->vocoder_type == 1, "vocoder_type must be 0 (hifigan) or 1 (vocos)");
-  WETTS_REQUIRE(c->transformer_flows == 0 || c->transformer_flows == 1,
-                "transformer_flows must be 0 or 1 (pre_conv)");
-  WETTS_REQUIRE(c->transformer_flows == 0 || (c->inter_channels / 2) % 2 == 0,
+  WETTS_REQUIRE(c->transformer_flows >= 0 && c->transformer_flows <= 2,
+                "transformer_flows must be 0, 1 (pre_conv) or 2 (pre_conv2)");
+  WETTS_REQUIRE(c->transformer_flows != 1 || (c->inter_channels / 2) % 2 == 0,
                 "pre_conv flows need inter_channels/2 divisible by their 2 heads");
+  WETTS_REQUIRE(c->transformer_flows != 2 || c->hidden_channels % 2 == 0,
+                "pre_conv2 flows need hidden_channels divisible by their 2 heads");
+  WETTS_REQUIRE(c->use_spk_conditioned_encoder == 0 ||
+                    (c->n_speakers > 0 && c->gin_channels > 0 && c->n_layers > 2),
+                "speaker-conditioned encoder needs speakers, gin_channels and n_layers > 2 "
+                "(cond_layer_idx = 2, attentions.py:44-48)");
   if (c->vocoder_type == 1) {
     WETTS_REQUIRE(c->vocos_channels > 0 && c->vocos_h_channels > 0 && c->vocos_num_layers >= 1 &&
                       c->vocos_num_layers <= 64, "bad vocos channels / layers");
@@ -138,6 +144,10 @@ static void build_layout(const wetts_config_t* c, Layout& L) {
     L.add(f + ".conv_2.bias", H);
     L.add(S("enc_p.encoder.norm_layers_2.%d.gamma", l), H);
     L.add(S("enc_p.encoder.norm_layers_2.%d.beta", l), H);
+  }
+  if (c->use_spk_conditioned_encoder) {  // nn.Linear(gin, hidden) (attentions.py:41-43)
+    L.add("enc_p.encoder.spk_emb_linear.weight", H, gin);
+    L.add("enc_p.encoder.spk_emb_linear.bias", H);
   }
   L.add("enc_p.proj.weight", 2 * I, H, 1);
   L.add("enc_p.proj.bias", 2 * I);
@@ -206,6 +216,25 @@ static void build_layout(const wetts_config_t* c, Layout& L) {
         L.add(p + S(".pre_transformer.norm_layers_2.%d.gamma", l), Hh);
         L.add(p + S(".pre_transformer.norm_layers_2.%d.beta", l), Hh);
       }
+    }
+    if (c->transformer_flows == 2) {
+      // Encoder(hidden, hidden, n_heads=2, n_layers=1, kernel_size=flow kernel, window 4), flows.py:40-48
+      const int dkf = H / 2, Wf = 2 * 4 + 1, fk2 = c->flow_kernel_size;
+      std::string a = p + ".pre_transformer.attn_layers.0";
+      L.add(a + ".emb_rel_k", 1, Wf, dkf);
+      L.add(a + ".emb_rel_v", 1, Wf, dkf);
+      for (const char* n : {"conv_q", "conv_k", "conv_v", "conv_o"}) {
+        L.add(a + "." + n + ".weight", H, H, 1);
+        L.add(a + "." + n + ".bias", H);
+      }
+      L.add(p + ".pre_transformer.norm_layers_1.0.gamma", H);
+      L.add(p + ".pre_transformer.norm_layers_1.0.beta", H);
+      L.add(p + ".pre_transformer.ffn_layers.0.conv_1.weight", H, H, fk2);
+      L.add(p + ".pre_transformer.ffn_layers.0.conv_1.bias", H);
+      L.add(p + ".pre_transformer.ffn_layers.0.conv_2.weight", H, H, fk2);
+      L.add(p + ".pre_transformer.ffn_layers.0.conv_2.bias", H);
+      L.add(p + ".pre_transformer.norm_layers_2.0.gamma", H);
+      L.add(p + ".pre_transformer.norm_layers_2.0.beta", H);
     }
     L.add(p + ".pre.weight", H, I / 2, 1);
     L.add(p + ".pre.bias", H);
@@ -331,6 +360,7 @@ struct wetts_model {
   const float* emb = nullptr;
   std::vector<EncLayer> enc;
   PackedConv enc_proj;
+  const float *enc_spk_w = nullptr, *enc_spk_b = nullptr;  // spk_emb_linear (speaker-conditioned)
   const float* emb_g = nullptr;
   // sdp
   PackedConv sdp_pre, sdp_proj;
@@ -481,6 +511,8 @@ static int32_t build_model(wetts_model* m, hipStream_t s) {
   const int H = c->hidden_channels, I = c->inter_channels, F = c->filter_channels;
   const int ks = c->kernel_size;
   m->emb = m->T("enc_p.emb.weight");
+  m->enc_spk_w = m->T("enc_p.encoder.spk_emb_linear.weight");
+  m->enc_spk_b = m->T("enc_p.encoder.spk_emb_linear.bias");
   m->enc.resize(c->n_layers);
   for (int l = 0; l < c->n_layers; ++l) {
     EncLayer& e = m->enc[l];
@@ -554,6 +586,24 @@ static int32_t build_model(wetts_model* m, hipStream_t s) {
     }
     fw.cond_w = m->T(p + ".enc.cond_layer.weight");
     fw.cond_b = m->T(p + ".enc.cond_layer.bias");
+    if (c->transformer_flows == 2) {
+      fw.pre_tr.resize(1);
+      EncLayer& e = fw.pre_tr[0];
+      std::string a = p + ".pre_transformer.attn_layers.0";
+      e.rel_k = m->T(a + ".emb_rel_k");
+      e.rel_v = m->T(a + ".emb_rel_v");
+      WETTS_TRY(pack(m, a + ".conv_q.weight", a + ".conv_q.bias", H, H, 1, 1, 0, 0, 0, s, &e.q));
+      WETTS_TRY(pack(m, a + ".conv_k.weight", a + ".conv_k.bias", H, H, 1, 1, 0, 0, 0, s, &e.k));
+      WETTS_TRY(pack(m, a + ".conv_v.weight", a + ".conv_v.bias", H, H, 1, 1, 0, 0, 0, s, &e.v));
+      WETTS_TRY(pack(m, a + ".conv_o.weight", a + ".conv_o.bias", H, H, 1, 1, 0, 0, 0, s, &e.o));
+      e.n1g = m->T(p + ".pre_transformer.norm_layers_1.0.gamma");
+      e.n1b = m->T(p + ".pre_transformer.norm_layers_1.0.beta");
+      e.n2g = m->T(p + ".pre_transformer.norm_layers_2.0.gamma");
+      e.n2b = m->T(p + ".pre_transformer.norm_layers_2.0.beta");
+      std::string ff = p + ".pre_transformer.ffn_layers.0";
+      WETTS_TRY(pack(m, ff + ".conv_1.weight", ff + ".conv_1.bias", H, H, fk, 1, (fk - 1) / 2, 0, 0, s, &e.f1));
+      WETTS_TRY(pack(m, ff + ".conv_2.weight", ff + ".conv_2.bias", H, H, fk, 1, (fk - 1) / 2, 0, 0, s, &e.f2));
+    }
     if (c->transformer_flows == 1) {
       const int Hh = I / 2;
       fw.pre_tr.resize(2);
@@ -634,6 +684,7 @@ static int64_t ws_encoder(const wetts_config_t* c, int B, int Tx) {
   n += A256(B * F * Tx);              // ffn hidden
   n += A256(B * nh * (int64_t)Tx * Tx + B * H * Tx + B * nh * (2 * c->window_size + 1) * Tx);  // scores + vT + rel
   n += A256(B * H * Tx);              // x ping
+  n += A256(B * H);                   // speaker conditioning vector
   return n;
 }
 
@@ -651,8 +702,10 @@ static int64_t ws_flow(const wetts_config_t* c, int B, int Ty) {
   const int64_t H = c->hidden_channels, I = c->inter_channels;
   int64_t n = 2 * A256(B * I * Ty) + 3 * A256(B * H * Ty) + 2 * A256(B * 2 * H * Ty) +
               A256(B * (I / 2) * Ty) + A256(B * 2 * H * c->flow_wn_layers);
-  if (c->transformer_flows == 1)
-    n += 9 * A256(B * (I / 2) * Ty) + A256((int64_t)B * 2 * Ty * Ty + B * (I / 2) * Ty);
+  if (c->transformer_flows != 0) {
+    const int64_t He = c->transformer_flows == 1 ? I / 2 : H;
+    n += 9 * A256(B * He * Ty) + A256((int64_t)B * 2 * Ty * Ty + B * He * Ty + (int64_t)B * 2 * 9 * Ty);
+  }
   return n;
 }
 
@@ -831,11 +884,13 @@ namespace wetts {
 static int32_t run_enc_layers(const std::vector<EncLayer>& layers, float* xa, const float* x_mask,
                               int B, int H, int F, int nh, int window, int T, float* q, float* k,
                               float* v, float* att, float* y, float* hid, float* sc, float* xb,
-                              hipStream_t s) {
+                              hipStream_t s, const float* spk_cond = nullptr, int cond_idx = -1) {
   const int dk = H / nh, n = (int)layers.size();
   for (int l = 0; l < n; ++l) {
     const EncLayer& e = layers[l];
     const bool last = (l == n - 1);
+    // speaker-conditioned encoder (attentions.py:74-78): x = (x + spk_emb_linear(g)) * x_mask
+    if (spk_cond && l == cond_idx) WETTS_TRY(k_add_bias_b_mask(xa, spk_cond, x_mask, B, H, T, s));
     WETTS_TRY(launch_conv(e.q, conv_io(xa, H, T, q, H, B), s));
     WETTS_TRY(launch_conv(e.k, conv_io(xa, H, T, k, H, B), s));
     WETTS_TRY(launch_conv(e.v, conv_io(xa, H, T, v, H, B), s));
@@ -867,8 +922,8 @@ static int32_t run_enc_layers(const std::vector<EncLayer>& layers, float* xa, co
 }  // namespace wetts
 
 int32_t wetts_text_encoder(const wetts_model_t* m, const int64_t* x, const int64_t* x_lengths,
-                           int32_t B, int32_t Tx, float* x_enc, float* stats, float* x_mask,
-                           void* workspace, int64_t workspace_bytes, void* stream) {
+                           const float* g, int32_t B, int32_t Tx, float* x_enc, float* stats,
+                           float* x_mask, void* workspace, int64_t workspace_bytes, void* stream) {
   WETTS_REQUIRE(m && x && x_lengths && x_enc && stats && x_mask, "null argument");
   if (B == 0 || Tx == 0) return WETTS_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -885,15 +940,21 @@ int32_t wetts_text_encoder(const wetts_model_t* m, const int64_t* x, const int64
   float* sc = ws.take<float>((int64_t)B * nh * Tx * Tx + (int64_t)B * H * Tx +
                              (int64_t)B * nh * (2 * c->window_size + 1) * Tx);  // + vT + rel table
   float* xb = ws.take<float>((int64_t)B * H * Tx);
+  float* spk = ws.take<float>((int64_t)B * H);
   if (!ws.ok) {
     set_error("text_encoder: workspace too small (%lld bytes)", (long long)workspace_bytes);
     return WETTS_E_WORKSPACE;
+  }
+  const bool spk_on = c->use_spk_conditioned_encoder && has_g(c);
+  if (spk_on) {
+    WETTS_REQUIRE(g != nullptr, "speaker-conditioned encoder needs g");
+    WETTS_TRY(k_cond_linear(g, m->enc_spk_w, m->enc_spk_b, B, H, c->gin_channels, spk, s));
   }
   // x = emb(x)*sqrt(H), masked (encoders.py:48-53; Encoder.forward x = x * x_mask, attentions.py:72)
   float* xa = x_enc;  // current activations live in xa
   WETTS_TRY(k_embed_mask(x, x_lengths, m->emb, c->n_vocab, B, H, Tx, xa, x_mask, s));
   WETTS_TRY(run_enc_layers(m->enc, xa, x_mask, B, H, F, nh, c->window_size, Tx, q, k, v, att, y,
-                           hid, sc, xb, s));
+                           hid, sc, xb, s, spk_on ? spk : nullptr, 2));
   if (c->n_layers == 0) {
     // Encoder with no layers still masks its input; embed_mask already did.
   }
@@ -1090,12 +1151,13 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
   float* gl = ws.take<float>((int64_t)B * 2 * H * NL);
   float *tx0 = nullptr, *txm = nullptr, *tq = nullptr, *tk = nullptr, *tv = nullptr,
         *tatt = nullptr, *ty = nullptr, *thid = nullptr, *txb = nullptr, *tsc = nullptr;
-  if (c->transformer_flows == 1) {
-    const int64_t nh2 = (int64_t)B * (I / 2) * Ty;
+  if (c->transformer_flows != 0) {
+    // encoder width: x0 (I/2 channels) for pre_conv, the hidden h for pre_conv2
+    const int64_t nh2 = (int64_t)B * (c->transformer_flows == 1 ? I / 2 : H) * Ty;
     tx0 = ws.take<float>(nh2); txm = ws.take<float>(nh2); tq = ws.take<float>(nh2);
     tk = ws.take<float>(nh2); tv = ws.take<float>(nh2); tatt = ws.take<float>(nh2);
     ty = ws.take<float>(nh2); thid = ws.take<float>(nh2); txb = ws.take<float>(nh2);
-    tsc = ws.take<float>((int64_t)B * 2 * Ty * Ty + nh2);  // scores + transposed v (attention.hip)
+    tsc = ws.take<float>((int64_t)B * 2 * Ty * Ty + nh2 + (int64_t)B * 2 * 9 * Ty);  // scores + vT + rel table
   }
   if (!ws.ok) {
     set_error("flow_reverse: workspace too small");
@@ -1125,6 +1187,14 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
       p.out_mask = y_mask;
       p.out_mask_stride = Ty;
       WETTS_TRY(launch_conv(fw.pre, p, s));
+      if (c->transformer_flows == 2) {
+        // "pre_conv2" (flows.py:64-67): h = h + pre_transformer(h * mask, mask)
+        WETTS_HIP_CHECK(hipMemcpyAsync(txm, h, (size_t)B * H * Ty * sizeof(float),
+                                       hipMemcpyDeviceToDevice, s));
+        WETTS_TRY(run_enc_layers(fw.pre_tr, txm, y_mask, B, H, H, 2, 4, Ty, tq, tk, tv, tatt, ty,
+                                 thid, tsc, txb, s));
+        WETTS_TRY(k_add(h, txm, (int64_t)B * H * Ty, h, s));
+      }
     }
     const bool use_g = has_g(c) && g;
     if (use_g)
@@ -1800,7 +1870,7 @@ int32_t wetts_infer(const wetts_model_t* m, const int64_t* x, const int64_t* x_l
   const int64_t scratch_bytes = workspace_bytes - ws.off;
   WETTS_TRY(wetts_speaker_embedding(m, sid, B, g, stream));
   const float* gp = has_g(c) ? g : nullptr;
-  WETTS_TRY(wetts_text_encoder(m, x, x_lengths, B, Tx, x_enc, stats, x_mask, scratch,
+  WETTS_TRY(wetts_text_encoder(m, x, x_lengths, gp, B, Tx, x_enc, stats, x_mask, scratch,
                                scratch_bytes, stream));
   if (c->use_sdp) {
     WETTS_REQUIRE(eps_w != nullptr, "eps_w required for the stochastic duration predictor");

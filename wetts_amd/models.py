@@ -222,7 +222,8 @@ class SynthesizerTrn:
         x_enc = torch.empty(B, H, Tx, dtype=torch.float32, device=dev)
         stats = torch.empty(B, 2 * I, Tx, dtype=torch.float32, device=dev)
         x_mask = torch.empty(B, Tx, dtype=torch.float32, device=dev)
-        _lib.check(lib.wetts_text_encoder(self._handle, _lib.ptr(x), _lib.ptr(x_lengths), B, Tx,
+        _lib.check(lib.wetts_text_encoder(self._handle, _lib.ptr(x), _lib.ptr(x_lengths),
+                                          _lib.ptr(g), B, Tx,
                                           _lib.ptr(x_enc), _lib.ptr(stats), _lib.ptr(x_mask),
                                           _lib.ptr(ws), nws, s), "text_encoder")
         logw = torch.empty(B, Tx, dtype=torch.float32, device=dev)
