@@ -46,6 +46,14 @@ def parse_args():
                     help="HiFi-GAN arithmetic; the headline metric is quoted at f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2, help="utterances in the CPU sample")
+    # secondary mode: streaming (chunked decoder) latency at B = 1 instead of the throughput step
+    ap.add_argument("--stream", action="store_true", help="print the streaming-latency JSON instead")
+    ap.add_argument("--stream-phonemes", type=int, default=64)
+    ap.add_argument("--stream-chunk", type=int, default=40)
+    ap.add_argument("--stream-pad", type=int, default=10)
+    ap.add_argument("--stream-reps", type=int, default=30)
+    ap.add_argument("--stream-cpu", action="store_true", help="add the CPU-port timing of one window")
+    ap.add_argument("--stream-unfused", action="store_true", help="one launch per conv (diagnostic)")
     return ap.parse_args()
 
 
@@ -58,6 +66,94 @@ def make_inputs(model_name, n_vocab, n_speakers, total_utts, tx, ragged, seed=0)
         lens = torch.full((total_utts,), tx, dtype=torch.long)
     sid = torch.randint(0, max(1, n_speakers), (total_utts,), generator=g)
     return x, lens, sid
+
+
+def stream_bench(args):
+    """`bench.py --stream`: chunked-decoder latency at B = 1 (the reference's streaming
+    clients inference_onnx.py:37-76, vits_model.cc:96-153).  Prints one JSON line; with --stream-cpu the
+    cpu_baseline leg times the oracle (CPU port) on the first decoder window."""
+    import statistics
+    import numpy as np
+    from wetts_amd import SynthesizerTrn, checkpoint, config, synth
+    from wetts_amd.session import (DecoderSession, EncoderSession, InferenceSession, depad_bounds,
+                                   get_chunks)
+
+    def med(f, n):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            f()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return statistics.median(ts)
+
+    dev = torch.device("cuda:0")
+    net = SynthesizerTrn(256, 513, 32, n_speakers=1, **config.MODEL_CONFIGS[args.model]).to(dev)
+    sr = config.SAMPLING_RATES[args.model]
+    cfg = net.cfg
+    sd = synth.make_state_dict(cfg, seed=0)
+    net.load_blob(checkpoint.pack_blob(cfg, sd).to(dev))
+    hop = net.hop_length
+    if args.stream_unfused:
+        net.set_decoder_dtype(torch.float32, fused=False)
+    torch.manual_seed(0)
+    ids = torch.randint(0, 256, (1, args.stream_phonemes)).numpy()
+    feeds = {"input": ids, "input_lengths": np.array([args.stream_phonemes], dtype=np.int64),
+             "scales": np.array([[0.667, 1.0, 0.8]], dtype=np.float32),
+             "sid": np.array([0], dtype=np.int64)}
+    enc, full = EncoderSession(net), InferenceSession(net)
+    dec, decg = DecoderSession(net), DecoderSession(net, use_graph=True)
+    torch.manual_seed(1)
+    z = enc.run(None, feeds)[0]
+    L = z.shape[1]
+    wins = get_chunks(L, args.stream_chunk, args.stream_pad)
+    sid = feeds["sid"]
+
+    def stream(d):
+        out = []
+        for i, (a, b) in enumerate(wins):
+            o = d.run(None, {"z": z[:, a:b], "sid": sid})[0].reshape(1, -1)
+            lo, hi = depad_bounds(len(wins), i, args.stream_chunk, args.stream_pad, hop, o.shape[1])
+            out.append(o[0, lo:hi])
+        return np.concatenate(out)
+
+    a0, a1 = stream(dec), stream(decg)  # warm-up (captures the graphs) + equality
+    res = {"model": args.model, "sampling_rate": sr, "phonemes": args.stream_phonemes, "frames": int(L),
+           "audio_s": L * hop / float(sr),
+           "windows": len(wins), "chunk": args.stream_chunk, "pad": args.stream_pad,
+           "graph_equals_plain": bool(np.array_equal(a0, a1)), "samples": int(a0.size)}
+    for _ in range(3):
+        enc.run(None, feeds)
+        full.run(None, feeds)
+    w0, wm = wins[0], wins[min(1, len(wins) - 1)]
+    res["encoder_ms"] = med(lambda: enc.run(None, feeds), args.stream_reps)
+    for name, d in (("plain", dec), ("graph", decg)):
+        res[f"first_window_ms_{name}"] = med(
+            lambda: d.run(None, {"z": z[:, w0[0]:w0[1]], "sid": sid}), args.stream_reps)
+        res[f"middle_window_ms_{name}"] = med(
+            lambda: d.run(None, {"z": z[:, wm[0]:wm[1]], "sid": sid}), args.stream_reps)
+        res[f"stream_total_ms_{name}"] = med(lambda: stream(d), max(5, args.stream_reps // 3))
+        res[f"first_chunk_latency_ms_{name}"] = res["encoder_ms"] + res[f"first_window_ms_{name}"]
+    res["non_stream_ms"] = med(lambda: full.run(None, feeds), args.stream_reps)
+    res["rtf_stream_graph"] = (res["encoder_ms"] + res["stream_total_ms_graph"]) / 1e3 / res["audio_s"]
+    if args.stream_cpu:  # the oracle (CPU port of the reference) on the same two stages
+        from oracle import vits_oracle as vo  # cpu_baseline leg only -- never on the product path
+        from tests import util
+        W = {k: v.float() for k, v in checkpoint.fold_weight_norm(sd).items()}
+        cd = util.cfg_dict(cfg)
+        zt = torch.from_numpy(z).transpose(1, 2).contiguous()
+        g = W["emb_g.weight"][0:1].unsqueeze(-1)
+        for thr in (1, min(16, os.cpu_count())):  # more threads only oversubscribe this tiny conv
+            torch.set_num_threads(thr)
+            with torch.no_grad():
+                vo.decoder(W, cd, zt[:, :, w0[0]:w0[1]], g)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    vo.decoder(W, cd, zt[:, :, w0[0]:w0[1]], g)
+                res.setdefault("cpu_baseline", {"kind": "port", "sample": "first decoder window, mean of 3"})[
+                    f"first_window_ms_{thr}thr"] = (time.perf_counter() - t0) / 3 * 1e3
+    print(json.dumps(res), flush=True)
 
 
 def cpu_baseline(cfg, sd, x, lens, sid, n_utts, sr, hop):
@@ -97,6 +193,9 @@ def cpu_baseline(cfg, sd, x, lens, sid, n_utts, sr, hop):
 
 def main():
     args = parse_args()
+    if args.stream:
+        assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+        return stream_bench(args)
     from wetts_amd import SynthesizerTrn, _lib, checkpoint, config, sharding, synth
 
     rank, local_rank, world = sharding.init_process_group()

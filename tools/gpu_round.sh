@@ -26,8 +26,8 @@ WETTS_PAIR=1 WETTS_SHAPES=128:3,128:7,128:11,64:3,64:7,64:11,32:3,32:7,32:11 pyt
 WETTS_PAIR=1 WETTS_CONV_FLAGS=16 WETTS_SHAPES=128:3,128:7,128:11,64:3,64:7,64:11,32:3,32:7,32:11 python tools/bench_conv.py 32,16 > gpurun_out/conv16_fused_pair.txt 2>&1
 python tools/bench_conv.py 0 > gpurun_out/conv_microbench.txt 2>&1
 # streaming (chunked decoder) latency; and the other model families' bench lines
-python tools/bench_stream.py --model v1 > gpurun_out/stream_v1.json 2>/dev/null
-python tools/bench_stream.py --model vits2_vocos_v1 --cpu > gpurun_out/stream_vits2_vocos.json 2>/dev/null
+python bench.py --stream --model v1 > gpurun_out/stream_v1.json 2>/dev/null
+python bench.py --stream --model vits2_vocos_v1 --stream-cpu > gpurun_out/stream_vits2_vocos.json 2>/dev/null
 python bench.py --model vocos --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_vocos.json 2>/dev/null
 python bench.py --model vits2_vocos_v1 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_vits2_vocos.json 2>/dev/null
 # BASELINE configs[2] (v3, B=64, bf16) and configs[4] (builder-defined 48 kHz stress shape, f16)

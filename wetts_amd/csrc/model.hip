@@ -1404,7 +1404,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
         // the gain
         // ... and only when the launch has enough time tiles to occupy the chip: a streaming
         // window (50-60 frames) would be 25 blocks of 150 us each; the small unfused tiles spread
-        // it over 4x as many CUs (tools/bench_stream.py: 3.4 -> 2.8 ms per window)
+        // it over 4x as many CUs (bench.py --stream: 3.4 -> 2.8 ms per window)
         const int pair_tiles = cdiv(len, pair_nto(ch, rb.c1[d].ktaps)) * B;
         const bool fuse32 = c->resblock == 1 && !m->dec_unfused &&
                             resblock_pair32_supported(rb.c1[d], rb.c2[d], m->fuse32_lds) &&
