@@ -186,3 +186,16 @@ def test_graphed_stream_decoder_equals_plain():
         b = np.concatenate(list(stream_decode(graphed, zz, sid, chunk_size=40, pad_size=10)))
         assert a.shape == b.shape == (131 * net.hop_length,)
         assert np.array_equal(a, b)
+
+
+def test_vocos_needs_two_frames_like_reflection_pad():
+    """nn.ReflectionPad1d([1, 0]) (decoders.py:265) raises for a single frame; the HIP path reports
+    the same condition instead of reading out of bounds.  Two frames work."""
+    from wetts_amd import _lib
+    net, case, cfg, *_ = _model("tiny_vocos_b2")
+    z = torch.randn(1, cfg.inter_channels, 1, device="cuda")
+    with pytest.raises(_lib.WettsError, match="at least 2 frames"):
+        net.hifigan(z, None if net.n_speakers == 0 else torch.zeros(1, net.gin_channels, device="cuda"))
+    z2 = torch.randn(1, cfg.inter_channels, 2, device="cuda")
+    out = net.hifigan(z2, None if net.n_speakers == 0 else torch.zeros(1, net.gin_channels, device="cuda"))
+    assert out.shape == (1, 1, 2 * net.hop_length) and torch.isfinite(out).all()
