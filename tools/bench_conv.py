@@ -19,6 +19,7 @@ for C_, u in [(256, 8), (128, 8), (64, 2), (32, 2)]:
         shapes.append((C_, k, 5, L, 1))       # c1-style: lrelu, dilation 5
 extra = int(os.environ.get("WETTS_CONV_FLAGS", "0"), 0)  # 16: bf16 decoder kernel, 32: f16
 esz = 2 if extra & 48 else 4
+rb2 = os.environ.get("WETTS_RB2") == "1"  # with WETTS_PAIR: ResBlock2 chains (c2 residual, dilation 2d)
 pair = os.environ.get("WETTS_PAIR") == "1"  # ResBlock1 (c1 dil d, c2 dil 1) pairs: variants 32 / 16
 if pair:
     shapes = [(c, k, d, L_, 1 | 2) for (c, k, _, L_, fl) in shapes if fl == 3 for d in (1, 3, 5)]
@@ -32,7 +33,8 @@ for (ch, k, d, L, fl) in shapes:
     ref = None
     for v in variants:
         ms, cs = C.c_double(), C.c_double()
-        rc = lib.wetts_bench_conv(ch, ch, k, d, B, L, fl | extra, v, 5, C.byref(ms), C.byref(cs))
+        rc = lib.wetts_bench_conv(ch, ch, k, d, B, L, fl | extra | (64 if rb2 else 0), v, 5,
+                                  C.byref(ms), C.byref(cs))
         if rc != 0:
             row += f"  ERR {_lib.last_error()}"
             continue

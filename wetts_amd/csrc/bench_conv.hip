@@ -203,8 +203,17 @@ int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int3
     WETTS_HIP_CHECK(hipMalloc((void**)&w2, nw * 4));
     WETTS_HIP_CHECK(hipMalloc((void**)&ft, no * 4));
     WETTS_TRY(fill_pseudo(w2, nw, 5, 1.f / sqrtf((float)Cin * k), s));
-    WETTS_TRY(pack_conv_weight(w2, bias, Cout, Cin, k, 1, (k - 1) / 2, 0, 0, s, &pc2));
+    const bool rb2 = (flags & 64) != 0;  // ResBlock2 chain: both convs residual, c2 at dilation 2*dil
+    const int dil2 = rb2 ? 2 * dil : 1;
+    WETTS_TRY(pack_conv_weight(w2, bias, Cout, Cin, k, dil2, (k - 1) / 2 * dil2, 0, 0, s, &pc2));
     auto run = [&]() -> int32_t {
+      if ((variant & 16) && rb2) {
+        ResPair32Params pp;
+        memset(&pp, 0, sizeof(pp));
+        pp.x = x; pp.out = o; pp.T = T; pp.B = B; pp.accum = (flags & 4) ? 1 : 0;
+        pp.out_div = (flags & 8) ? 3.f : 1.f; pp.slope = 0.1f;
+        return launch_resblock2_chain32(pc, pc2, pp, s);
+      }
       if (variant & 16) {
         ResPair32Params pp;
         memset(&pp, 0, sizeof(pp));
@@ -215,11 +224,12 @@ int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int3
       }
       ConvParams p1 = conv_io(x, Cin, T, ft, Cout, B);
       p1.in_act = IN_LRELU; p1.in_slope = 0.1f;
+      if (rb2) { p1.res = x; p1.r_bs = (int64_t)Cout * T; p1.r_cs = T; }
       int32_t rc1 = launch_conv(pc, p1, s);
       if (rc1 != WETTS_OK) return rc1;
       ConvParams p2 = conv_io(ft, Cin, T, o, Cout, B);
       p2.in_act = IN_LRELU; p2.in_slope = 0.1f;
-      p2.res = x; p2.r_bs = (int64_t)Cout * T; p2.r_cs = T;
+      p2.res = rb2 ? ft : x; p2.r_bs = (int64_t)Cout * T; p2.r_cs = T;
       p2.accum = (flags & 4) ? 1 : 0;
       p2.out_div = (flags & 8) ? 3.f : 1.f;
       return launch_conv(pc2, p2, s);

@@ -400,6 +400,8 @@ struct wetts_model {
   int fuse32_lds = 160 * 1024;    // largest f32 pair tile run fused (WETTS_FUSE32_LDS, bytes)
   int fuse32_kmax128 = 11;        // C>=128 pairs with this many taps or more stay unfused
   int fuse_min_blocks = 128;      // fused pair kernels need this many tiles (else: small unfused tiles)
+  int fuse2_waste_pct = 15;       // ResBlock2 chains: max % of tile columns lost to c2's halo at C = 32
+                                  // (HBM-bound, +6..30 %); half of it at C >= 64 (profiles/r01_conv32_rb2_chain.txt)
   mutable std::vector<PackedConvB> b_ups;
   mutable std::vector<std::vector<PackedConvB>> b_c1, b_c2;  // per resblock
   int mrf_streams = 1;
@@ -808,6 +810,8 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     if (fk) m->fuse32_kmax128 = atoi(fk);
     const char* fm = getenv("WETTS_FUSE_MIN_BLOCKS");
     if (fm) m->fuse_min_blocks = atoi(fm);
+    const char* fw2 = getenv("WETTS_FUSE2_WASTE_PCT");
+    if (fw2) m->fuse2_waste_pct = atoi(fw2);
     (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
     for (int j = 0; j < cfg->n_resblock_kernels; ++j) {
       (void)hipEventCreateWithFlags(&m->ev_chain[j], hipEventDisableTiming);
@@ -1398,6 +1402,27 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           odiv = (j == nk - 1) ? (float)nk : 1.f;  // x = xs / self.num_kernels
         } else {
           outp = (rx == fa) ? fb : fa;
+        }
+        // ResBlock2 (two residual convs): both dilations in one launch where the second conv's
+        // halo wastes little of the tile; then the d loop is done
+        if (c->resblock == 2 && nd == 2 && d == 0 && !m->dec_unfused && !forked &&
+            resblock2_chain32_supported(rb.c1[0], rb.c1[1], m->fuse32_lds,
+                                        ch <= 32 ? m->fuse2_waste_pct : (m->fuse2_waste_pct + 1) / 2) &&
+            cdiv(len, pair_nto(ch, 1) - (rb.c1[1].ktaps - 1) * rb.c1[1].dil) * B >= m->fuse_min_blocks) {
+          ResPair32Params pp;
+          memset(&pp, 0, sizeof(pp));
+          pp.x = rx;
+          pp.out = xsum;
+          pp.T = len;
+          pp.B = B;
+          pp.accum = (j > 0) ? 1 : 0;
+          pp.out_div = (j == nk - 1) ? (float)nk : 1.f;
+          pp.slope = 0.1f;
+          WETTS_TRY(launch_resblock2_chain32(rb.c1[0], rb.c1[1], pp, sj));
+          if (tm && tm->on) tm->launches += 1;
+          if (m->mrf_timing) m->mrf_launches += 1;
+          rx = xsum;
+          break;
         }
         // fused wherever it measures faster (profiles/r01_conv32_fused_pair.txt): everything but
         // the MFMA-bound C=128, k=11 pairs, whose 2*(k-1)/2 discarded columns per 128 outweigh

@@ -12,7 +12,8 @@ struct ResPair32Params {
   const float *wpk1, *wpk2;  // pack_conv_weight layouts of c1 / c2
   const float *bias1, *bias2;
   int T, B;
-  int ktaps, dil;  // c1: ktaps taps at dilation dil; c2: ktaps taps at dilation 1
+  int ktaps, dil;  // c1: ktaps taps at dilation dil; c2: ktaps taps at dilation 1 (ResBlock1) / dil2
+  int dil2;        // ResBlock2 chain only: dilation of the second conv
   int accum;       // add the previous contents of out (running MRF sum)
   float out_div;
   float slope;     // leaky-relu slope in front of both convs
@@ -25,5 +26,13 @@ struct ResPair32Params {
 bool resblock_pair32_supported(const PackedConv& c1, const PackedConv& c2, int max_lds_bytes);
 int32_t launch_resblock_pair32(const PackedConv& c1, const PackedConv& c2, ResPair32Params p,
                                hipStream_t stream);
+
+// ResBlock2 (decoders.py:205-214) as one launch: out = (t1 + c2(lrelu(t1)) [+ out]) / div with
+// t1 = x + c1(lrelu(x)); c2 keeps its own dilation.  max_waste_pct bounds the share of tile columns
+// the second conv's halo discards ((k-1)*d2 of NTC).
+bool resblock2_chain32_supported(const PackedConv& c1, const PackedConv& c2, int max_lds_bytes,
+                                 int max_waste_pct);
+int32_t launch_resblock2_chain32(const PackedConv& c1, const PackedConv& c2, ResPair32Params p,
+                                 hipStream_t stream);
 
 }  // namespace wetts

@@ -26,7 +26,14 @@ namespace wetts {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };  // dword-aligned 16-byte load
 
-template <int C, bool DBG>
+// RB2 = true: the ResBlock2 chain (decoders.py:205-214)  t1 = x + c1(lrelu(x)),
+// out = t1 + c2(lrelu(t1)) with c2 at dilation p.dil2.  c2 uses the SAME column -> time mapping as
+// c1 (column c = time n0-h2+c), so the raw t1 a lane needs as c2's residual is the value already in
+// its own accumulators: c2 simply keeps accumulating.  lrelu(t1) goes to the tile shifted by h2
+// columns (c2 reads column c + tap*dil2); valid outputs are the middle columns [h2, NTC-h2).
+// (A first version kept the tile raw and applied leaky-relu at the B read: the two VALU ops in
+// front of every MFMA made it slower than two launches.)
+template <int C, bool DBG, bool RB2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void resblock_pair32_kernel(const ResPair32Params p) {
   constexpr int WM = C / 32, WN = 4 / WM, NB = 4;
@@ -45,7 +52,8 @@ void resblock_pair32_kernel(const ResPair32Params p) {
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5;
 
-  const int h2 = (p.ktaps - 1) / 2, h1 = h2 * p.dil;
+  const int dil2 = RB2 ? p.dil2 : 1;
+  const int h2 = (p.ktaps - 1) / 2 * dil2, h1 = (p.ktaps - 1) / 2 * p.dil;
   const int NTO = NTC - 2 * h2;
   const int Wp = p.Wp;
   int bid = blockIdx.x;
@@ -69,6 +77,25 @@ void resblock_pair32_kernel(const ResPair32Params p) {
   float4 aa[2];
   aa[0] = abase1[0];
   aa[1] = aa[0];
+
+  // Raw residual, requested first so that it is the oldest load in flight.  ResBlock1: x at c2's
+  // output columns (time n0 + col), consumed after c1.  ResBlock2: x at c1's columns (time
+  // n0 - h2 + col), which initialises c1's accumulators.
+  const int co_blk = wm * 32;
+  const int wcol = wn * (32 * NB) + (lane & 31);
+  float rres[NB][16];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int col = wcol + 32 * j;
+    const int t = RB2 ? n0 - h2 + col : n0 + col;
+    const bool ok = (RB2 ? t >= 0 : col < NTO) && t < p.T && !(DBG && (ab & 2));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = 0.f;
+      if (ok) v = xb[(int64_t)(co_blk + (r & 3) + 8 * (r >> 2) + 4 * half) * p.T + t];
+      rres[j][r] = v;
+    }
+  }
 
   // ---- 1. stage lrelu(x): wave w takes rows w, w+4, ...; a lane takes 16-byte pieces --------
   {
@@ -125,9 +152,13 @@ void resblock_pair32_kernel(const ResPair32Params p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  const int co_blk = wm * 32;
-  const int wcol = wn * (32 * NB) + (lane & 31);
   const float* bcol = smem_p + (size_t)half * Wp + wcol;
+  if (RB2) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = rres[j][r];
+  }
 
   // 16 MFMAs of one group: k-steps s = 0..3 are channels chunk*16 + hp*8 + 2s + half
   auto mma_group = [&](const float4& av, int chunk, int tap, int hp, int dil) {
@@ -160,22 +191,6 @@ void resblock_pair32_kernel(const ResPair32Params p) {
     }
   };
 
-  // raw residual for c2's accumulator: requested now (L2 hits: the tile was just read), consumed
-  // after c1, so its latency hides behind c1's MFMA work
-  float rres[NB][16];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int col = wcol + 32 * j;
-    const int t = n0 + col;
-    const bool ok = col < NTO && t < p.T && !(DBG && (ab & 2));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = 0.f;
-      if (ok) v = xb[(int64_t)(co_blk + (r & 3) + 8 * (r >> 2) + 4 * half) * p.T + t];
-      rres[j][r] = v;
-    }
-  }
-
   // ---- 2. c1 ---------------------------------------------------------------------------------
   conv_loop(abase1, p.dil);
   aa[0] = abase2[0];  // c2's first group; lands during step 3
@@ -194,8 +209,10 @@ void resblock_pair32_kernel(const ResPair32Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[j][r] + bia[r];
+        if (RB2) acc[j][r] = v;  // raw t1: c2's residual, already in place
         v = v > 0.f ? v : v * p.slope;
-        smem_p[(size_t)(co_blk + (r & 3) + 8 * (r >> 2) + 4 * half) * Wp + col] = inside ? v : 0.f;
+        smem_p[(size_t)(co_blk + (r & 3) + 8 * (r >> 2) + 4 * half) * Wp + col + (RB2 ? h2 : 0)] =
+            inside ? v : 0.f;
       }
     }
   }
@@ -204,17 +221,18 @@ void resblock_pair32_kernel(const ResPair32Params p) {
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int col = wcol + 32 * j;
-    const int t = n0 + col;
-    const bool ok = col < NTO && t < p.T && !(DBG && (ab & 2));
+    const int t = RB2 ? n0 - h2 + col : n0 + col;
+    const bool ok = (RB2 ? (col >= h2 && col < NTC - h2 && t >= 0) : col < NTO) && t < p.T &&
+                    !(DBG && (ab & 2));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float v = rres[j][r];
+      float v = RB2 ? acc[j][r] : rres[j][r];
       if (p.accum && ok) v += ob[(int64_t)(co_blk + (r & 3) + 8 * (r >> 2) + 4 * half) * p.T + t];
       acc[j][r] = v;
     }
   }
   __syncthreads();  // ft complete
-  conv_loop(abase2, 1);
+  conv_loop(abase2, dil2);
 
   // ---- 5. epilogue -----------------------------------------------------------------------------
   float bia[16];
@@ -224,8 +242,9 @@ void resblock_pair32_kernel(const ResPair32Params p) {
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int col = wcol + 32 * j;
-    const int t = n0 + col;
-    if (col >= NTO || t >= p.T) continue;
+    const int t = RB2 ? n0 - h2 + col : n0 + col;
+    if (RB2 ? (col < h2 || col >= NTC - h2 || t < 0) : col >= NTO) continue;
+    if (t >= p.T) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float v = acc[j][r] + bia[r];
@@ -236,14 +255,16 @@ void resblock_pair32_kernel(const ResPair32Params p) {
   }
 }
 
-template <int C>
+template <int C, bool RB2>
 static int32_t launch_pair32(const ResPair32Params& p0, hipStream_t stream) {
   constexpr int WM = C / 32, WN = 4 / WM, NTC = 128 * WN;
   ResPair32Params p = p0;
-  const int h2 = (p.ktaps - 1) / 2, h1 = h2 * p.dil;
+  const int h2 = (p.ktaps - 1) / 2 * (RB2 ? p.dil2 : 1), h1 = (p.ktaps - 1) / 2 * p.dil;
   const int NTO = NTC - 2 * h2;
+  WETTS_REQUIRE(NTO > 0, "second conv's halo exceeds the tile");
   p.ntiles = cdiv(p.T, NTO);
-  p.Wp = (NTC + 2 * h1 + 3) & ~3;
+  // the tile also backs c2's reads of its (discarded) last columns: NTC + 2*max(h1, h2) wide
+  p.Wp = (NTC + 2 * (h1 > h2 ? h1 : h2) + 3) & ~3;
   const int64_t nb = (int64_t)p.ntiles * p.B;
   if (nb <= 0) return WETTS_OK;
   WETTS_REQUIRE(nb < (1ll << 30), "resblock grid too large");
@@ -254,17 +275,17 @@ static int32_t launch_pair32(const ResPair32Params& p0, hipStream_t stream) {
   const int dbg = p.ablate ? 1 : 0;
   if (!attr_done[dbg]) {  // tiles above the default 64 KB dynamic-LDS limit
     if (dbg)
-      WETTS_HIP_CHECK(hipFuncSetAttribute((const void*)resblock_pair32_kernel<C, true>,
+      WETTS_HIP_CHECK(hipFuncSetAttribute((const void*)resblock_pair32_kernel<C, true, RB2>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     else
-      WETTS_HIP_CHECK(hipFuncSetAttribute((const void*)resblock_pair32_kernel<C, false>,
+      WETTS_HIP_CHECK(hipFuncSetAttribute((const void*)resblock_pair32_kernel<C, false, RB2>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dbg] = true;
   }
   if (dbg)
-    hipLaunchKernelGGL((resblock_pair32_kernel<C, true>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((resblock_pair32_kernel<C, true, RB2>), dim3(grid), dim3(256), lds, stream, p);
   else
-    hipLaunchKernelGGL((resblock_pair32_kernel<C, false>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((resblock_pair32_kernel<C, false, RB2>), dim3(grid), dim3(256), lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -292,10 +313,46 @@ int32_t launch_resblock_pair32(const PackedConv& c1, const PackedConv& c2, ResPa
   WETTS_REQUIRE(p.bias1 && p.bias2, "resblock convs carry a bias");
   p.ktaps = c1.ktaps;
   p.dil = c1.dil;
+  p.dil2 = 1;
   switch (c1.Cin) {
-    case 32: return launch_pair32<32>(p, stream);
-    case 64: return launch_pair32<64>(p, stream);
-    default: return launch_pair32<128>(p, stream);
+    case 32: return launch_pair32<32, false>(p, stream);
+    case 64: return launch_pair32<64, false>(p, stream);
+    default: return launch_pair32<128, false>(p, stream);
+  }
+}
+
+// ResBlock2 (decoders.py:205-214): both convs carry the residual; c2 keeps its own dilation
+bool resblock2_chain32_supported(const PackedConv& c1, const PackedConv& c2, int max_lds_bytes,
+                                 int max_waste_pct) {
+  const int C = c1.Cin;
+  if (!(C == 32 || C == 64 || C == 128)) return false;
+  if (c1.Cout != C || c2.Cin != C || c2.Cout != C || c1.up || c2.up) return false;
+  if (c1.M != C || c2.M != C) return false;
+  if (c1.ktaps != c2.ktaps || (c1.ktaps & 1) == 0) return false;
+  if (c1.pad != (c1.ktaps - 1) / 2 * c1.dil || c2.pad != (c2.ktaps - 1) / 2 * c2.dil) return false;
+  const int span = (c1.ktaps - 1) * (c1.dil > c2.dil ? c1.dil : c2.dil);
+  if (span > RESPAIR32_MAX_SPAN) return false;
+  const int NTC = 128 * (4 / (C / 32));
+  const int lost = (c2.ktaps - 1) * c2.dil;  // columns of the tile the second conv cannot produce
+  if (lost * 100 > max_waste_pct * NTC) return false;
+  const int Wp = (NTC + span + 3) & ~3;
+  return (int64_t)C * Wp * 4 <= max_lds_bytes;
+}
+
+int32_t launch_resblock2_chain32(const PackedConv& c1, const PackedConv& c2, ResPair32Params p,
+                                 hipStream_t stream) {
+  WETTS_REQUIRE(resblock2_chain32_supported(c1, c2, 160 * 1024, 100),
+                "ResBlock2 shape not supported by the fused f32 kernel");
+  WETTS_REQUIRE(c1.wpk && c2.wpk && c1.bias && c2.bias, "conv weight not packed");
+  p.wpk1 = c1.wpk; p.bias1 = c1.bias;
+  p.wpk2 = c2.wpk; p.bias2 = c2.bias;
+  p.ktaps = c1.ktaps;
+  p.dil = c1.dil;
+  p.dil2 = c2.dil;
+  switch (c1.Cin) {
+    case 32: return launch_pair32<32, true>(p, stream);
+    case 64: return launch_pair32<64, true>(p, stream);
+    default: return launch_pair32<128, true>(p, stream);
   }
 }
 
