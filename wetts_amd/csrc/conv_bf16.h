@@ -42,7 +42,8 @@ struct ResPairParams {
   const unsigned short *wpk1, *wpk2;
   const float *bias1, *bias2;
   int T, B;
-  int ktaps, dil;  // c1: ktaps taps at dilation dil; c2: ktaps taps at dilation 1
+  int ktaps, dil;  // c1: ktaps taps at dilation dil; c2: ktaps taps at dilation 1 (ResBlock1) / dil2
+  int dil2;        // ResBlock2 chain only
   int accum;       // add the previous contents of out (running MRF sum)
   float out_div;
   float slope;     // leaky-relu slope in front of both convs
@@ -53,6 +54,10 @@ struct ResPairParams {
 bool resblock_pair16_supported(const PackedConvB& c1, const PackedConvB& c2);
 int32_t launch_resblock_pair16(const PackedConvB& c1, const PackedConvB& c2, ResPairParams p,
                                hipStream_t stream);
+// a whole ResBlock2 (two residual convs, c2 at its own dilation) in one launch
+bool resblock2_chain16_supported(const PackedConvB& c1, const PackedConvB& c2, int max_waste_pct);
+int32_t launch_resblock2_chain16(const PackedConvB& c1, const PackedConvB& c2, ResPairParams p,
+                                 hipStream_t stream);
 
 int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
                               int dil, int pad, int transposed, int up, int f16, hipStream_t stream,

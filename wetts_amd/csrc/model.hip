@@ -1637,6 +1637,26 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
         unsigned short* outp = last_d ? xsum : ((rx == fa) ? fb : fa);
         const int accum = (last_d && j > 0) ? 1 : 0;
         const float odiv = (last_d && j == nk - 1) ? (float)nk : 1.f;
+        if (c->resblock == 2 && nd == 2 && d == 0 && !m->dec_unfused &&
+            resblock2_chain16_supported(m->b_c1[n][0], m->b_c1[n][1],
+                                        ch <= 32 ? m->fuse2_waste_pct : (m->fuse2_waste_pct + 1) / 2) &&
+            cdiv(len, pair_nto(ch, 1) - (m->b_c1[n][1].ktaps - 1) * m->b_c1[n][1].dil) * B >=
+                m->fuse_min_blocks) {
+          // a whole ResBlock2 in one launch (see resblock16.hip, RB2)
+          ResPairParams pp;
+          memset(&pp, 0, sizeof(pp));
+          pp.x = rx;
+          pp.out = xsum;
+          pp.T = len;
+          pp.B = B;
+          pp.accum = (j > 0) ? 1 : 0;
+          pp.out_div = (j == nk - 1) ? (float)nk : 1.f;
+          pp.slope = 0.1f;
+          WETTS_TRY(launch_resblock2_chain16(m->b_c1[n][0], m->b_c1[n][1], pp, s));
+          if (m->mrf_timing) m->mrf_launches += 1;
+          rx = xsum;
+          break;
+        }
         if (c->resblock == 1 && !m->dec_unfused &&
             resblock_pair16_supported(m->b_c1[n][d], m->b_c2[n][d]) &&
             cdiv(len, pair_nto(ch, m->b_c1[n][d].ktaps)) * B >= m->fuse_min_blocks) {
@@ -1650,6 +1670,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           pp.out_div = odiv;
           pp.slope = 0.1f;
           WETTS_TRY(launch_resblock_pair16(m->b_c1[n][d], m->b_c2[n][d], pp, s));
+          if (m->mrf_timing) m->mrf_launches += 1;
         } else if (c->resblock == 1) {
           WETTS_TRY(launch_conv_bf16(m->b_c1[n][d], convb_io(rx, ch, len, ft, ch, len, B), s));
           ConvBParams p2 = convb_io(ft, ch, len, outp, ch, len, B);
@@ -1658,6 +1679,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           p2.accum = accum;
           p2.out_div = odiv;
           WETTS_TRY(launch_conv_bf16(m->b_c2[n][d], p2, s));
+          if (m->mrf_timing) m->mrf_launches += 2;
         } else {
           ConvBParams p1 = convb_io(rx, ch, len, outp, ch, len, B);
           p1.res = rx;
@@ -1665,6 +1687,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           p1.accum = accum;
           p1.out_div = odiv;
           WETTS_TRY(launch_conv_bf16(m->b_c1[n][d], p1, s));
+          if (m->mrf_timing) m->mrf_launches += 1;
         }
         rx = outp;
       }
@@ -1672,12 +1695,6 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
     if (m->mrf_timing) {
       WETTS_HIP_CHECK(hipEventRecord(lv1, s));
       m->mrf_events.emplace_back(lv0, lv1);
-      int64_t per = (c->resblock == 1) ? 2 : 1;
-      if (c->resblock == 1 && !m->dec_unfused &&
-          resblock_pair16_supported(m->b_c1[i * nk][0], m->b_c2[i * nk][0]) &&
-          cdiv(len, pair_nto(ch, m->b_c1[i * nk][0].ktaps)) * B >= m->fuse_min_blocks)
-        per = 1;
-      m->mrf_launches += (int64_t)nk * nd * per;
     }
     x = xsum;
   }

@@ -28,7 +28,11 @@ namespace wetts {
 // NR = depth of the A-fragment register ring in (chunk, tap) groups: the fragments of group g+NR-1
 // are requested while group g computes, which has to cover a loaded L2 round trip (~1-2 us);
 // OCC = waves per SIMD the register allocation is held to.
-template <int C, bool F16, int NR, int OCC, bool DBG>
+// RB2 = true: a whole ResBlock2 (decoders.py:205-214: both convs residual, c2 at dilation p.dil2) --
+// c2 shares c1's column -> time mapping, so the rounded t1 a lane needs as c2's residual is what its
+// accumulators just produced; lrelu(t1) is written h2 rows down the tile, valid outputs are the
+// middle columns [h2, NTC - h2)  (see resblock32.hip).
+template <int C, bool F16, int NR, int OCC, bool DBG, bool RB2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 void resblock_pair16_kernel(const ResPairParams p) {
   constexpr int WM = C / 32, WN = 4 / WM, NB = 4;
@@ -49,7 +53,8 @@ void resblock_pair16_kernel(const ResPairParams p) {
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5;
 
-  const int h2 = (p.ktaps - 1) / 2, h1 = h2 * p.dil;
+  const int dil2 = RB2 ? p.dil2 : 1;
+  const int h2 = (p.ktaps - 1) / 2 * dil2, h1 = (p.ktaps - 1) / 2 * p.dil;
   const int NTO = NTC - 2 * h2;
   // XCD-aware tile order: the 8 XCDs take blocks round-robin, so give each XCD a contiguous run
   // of time tiles (neighbours share their halo rows through that XCD's L2)
@@ -62,7 +67,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
   const int ntile = bid % p.ntiles;
   const int b = bid / p.ntiles;
   const int n0 = ntile * NTO;
-  const int W1 = NTC + 2 * h1;
+  const int W1 = NTC + 2 * (h1 > h2 ? h1 : h2);  // also backs c2's reads of its discarded columns
   const int tx0 = n0 - h2 - h1;  // time of LDS row 0 of the x tile
 
   const unsigned short* xb = p.x + (int64_t)b * p.T * C;
@@ -82,6 +87,25 @@ void resblock_pair16_kernel(const ResPairParams p) {
     for (int s = 0; s < KS; ++s) aa[NR - 1][s] = aa[0][s];
   };
   a_prologue(abase1);
+
+  // ResBlock2: raw x at c1's columns (time n0 - h2 + col) initialises c1's accumulators; requested
+  // first so it is the oldest load in flight
+  const int co_blk = wm * 32;
+  const int wcol = wn * (32 * NB) + (lane & 31);  // this lane's column of n-block 0
+  uint4 rres[NB][2];
+  if (RB2) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = n0 - h2 + wcol + 32 * j;
+      const bool ok = t >= 0 && t < p.T && !(DBG && (ab & 2));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + co_blk + 16 * i + 8 * half);
+        rres[j][i] = v;
+      }
+    }
+  }
 
   // ---- 1. stage lrelu(x) ---------------------------------------------------------------------
   {
@@ -117,9 +141,20 @@ void resblock_pair16_kernel(const ResPairParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  const int co_blk = wm * 32;
-  const int wcol = wn * (32 * NB) + (lane & 31);  // this lane's column of n-block 0
   const unsigned char* bcol = smem_r + (size_t)wcol * RS + half * 16;
+  if (RB2) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned w4[4] = {rres[j][i].x, rres[j][i].y, rres[j][i].z, rres[j][i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[j][8 * i + 2 * e] = lo16<F16>(w4[e]);
+          acc[j][8 * i + 2 * e + 1] = hi16<F16>(w4[e]);
+        }
+      }
+  }
 
   // one conv over the LDS tile: groups g = chunk*ktaps + tap, A fragments from the register ring.
   // The prefetch of group g+NR-1 is issued UNCONDITIONALLY (index clamped to the last group):
@@ -168,12 +203,11 @@ void resblock_pair16_kernel(const ResPairParams p) {
 
   // c2's first A groups and the raw residual are requested now; they land during step 3
   a_prologue(abase2);
-  uint4 rres[NB][2];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int col = wcol + 32 * j;
     const int t = n0 + col;
-    const bool ok = col < NTO && t < p.T && !(DBG && (ab & 2));
+    const bool ok = !RB2 && col < NTO && t < p.T && !(DBG && (ab & 2));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -200,10 +234,14 @@ void resblock_pair16_kernel(const ResPairParams p) {
         for (int e = 0; e < 4; ++e) {
           const unsigned r16 = pk2<F16>(acc[j][8 * i + 2 * e] + bia[8 * i + 2 * e],
                                         acc[j][8 * i + 2 * e + 1] + bia[8 * i + 2 * e + 1]);
+          if (RB2) {  // the rounded t1 is c2's residual: it stays in the accumulators
+            acc[j][8 * i + 2 * e] = lo16<F16>(r16);
+            acc[j][8 * i + 2 * e + 1] = hi16<F16>(r16);
+          }
           w[e] = inside ? lrelu_pk<F16>(r16, p.slope) : 0u;
         }
-        *reinterpret_cast<uint4*>(smem_r + (size_t)col * RS + (co_blk + 16 * i + 8 * half) * 2) =
-            make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4*>(smem_r + (size_t)(col + (RB2 ? h2 : 0)) * RS +
+                                  (co_blk + 16 * i + 8 * half) * 2) = make_uint4(w[0], w[1], w[2], w[3]);
       }
     }
     __syncthreads();
@@ -214,16 +252,16 @@ void resblock_pair16_kernel(const ResPairParams p) {
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int col = wcol + 32 * j;
-    const int t = n0 + col;
-    const bool ok = col < NTO && t < p.T;
+    const int t = RB2 ? n0 - h2 + col : n0 + col;
+    const bool ok = (RB2 ? (col >= h2 && col < NTC - h2 && t >= 0) : col < NTO) && t < p.T;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const unsigned w4[4] = {rres[j][i].x, rres[j][i].y, rres[j][i].z, rres[j][i].w};
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[2 * e] = lo16<F16>(w4[e]);
-        v[2 * e + 1] = hi16<F16>(w4[e]);
+        v[2 * e] = RB2 ? acc[j][8 * i + 2 * e] : lo16<F16>(w4[e]);
+        v[2 * e + 1] = RB2 ? acc[j][8 * i + 2 * e + 1] : hi16<F16>(w4[e]);
       }
       if (p.accum && ok) {
         const uint4 oo = *reinterpret_cast<const uint4*>(ob + (int64_t)t * C + co_blk + 16 * i + 8 * half);
@@ -238,7 +276,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
       for (int e = 0; e < 8; ++e) acc[j][8 * i + e] = v[e];
     }
   }
-  conv_loop(abase2, 1);
+  conv_loop(abase2, dil2);
 
   // ---- 5. epilogue -----------------------------------------------------------------------------
   float bia[16];
@@ -248,8 +286,9 @@ void resblock_pair16_kernel(const ResPairParams p) {
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int col = wcol + 32 * j;
-    const int t = n0 + col;
-    if (col >= NTO || t >= p.T) continue;
+    const int t = RB2 ? n0 - h2 + col : n0 + col;
+    if (RB2 ? (col < h2 || col >= NTC - h2 || t < 0) : col >= NTO) continue;
+    if (t >= p.T) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float v[8];
@@ -267,25 +306,26 @@ void resblock_pair16_kernel(const ResPairParams p) {
   }
 }
 
-template <int C, int NR, int OCC>
+template <int C, int NR, int OCC, bool RB2>
 static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream) {
   constexpr int WM = C / 32, WN = 4 / WM, NTC = 128 * WN, RS = C * 2 + 16;
   ResPairParams p = p0;
-  const int h2 = (p.ktaps - 1) / 2, h1 = h2 * p.dil;
+  const int h2 = (p.ktaps - 1) / 2 * (RB2 ? p.dil2 : 1), h1 = (p.ktaps - 1) / 2 * p.dil;
   const int NTO = NTC - 2 * h2;
+  WETTS_REQUIRE(NTO > 0, "second conv's halo exceeds the tile");
   p.ntiles = cdiv(p.T, NTO);
   const int64_t nb = (int64_t)p.ntiles * p.B;
   if (nb <= 0) return WETTS_OK;
   WETTS_REQUIRE(nb < (1ll << 30), "resblock grid too large");
   p.nblocks = (int)nb;
   const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);
-  const size_t lds = (size_t)(NTC + 2 * h1) * RS;
+  const size_t lds = (size_t)(NTC + 2 * (h1 > h2 ? h1 : h2)) * RS;
   if (p.ablate)  // microbench instrumentation (bf16 storage only)
-    hipLaunchKernelGGL((resblock_pair16_kernel<C, false, NR, OCC, true>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, false, NR, OCC, true, RB2>), dim3(grid), dim3(256), lds, stream, p);
   else if (f16)
-    hipLaunchKernelGGL((resblock_pair16_kernel<C, true, NR, OCC, false>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, true, NR, OCC, false, RB2>), dim3(grid), dim3(256), lds, stream, p);
   else
-    hipLaunchKernelGGL((resblock_pair16_kernel<C, false, NR, OCC, false>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, false, NR, OCC, false, RB2>), dim3(grid), dim3(256), lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -310,10 +350,39 @@ int32_t launch_resblock_pair16(const PackedConvB& c1, const PackedConvB& c2, Res
   const bool h = c1.f16 != 0;
   // ring depth 2 at 3 waves/SIMD measured best (profiles/r01_conv16_fused_pair.txt: deeper rings
   // cost occupancy or issue slots and lose 5-15 %)
+  p.dil2 = 1;
   switch (c1.Cin) {
-    case 32: return launch_pair<32, 2, 3>(p, h, stream);
-    case 64: return launch_pair<64, 2, 3>(p, h, stream);
-    default: return launch_pair<128, 2, 3>(p, h, stream);
+    case 32: return launch_pair<32, 2, 3, false>(p, h, stream);
+    case 64: return launch_pair<64, 2, 3, false>(p, h, stream);
+    default: return launch_pair<128, 2, 3, false>(p, h, stream);
+  }
+}
+
+bool resblock2_chain16_supported(const PackedConvB& c1, const PackedConvB& c2, int max_waste_pct) {
+  const int C = c1.Cin;
+  if (!(C == 32 || C == 64 || C == 128)) return false;
+  if (c1.Cout != C || c2.Cin != C || c2.Cout != C || c1.up || c2.up) return false;
+  if (c1.ktaps != c2.ktaps || (c1.ktaps & 1) == 0 || c1.f16 != c2.f16) return false;
+  if (c1.pad != (c1.ktaps - 1) / 2 * c1.dil || c2.pad != (c2.ktaps - 1) / 2 * c2.dil) return false;
+  if ((c1.ktaps - 1) * (c1.dil > c2.dil ? c1.dil : c2.dil) > RESPAIR_MAX_SPAN) return false;
+  const int NTC = 128 * (4 / (C / 32));
+  return (c2.ktaps - 1) * c2.dil * 100 <= max_waste_pct * NTC;
+}
+
+int32_t launch_resblock2_chain16(const PackedConvB& c1, const PackedConvB& c2, ResPairParams p,
+                                 hipStream_t stream) {
+  WETTS_REQUIRE(resblock2_chain16_supported(c1, c2, 100), "ResBlock2 shape not supported by the fused kernel");
+  WETTS_REQUIRE(c1.wpk && c2.wpk, "16-bit conv weight not packed");
+  p.wpk1 = c1.wpk; p.bias1 = c1.bias;
+  p.wpk2 = c2.wpk; p.bias2 = c2.bias;
+  p.ktaps = c1.ktaps;
+  p.dil = c1.dil;
+  p.dil2 = c2.dil;
+  const bool h = c1.f16 != 0;
+  switch (c1.Cin) {
+    case 32: return launch_pair<32, 2, 3, true>(p, h, stream);
+    case 64: return launch_pair<64, 2, 3, true>(p, h, stream);
+    default: return launch_pair<128, 2, 3, true>(p, h, stream);
   }
 }
 
