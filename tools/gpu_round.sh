@@ -34,3 +34,7 @@ python bench.py --model vits2_vocos_v1 --steps 10 --warmup 3 --no-cpu-baseline >
 python bench.py --model v3 --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --decoder-dtype bf16 > gpurun_out/bench_cfg3_v3_b64_bf16.json 2>/dev/null
 python bench.py --model v3 --batch 64 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_cfg3_v3_b64_f32.json 2>/dev/null
 python bench.py --model stress48k --steps 10 --warmup 3 --no-cpu-baseline --decoder-dtype f16 > gpurun_out/bench_cfg5_stress48k_f16.json 2>/dev/null
+# control flow of the multi-rank bench (two ranks sharing this one GPU, gloo for the broadcast):
+# the driver runs the real N = 2/4/8 RCCL scaling bench at round end
+WETTS_BENCH_SINGLE_DEVICE=1 WETTS_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_2rank_dryrun.json 2> gpurun_out/bench_2rank_dryrun.err
+tail -c 400 gpurun_out/bench_2rank_dryrun.json
