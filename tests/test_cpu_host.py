@@ -23,7 +23,9 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert _lib.load().wetts_abi_version() == 4
+    assert _lib.load().wetts_abi_version() == _lib.ABI_VERSION
+    m = re.search(r"#define WETTS_ABI_VERSION (\d+)", src)
+    assert m and int(m.group(1)) == _lib.ABI_VERSION  # header and ctypes binding move together
 
 
 @pytest.mark.parametrize("mname", ["v1", "v2", "v3", "stress48k", "tiny", "tiny_dp", "vocos", "tiny_vocos", "vits2_vocos_v1",

@@ -22,6 +22,9 @@ class WettsError(RuntimeError):
     pass
 
 
+ABI_VERSION = 4  # WETTS_ABI_VERSION of include/wetts_hip.h this binding was written against
+
+
 class Config(C.Structure):
     """Mirror of wetts_config_t."""
     _fields_ = [
@@ -128,7 +131,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError => header / library mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.wetts_abi_version() != 4:
+    if lib.wetts_abi_version() != ABI_VERSION:
         raise WettsError("libwetts_hip.so ABI version mismatch")
     _lib = lib
     return lib
