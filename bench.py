@@ -342,8 +342,8 @@ def main():
         roofline = {
             "kernel": ("conv_mfma_kernel (Vocos ConvNeXt pointwise GEMMs 512<->1536)"
                        if "vocos" in args.model else
-                       "resblock_pair32_kernel + conv_mfma_kernel (MRF ResBlock convs; pairs fused "
-                       "except C>=256 and C=128,k=11)"),
+                       "conv_mfma_kernel + resblock_pair32_kernel (MRF ResBlock convs; the C=32 "
+                       "stage runs as fused pairs)"),
             "bound": "mfma", "achieved": mrf_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": mrf_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
             "traffic_unit": "HBM bytes per conv_mfma launch (2*FETCH_SIZE+WRITE_SIZE)*1024, PMC",

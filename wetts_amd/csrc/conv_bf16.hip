@@ -98,7 +98,10 @@ void free_packed_bf16(PackedConvB* pc) {
 // the conv kernel: 4 waves (WM x WN), each wave one 32-row m-block x NB 32-column n-blocks
 // ------------------------------------------------------------------------------------------
 template <int NB, int WM, int WN, int CKB, bool F16, bool DBG>
-__global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBParams p) {
+// three waves per SIMD where the register allocation reaches it without heavy spilling (the compiler
+// otherwise spreads over VGPRs + AGPRs and settles at two)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CKB == 32 || WM == 4) ? 3 : 1)))
+void conv_bf16_kernel(const ConvBParams p) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int MT = 32 * WM;
   constexpr int NT = 32 * NB * WN;

@@ -115,8 +115,12 @@ void free_packed(PackedConv* pc) {
 // OPT (experiment bits): 1 = stagger the staging-load issue point across co-resident blocks, 2 = ping-pong A registers,
 // compile-time ablations for the microbenchmark: 4 no A loads, 8 no LDS B reads, 16 no staging
 // loads/stores, 32 no per-chunk barrier; 64 = name tag of the MRF launches (no code change).
+// Four 32x32 accumulators per wave (64 AGPRs) plus ~105 VGPRs sat one allocation granule above the
+// three-waves-per-SIMD budget (168 registers): asking for three waves makes the compiler fit, and
+// the extra resident wave hides the staging / A-fragment waits of the chunked loop.
 template <int MB, int NB, int WM, int WN, bool PF, bool DBG = false, int EPI = 0, int OPT = 0>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB * NB >= 4 && WN < 4) ? 3 : 1)))
+void conv_mfma_kernel(const ConvParams p) {
   // DBG instantiations honour p.ablate (microbenchmark only): 1 no MFMA, 2 no staging loads,
   // 4 no A loads, 8 no epilogue stores, 16 no LDS B reads
   static_assert(WM * WN == 4, "4 waves per block");

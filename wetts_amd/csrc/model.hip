@@ -399,6 +399,11 @@ struct wetts_model {
   mutable int dec_unfused = 0;    // diagnostic: run ResBlock1 pairs as two conv launches
   int fuse32_lds = 160 * 1024;    // largest f32 pair tile run fused (WETTS_FUSE32_LDS, bytes)
   int fuse32_kmax128 = 11;        // C>=128 pairs with this many taps or more stay unfused
+  int fuse32_maxc = 32;           // widest stage whose f32 pairs run fused (WETTS_FUSE32_MAXC): since the
+                                  // chunked kernel runs at 4 waves/SIMD it wins at C >= 64
+                                  // (profiles/r01_conv32_fused_pair.txt; step 79.9 none / 78.4 C=32 / 78.9 all)
+  int fuse32_kmax = 99;           // largest tap count fused at f32 (WETTS_FUSE32_KMAX)
+  int fuse2_maxc = 128;           // widest stage whose f32 ResBlock2 chains run fused (WETTS_FUSE2_MAXC)
   int fuse_min_blocks = 128;      // fused pair kernels need this many tiles (else: small unfused tiles)
   int fuse2_waste_pct = 15;       // ResBlock2 chains: max % of tile columns lost to c2's halo at C = 32
                                   // (HBM-bound, +6..30 %); half of it at C >= 64 (profiles/r01_conv32_rb2_chain.txt)
@@ -808,6 +813,12 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     if (fl) m->fuse32_lds = atoi(fl);
     const char* fk = getenv("WETTS_FUSE32_KMAX128");
     if (fk) m->fuse32_kmax128 = atoi(fk);
+    const char* fc = getenv("WETTS_FUSE32_MAXC");
+    if (fc) m->fuse32_maxc = atoi(fc);
+    const char* f2c = getenv("WETTS_FUSE2_MAXC");
+    if (f2c) m->fuse2_maxc = atoi(f2c);
+    const char* fkm = getenv("WETTS_FUSE32_KMAX");
+    if (fkm) m->fuse32_kmax = atoi(fkm);
     const char* fm = getenv("WETTS_FUSE_MIN_BLOCKS");
     if (fm) m->fuse_min_blocks = atoi(fm);
     const char* fw2 = getenv("WETTS_FUSE2_WASTE_PCT");
@@ -1406,6 +1417,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
         // ResBlock2 (two residual convs): both dilations in one launch where the second conv's
         // halo wastes little of the tile; then the d loop is done
         if (c->resblock == 2 && nd == 2 && d == 0 && !m->dec_unfused && !forked &&
+            ch <= m->fuse2_maxc &&
             resblock2_chain32_supported(rb.c1[0], rb.c1[1], m->fuse32_lds,
                                         ch <= 32 ? m->fuse2_waste_pct : (m->fuse2_waste_pct + 1) / 2) &&
             cdiv(len, pair_nto(ch, 1) - (rb.c1[1].ktaps - 1) * rb.c1[1].dil) * B >= m->fuse_min_blocks) {
@@ -1434,6 +1446,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
         const bool fuse32 = c->resblock == 1 && !m->dec_unfused &&
                             resblock_pair32_supported(rb.c1[d], rb.c2[d], m->fuse32_lds) &&
                             !(ch >= 128 && rb.c1[d].ktaps >= m->fuse32_kmax128) &&
+                            ch <= m->fuse32_maxc && rb.c1[d].ktaps <= m->fuse32_kmax &&
                             pair_tiles >= m->fuse_min_blocks;
         if (fuse32) {
           // x = x + c2(lrelu(c1(lrelu(x)))) in one kernel (intermediate in LDS)
