@@ -38,40 +38,44 @@ __global__ __launch_bounds__(64) void attn_scores_kernel(
   S[(((int64_t)bh * T) + j) * T + i] = sc;
 }
 
-// softmax over j for every (b,h,i); block = 16 query lanes x 16 key groups (latency-bound: T is a
-// few hundred, so many short threads); grid: (ceil(T/16), B*H)
+// softmax over j for every (b,h,i); block = 16 query lanes x 16 key groups; grid: (ceil(T/16), B*H).
+// Two passes over S instead of three: each thread keeps a running (max, sum) over its keys
+// (online rescaling), the 16 groups are merged through LDS, then P = exp(s - M) / Z is written.
 __global__ __launch_bounds__(256) void attn_softmax_kernel(int T, float* __restrict__ S) {
   constexpr int TL = 16, JG = 16;
-  __shared__ float red[JG][TL + 1];
+  __shared__ float red_m[JG][TL + 1];
+  __shared__ float red_s[JG][TL + 1];
   const int il = threadIdx.x % TL, jg = threadIdx.x / TL;
   const int i = blockIdx.x * TL + il;
   const int bh = blockIdx.y;
   const bool ok = i < T;
   float* col = S + (int64_t)bh * T * T + (ok ? i : 0);
   const int j0 = (T * jg) / JG, j1 = (T * (jg + 1)) / JG;
-  float mx = -INFINITY;
-  if (ok)
-    for (int j = j0; j < j1; ++j) mx = fmaxf(mx, col[(int64_t)j * T]);
-  red[jg][il] = mx;
-  __syncthreads();
-  mx = -INFINITY;
-#pragma unroll
-  for (int q = 0; q < JG; ++q) mx = fmaxf(mx, red[q][il]);
-  __syncthreads();
-  float sm = 0.f;
-  if (ok)
+  float mx = -INFINITY, sm = 0.f;
+  if (ok) {
     for (int j = j0; j < j1; ++j) {
-      float e = expf(col[(int64_t)j * T] - mx);
-      col[(int64_t)j * T] = e;
-      sm += e;
+      const float x = col[(int64_t)j * T];
+      if (x > mx) {
+        sm = sm * expf(mx - x);  // exp(-inf) = 0 on the first element
+        mx = x;
+      }
+      sm += expf(x - mx);
     }
-  red[jg][il] = sm;
+  }
+  red_m[jg][il] = mx;
+  red_s[jg][il] = sm;
   __syncthreads();
-  sm = 0.f;
+  float M = -INFINITY;
 #pragma unroll
-  for (int q = 0; q < JG; ++q) sm += red[q][il];
+  for (int q = 0; q < JG; ++q) M = fmaxf(M, red_m[q][il]);
+  float Z = 0.f;
+#pragma unroll
+  for (int q = 0; q < JG; ++q) {
+    const float mq = red_m[q][il];
+    if (mq > -INFINITY) Z += red_s[q][il] * expf(mq - M);
+  }
   if (ok)
-    for (int j = j0; j < j1; ++j) col[(int64_t)j * T] = col[(int64_t)j * T] / sm;
+    for (int j = j0; j < j1; ++j) col[(int64_t)j * T] = expf(col[(int64_t)j * T] - M) / Z;
 }
 
 // out[b, h*dk+d, i] = sum_j P[j,i] v[d,j] + sum_r P[i+r,i] E_v[r+w][d];  grid (ceil(T/64), dk, B*H)
