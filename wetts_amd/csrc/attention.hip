@@ -15,14 +15,14 @@ namespace wetts {
 __global__ __launch_bounds__(64) void attn_scores_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ mask,
     const float* __restrict__ emb_rel_k, int window, int n_heads, int dk, int T, float qdiv,
-    float* __restrict__ S) {
+    int64_t qbs, float* __restrict__ S) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   const int j = blockIdx.y;
   const int bh = blockIdx.z;
   const int b = bh / n_heads, h = bh % n_heads;
   if (i >= T) return;
-  const float* qb = q + ((int64_t)b * n_heads + h) * dk * T;
-  const float* kb = k + ((int64_t)b * n_heads + h) * dk * T;
+  const float* qb = q + (int64_t)b * qbs + (int64_t)h * dk * T;
+  const float* kb = k + (int64_t)b * qbs + (int64_t)h * dk * T;
   const int r = j - i;
   const bool in_band = (r >= -window) && (r <= window);
   const float* er = emb_rel_k + (int64_t)(in_band ? (r + window) : 0) * dk;
@@ -83,13 +83,13 @@ __global__ __launch_bounds__(64) void attn_pv_kernel(const float* __restrict__ P
                                                      const float* __restrict__ v,
                                                      const float* __restrict__ emb_rel_v,
                                                      int window, int n_heads, int dk, int T,
-                                                     float* __restrict__ out) {
+                                                     int64_t qbs, float* __restrict__ out) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   const int d = blockIdx.y;
   const int bh = blockIdx.z;
   if (i >= T) return;
   const float* Pc = P + (int64_t)bh * T * T + i;
-  const float* vr = v + ((int64_t)bh * dk + d) * T;
+  const float* vr = v + (int64_t)(bh / n_heads) * qbs + ((int64_t)(bh % n_heads) * dk + d) * T;
   float acc = 0.f;
   for (int j = 0; j < T; ++j) acc += Pc[(int64_t)j * T] * vr[j];
   float rel = 0.f;
@@ -112,11 +112,12 @@ typedef float f32x16a __attribute__((ext_vector_type(16)));
 // block = 4 waves = 4 j-blocks of 32 x one i-block of 32;  grid (ceil(T/32), ceil(T/128), B*H)
 // rel[bh][r][i] = (q_i / sqrt(dk)) . E_k[r]   for the 2w+1 relative positions (attentions.py:246-252)
 __global__ void attn_relk_kernel(const float* __restrict__ q, const float* __restrict__ emb_rel_k,
-                                 int nrel, int dk, int T, float qdiv, float* __restrict__ rel) {
+                                 int nrel, int n_heads, int dk, int T, float qdiv, int64_t qbs,
+                                 float* __restrict__ rel) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   const int r = blockIdx.y, bh = blockIdx.z;
   if (i >= T) return;
-  const float* qb = q + (int64_t)bh * dk * T;
+  const float* qb = q + (int64_t)(bh / n_heads) * qbs + (int64_t)(bh % n_heads) * dk * T;
   const float* er = emb_rel_k + (int64_t)r * dk;
   float acc = 0.f;
   for (int d = 0; d < dk; ++d) acc += (qb[(int64_t)d * T + i] / qdiv) * er[d];
@@ -140,7 +141,7 @@ __global__ void attn_relv_add_kernel(const float* __restrict__ P, const float* _
 
 __global__ __launch_bounds__(256) void attn_scores_mfma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ mask,
-    const float* __restrict__ rel, int window, int n_heads, int dk, int T, float qdiv,
+    const float* __restrict__ rel, int window, int n_heads, int dk, int T, float qdiv, int64_t qbs,
     float* __restrict__ S) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
   const int bh = blockIdx.z, b = bh / n_heads;
@@ -148,8 +149,8 @@ __global__ __launch_bounds__(256) void attn_scores_mfma_kernel(
   const int jb = (blockIdx.y * 4 + wave) * 32;
   if (jb >= T) return;
   const int j = jb + (lane & 31);
-  const float* qb = q + (int64_t)bh * dk * T;
-  const float* kb = k + (int64_t)bh * dk * T;
+  const float* qb = q + (int64_t)b * qbs + (int64_t)(bh % n_heads) * dk * T;
+  const float* kb = k + (int64_t)b * qbs + (int64_t)(bh % n_heads) * dk * T;
   const bool iok = i < T, jok = j < T;
   f32x16a acc;
 #pragma unroll
@@ -188,14 +189,14 @@ __global__ __launch_bounds__(256) void attn_scores_mfma_kernel(
 }
 
 // vT[bh][j][d] = v[bh][d][j]
-__global__ void attn_transpose_v_kernel(const float* __restrict__ v, int dk, int T,
-                                        float* __restrict__ vT, int64_t total) {
+__global__ void attn_transpose_v_kernel(const float* __restrict__ v, int n_heads, int dk, int T,
+                                        int64_t qbs, float* __restrict__ vT, int64_t total) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int d = (int)(idx % dk);
   const int j = (int)((idx / dk) % T);
   const int64_t bh = idx / ((int64_t)dk * T);
-  vT[idx] = v[(bh * dk + d) * T + j];
+  vT[idx] = v[(bh / n_heads) * qbs + ((bh % n_heads) * dk + d) * T + j];
 }
 
 // out[bh][d][i] = sum_j vT[j][d] * P[j][i]
@@ -250,9 +251,11 @@ __global__ __launch_bounds__(256) void attn_pv_mfma_kernel(const float* __restri
   }
 }
 
-int32_t k_rel_attention(const float* q, const float* k, const float* v, const float* mask,
-                        const float* emb_rel_k, const float* emb_rel_v, int window, int B,
-                        int n_heads, int dk, int T, float* scores, float* out, hipStream_t s) {
+int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t qkv_batch_stride,
+                        const float* mask, const float* emb_rel_k, const float* emb_rel_v,
+                        int window, int B, int n_heads, int dk, int T, float* scores, float* out,
+                        hipStream_t s) {
+  const int64_t qbs = qkv_batch_stride;
   if (B * T == 0) return WETTS_OK;
   WETTS_REQUIRE(T <= 65535, "attention length %d too large", T);
   const float qdiv = (float)sqrt((double)dk);
@@ -268,18 +271,18 @@ int32_t k_rel_attention(const float* q, const float* k, const float* v, const fl
     if (window >= 0) {
       rel = vT + (int64_t)B * n_heads * dk * T;
       hipLaunchKernelGGL(attn_relk_kernel, dim3(cdiv(T, 64), nrel, B * n_heads), dim3(64), 0, s, q,
-                         emb_rel_k, nrel, dk, T, qdiv, rel);
+                         emb_rel_k, nrel, n_heads, dk, T, qdiv, qbs, rel);
       WETTS_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(attn_scores_mfma_kernel, dim3(cdiv(T, 32), cdiv(T, 128), B * n_heads),
                        dim3(256), 0, s, q, k, mask, rel, window < 0 ? 0 : window, n_heads, dk, T,
-                       qdiv, scores);
+                       qdiv, qbs, scores);
     WETTS_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_softmax_kernel, dim3(cdiv(T, 16), B * n_heads), dim3(256), 0, s, T, scores);
     WETTS_LAUNCH_CHECK();
     const int64_t nv = (int64_t)B * n_heads * dk * T;
     hipLaunchKernelGGL(attn_transpose_v_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s,
-                       v, dk, T, vT, nv);
+                       v, n_heads, dk, T, qbs, vT, nv);
     WETTS_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_pv_mfma_kernel, dim3(cdiv(T, 128), cdiv(dk, 32), B * n_heads),
                        dim3(256), 0, s, scores, vT, dk, T, out);
@@ -293,12 +296,12 @@ int32_t k_rel_attention(const float* q, const float* k, const float* v, const fl
   }
   int tb = cdiv(T, 64);
   hipLaunchKernelGGL(attn_scores_kernel, dim3(tb, T, B * n_heads), dim3(64), 0, s, q, k, mask,
-                     emb_rel_k, window, n_heads, dk, T, qdiv, scores);
+                     emb_rel_k, window, n_heads, dk, T, qdiv, qbs, scores);
   WETTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_softmax_kernel, dim3(cdiv(T, 16), B * n_heads), dim3(256), 0, s, T, scores);
   WETTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_pv_kernel, dim3(tb, dk, B * n_heads), dim3(64), 0, s, scores, v,
-                     emb_rel_v, window, n_heads, dk, T, out);
+                     emb_rel_v, window, n_heads, dk, T, qbs, out);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

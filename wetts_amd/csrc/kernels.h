@@ -110,9 +110,12 @@ int32_t k_add(const float* a, const float* b, int64_t n, float* out, hipStream_t
 // a5 windowed relative-position attention (attentions.py:235-282), banded form.
 //   qkv: q,k,v [B,H*dk,T];  out [B,H*dk,T];  scores workspace: B*H*T*T + B*H*dk*T (transposed v
 //   of the MFMA path) + B*H*(2*window+1)*T (relative-key table, window >= 0) floats
-int32_t k_rel_attention(const float* q, const float* k, const float* v, const float* mask,
-                        const float* emb_rel_k, const float* emb_rel_v, int window, int B,
-                        int n_heads, int dk, int T, float* scores, float* out, hipStream_t s);
+//   q, k, v may be slices of one fused projection [B, 3*H*dk, T]: qkv_batch_stride is their
+//   batch stride in floats (H*dk*T when they are separate contiguous tensors)
+int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t qkv_batch_stride,
+                        const float* mask, const float* emb_rel_k, const float* emb_rel_v,
+                        int window, int B, int n_heads, int dk, int T, float* scores, float* out,
+                        hipStream_t s);
 
 // a15 MAS
 int32_t k_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, int B, int Ty,

@@ -322,7 +322,7 @@ struct DDS {
 
 struct EncLayer {
   const float *rel_k, *rel_v, *n1g, *n1b, *n2g, *n2b;
-  PackedConv q, k, v, o, f1, f2;
+  PackedConv qkv, o, f1, f2;  // qkv: conv_q / conv_k / conv_v concatenated along Cout (one launch)
 };
 
 struct ConvFlowW {
@@ -451,6 +451,29 @@ static int32_t pack(wetts_model* m, const std::string& wname, const std::string&
   return WETTS_OK;
 }
 
+// conv_q, conv_k, conv_v of a MultiHeadAttention (attentions.py:225-233) as ONE 1x1 conv with
+// 3*H output channels: the three weights / biases are concatenated into an owned device buffer
+static int32_t pack_qkv(wetts_model* m, const std::string& a, int H, hipStream_t s, PackedConv* pc) {
+  float *w = nullptr, *b = nullptr;
+  WETTS_HIP_CHECK(hipMalloc((void**)&w, (size_t)3 * H * H * sizeof(float)));
+  m->v_owned.push_back(w);
+  WETTS_HIP_CHECK(hipMalloc((void**)&b, (size_t)3 * H * sizeof(float)));
+  m->v_owned.push_back(b);
+  const char* names[3] = {"conv_q", "conv_k", "conv_v"};
+  for (int i = 0; i < 3; ++i) {
+    const float* wi = m->T(a + "." + names[i] + ".weight");
+    const float* bi = m->T(a + "." + names[i] + ".bias");
+    WETTS_REQUIRE(wi && bi, "tensor %s.%s missing from layout", a.c_str(), names[i]);
+    WETTS_HIP_CHECK(hipMemcpyAsync(w + (size_t)i * H * H, wi, (size_t)H * H * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s));
+    WETTS_HIP_CHECK(hipMemcpyAsync(b + (size_t)i * H, bi, (size_t)H * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s));
+  }
+  WETTS_TRY(pack_conv_weight(w, b, 3 * H, H, 1, 1, 0, 0, 0, s, pc));
+  m->all_packed.push_back(pc);
+  return WETTS_OK;
+}
+
 static int32_t load_dds(wetts_model* m, const std::string& p, int C, hipStream_t s, DDS* d) {
   for (int i = 0; i < 3; ++i) {
     d->sep_w[i] = m->T(p + S(".convs_sep.%d.weight", i));
@@ -526,9 +549,7 @@ static int32_t build_model(wetts_model* m, hipStream_t s) {
     std::string a = S("enc_p.encoder.attn_layers.%d", l);
     e.rel_k = m->T(a + ".emb_rel_k");
     e.rel_v = m->T(a + ".emb_rel_v");
-    WETTS_TRY(pack(m, a + ".conv_q.weight", a + ".conv_q.bias", H, H, 1, 1, 0, 0, 0, s, &e.q));
-    WETTS_TRY(pack(m, a + ".conv_k.weight", a + ".conv_k.bias", H, H, 1, 1, 0, 0, 0, s, &e.k));
-    WETTS_TRY(pack(m, a + ".conv_v.weight", a + ".conv_v.bias", H, H, 1, 1, 0, 0, 0, s, &e.v));
+    WETTS_TRY(pack_qkv(m, a, H, s, &e.qkv));
     WETTS_TRY(pack(m, a + ".conv_o.weight", a + ".conv_o.bias", H, H, 1, 1, 0, 0, 0, s, &e.o));
     e.n1g = m->T(S("enc_p.encoder.norm_layers_1.%d.gamma", l));
     e.n1b = m->T(S("enc_p.encoder.norm_layers_1.%d.beta", l));
@@ -599,9 +620,7 @@ static int32_t build_model(wetts_model* m, hipStream_t s) {
       std::string a = p + ".pre_transformer.attn_layers.0";
       e.rel_k = m->T(a + ".emb_rel_k");
       e.rel_v = m->T(a + ".emb_rel_v");
-      WETTS_TRY(pack(m, a + ".conv_q.weight", a + ".conv_q.bias", H, H, 1, 1, 0, 0, 0, s, &e.q));
-      WETTS_TRY(pack(m, a + ".conv_k.weight", a + ".conv_k.bias", H, H, 1, 1, 0, 0, 0, s, &e.k));
-      WETTS_TRY(pack(m, a + ".conv_v.weight", a + ".conv_v.bias", H, H, 1, 1, 0, 0, 0, s, &e.v));
+      WETTS_TRY(pack_qkv(m, a, H, s, &e.qkv));
       WETTS_TRY(pack(m, a + ".conv_o.weight", a + ".conv_o.bias", H, H, 1, 1, 0, 0, 0, s, &e.o));
       e.n1g = m->T(p + ".pre_transformer.norm_layers_1.0.gamma");
       e.n1b = m->T(p + ".pre_transformer.norm_layers_1.0.beta");
@@ -618,9 +637,7 @@ static int32_t build_model(wetts_model* m, hipStream_t s) {
         EncLayer& e = fw.pre_tr[l];
         std::string a = p + S(".pre_transformer.attn_layers.%d", l);
         e.rel_k = e.rel_v = nullptr;  // window_size=None
-        WETTS_TRY(pack(m, a + ".conv_q.weight", a + ".conv_q.bias", Hh, Hh, 1, 1, 0, 0, 0, s, &e.q));
-        WETTS_TRY(pack(m, a + ".conv_k.weight", a + ".conv_k.bias", Hh, Hh, 1, 1, 0, 0, 0, s, &e.k));
-        WETTS_TRY(pack(m, a + ".conv_v.weight", a + ".conv_v.bias", Hh, Hh, 1, 1, 0, 0, 0, s, &e.v));
+        WETTS_TRY(pack_qkv(m, a, Hh, s, &e.qkv));
         WETTS_TRY(pack(m, a + ".conv_o.weight", a + ".conv_o.bias", Hh, Hh, 1, 1, 0, 0, 0, s, &e.o));
         e.n1g = m->T(p + S(".pre_transformer.norm_layers_1.%d.gamma", l));
         e.n1b = m->T(p + S(".pre_transformer.norm_layers_1.%d.beta", l));
@@ -906,10 +923,12 @@ static int32_t run_enc_layers(const std::vector<EncLayer>& layers, float* xa, co
     const bool last = (l == n - 1);
     // speaker-conditioned encoder (attentions.py:74-78): x = (x + spk_emb_linear(g)) * x_mask
     if (spk_cond && l == cond_idx) WETTS_TRY(k_add_bias_b_mask(xa, spk_cond, x_mask, B, H, T, s));
-    WETTS_TRY(launch_conv(e.q, conv_io(xa, H, T, q, H, B), s));
-    WETTS_TRY(launch_conv(e.k, conv_io(xa, H, T, k, H, B), s));
-    WETTS_TRY(launch_conv(e.v, conv_io(xa, H, T, v, H, B), s));
-    WETTS_TRY(k_rel_attention(q, k, v, x_mask, e.rel_k, e.rel_v, window, B, nh, dk, T, sc, att, s));
+    // q, k, v = one [B, 3H, T] projection (q / k / v scratch are contiguous: q is its base)
+    WETTS_TRY(launch_conv(e.qkv, conv_io(xa, H, T, q, 3 * H, B), s));
+    const float* qp = q;
+    WETTS_TRY(k_rel_attention(qp, qp + (int64_t)H * T, qp + (int64_t)2 * H * T, (int64_t)3 * H * T,
+                              x_mask, e.rel_k, e.rel_v, window, B, nh, dk, T, sc, att, s));
+    (void)k; (void)v;
     WETTS_TRY(launch_conv(e.o, conv_io(att, H, T, y, H, B), s));
     // x = norm_layers_1(x + y)
     WETTS_TRY(k_layernorm(xa, y, e.n1g, e.n1b, nullptr, nullptr, 0, B, H, T, xb, s));
