@@ -40,6 +40,21 @@ only = os.environ.get("WETTS_SHAPES")
 if only:
     keep = {tuple(int(v) for v in it.split(":")) for it in only.split(",")}
     shapes = [sh for sh in shapes if (sh[0], sh[1]) in keep]
+xs = os.environ.get("WETTS_XSHAPES")  # cin:cout:k:L,... rectangular convs (flow / encoder shapes)
+if xs:
+    print(f"{'shape':34s}" + "".join(f"  v{v:#06x}: ms TF/s      " for v in variants))
+    for it in xs.split(","):
+        ci, co, k, L = (int(v) for v in it.split(":"))
+        row = f"{ci:4d}->{co:4d} k={k:2d} L={L:6d}          "
+        for v in variants:
+            ms, cs = C.c_double(), C.c_double()
+            rc = lib.wetts_bench_conv(ci, co, k, 1, B, L, extra, v, 20, C.byref(ms), C.byref(cs))
+            if rc != 0:
+                row += f"  ERR {_lib.last_error()}"
+                continue
+            row += f"  {ms.value:7.4f} {2.0 * ci * co * k * L * B / (ms.value * 1e-3) / 1e12:6.1f}  "
+        print(row, flush=True)
+    sys.exit(0)
 print(f"{'shape':34s}" + "".join(f"  v{v:#06x}: ms TF/s GB/s  " for v in variants))
 for (ch, k, d, L, fl) in shapes:
     row = f"C={ch:3d} k={k:2d} d={d} L={L:6d} fl={fl}      "

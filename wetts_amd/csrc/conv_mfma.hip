@@ -684,8 +684,26 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
   const int64_t cols = (int64_t)p.N * p.B;
   // 1x4 wave tiles (one A fragment feeds four B fragments) measured 2-3 % faster than 2x2 at
   // every MRF shape (profiles/r01_conv_tileshape_ab.txt): half the A-stream loads per MFMA.
-  if (p.M >= 128 && cols >= 4096) return launch_cfg<1, 4, 4, 1>(p, stream);
-  if (p.M > 32 && cols >= 8192) return launch_cfg<1, 4, 2, 2>(p, stream);
+  switch (conv_variant()) {  // microbenchmark override (tools/bench_conv.py); 0 in production
+    case 2: return launch_cfg<1, 2, 4, 1>(p, stream);
+    case 3: return launch_cfg<1, 4, 2, 2>(p, stream);
+    case 4: return launch_cfg<1, 2, 2, 2>(p, stream);
+    case 5: return launch_cfg<1, 1, 2, 2>(p, stream);
+    default: break;
+  }
+  // ... but a grid of fewer than 1.5 big tiles per CU leaves CUs idle or unevenly loaded: the flow /
+  // encoder convs (192 -> 384 over B*Ty = 13 k columns: 336 big tiles) run 28-50 % faster on
+  // 64x64 tiles (profiles/r01_conv_tile_fill.txt); the MRF shapes have >= 1600 big tiles.
+  auto nblk = [&](int mt, int nt) { return (int64_t)cdiv(p.M, mt) * cdiv(p.N, nt) * p.B; };
+  constexpr int64_t kFill = 384;
+  if (p.M >= 128 && cols >= 4096) {
+    if (nblk(128, 128) >= kFill) return launch_cfg<1, 4, 4, 1>(p, stream);
+    return launch_cfg<1, 1, 2, 2>(p, stream);
+  }
+  if (p.M > 32 && cols >= 8192) {
+    if (nblk(64, 256) >= kFill) return launch_cfg<1, 4, 2, 2>(p, stream);
+    return launch_cfg<1, 1, 2, 2>(p, stream);
+  }
   if (p.M <= 32 && cols >= 8192 && p.ktaps >= 5) return launch_cfg<1, 4, 1, 4>(p, stream);
   if (p.M <= 32 && cols >= 8192) return launch_cfg<1, 2, 1, 4>(p, stream);
   return launch_cfg<1, 1, 2, 2>(p, stream);
