@@ -403,6 +403,8 @@ struct wetts_model {
                                   // chunked kernel runs at 4 waves/SIMD it wins at C >= 64
                                   // (profiles/r01_conv32_fused_pair.txt; step 79.9 none / 78.4 C=32 / 78.9 all)
   int fuse32_kmax = 99;           // largest tap count fused at f32 (WETTS_FUSE32_KMAX)
+  int fuse32_kwide = 3;           // ... but pairs with at most this many taps fuse at any width: k = 3 pairs are
+                                  // short on MFMA work per byte (C=64 +10 %, C=128 +3 %; WETTS_FUSE32_KWIDE)
   int fuse2_maxc = 128;           // widest stage whose f32 ResBlock2 chains run fused (WETTS_FUSE2_MAXC)
   int fuse_min_blocks = 128;      // fused pair kernels need this many tiles (else: small unfused tiles)
   int fuse2_waste_pct = 15;       // ResBlock2 chains: max % of tile columns lost to c2's halo at C = 32
@@ -836,6 +838,8 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     if (f2c) m->fuse2_maxc = atoi(f2c);
     const char* fkm = getenv("WETTS_FUSE32_KMAX");
     if (fkm) m->fuse32_kmax = atoi(fkm);
+    const char* fkw = getenv("WETTS_FUSE32_KWIDE");
+    if (fkw) m->fuse32_kwide = atoi(fkw);
     const char* fm = getenv("WETTS_FUSE_MIN_BLOCKS");
     if (fm) m->fuse_min_blocks = atoi(fm);
     const char* fw2 = getenv("WETTS_FUSE2_WASTE_PCT");
@@ -1465,7 +1469,8 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
         const bool fuse32 = c->resblock == 1 && !m->dec_unfused &&
                             resblock_pair32_supported(rb.c1[d], rb.c2[d], m->fuse32_lds) &&
                             !(ch >= 128 && rb.c1[d].ktaps >= m->fuse32_kmax128) &&
-                            ch <= m->fuse32_maxc && rb.c1[d].ktaps <= m->fuse32_kmax &&
+                            (ch <= m->fuse32_maxc || rb.c1[d].ktaps <= m->fuse32_kwide) &&
+                            rb.c1[d].ktaps <= m->fuse32_kmax &&
                             pair_tiles >= m->fuse_min_blocks;
         if (fuse32) {
           // x = x + c2(lrelu(c1(lrelu(x)))) in one kernel (intermediate in LDS)
