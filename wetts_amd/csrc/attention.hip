@@ -251,6 +251,159 @@ __global__ __launch_bounds__(256) void attn_pv_mfma_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Window-less attention in one kernel (flash style): the S^T tile of 32 keys x 32 queries leaves
+// the score MFMAs in exactly the lane layout the P.V MFMA wants for its B operand -- lane (i, half)
+// holds P[j][i] for j = jmap(r, half), r = 0..15 -- so k-step r of the second contraction takes
+// acc[r] as is and loads v at the same 16 key positions: no S round trip through HBM, no
+// cross-lane movement.  Online softmax per query column (max / sum combined across the two lane
+// halves); the block's 4 waves split the key range and merge their (m, l, o) through LDS.
+// Masking follows attentions.py:253-256: masked pairs score -1e4 (a fully padded query row
+// therefore averages v over all T keys, like the reference), keys >= T do not exist.
+// grid (ceil(T/32), B*H), block 256;  NKS = k-steps over dk (2 per step), NDB = 32-row d-blocks
+// ---------------------------------------------------------------------------------------------
+template <int NKS, int NDB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NKS <= 24 ? 2 : 1))) void attn_flash_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vT,
+    const float* __restrict__ mask, int n_heads, int dk, int T, float qdiv, int64_t qbs,
+    float* __restrict__ out) {
+  constexpr int NR = NDB * 16;
+  __shared__ float sm_m[4][32];
+  __shared__ float sm_l[4][32];
+  __shared__ float sm_o[4 * NR * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+  const int bh = blockIdx.y, b = bh / n_heads;
+  const int i = blockIdx.x * 32 + col;
+  const bool iok = i < T;
+  const int icl = iok ? i : T - 1;
+  const float* qb = q + (int64_t)b * qbs + (int64_t)(bh % n_heads) * dk * T;
+  const float* kb = k + (int64_t)b * qbs + (int64_t)(bh % n_heads) * dk * T;
+  const float* vb = vT + (int64_t)bh * T * dk;
+  const float* mb = mask + (int64_t)b * T;
+  float qr[NKS];
+#pragma unroll
+  for (int u = 0; u < NKS; ++u) {
+    const int d = 2 * u + half;
+    // unconditional load (clamped row) times a 0/1 factor: a select would make the load itself
+    // conditional and serialise the 24 round trips
+    const float qv = qb[(int64_t)(d < dk ? d : 0) * T + icl];
+    qr[u] = (qv / qdiv) * (d < dk ? 1.f : 0.f);  // query / math.sqrt(k_channels)
+  }
+  const float mi = mb[icl];
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16a o[NDB];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+
+  for (int jb = wave * 32; jb < T; jb += 128) {
+    const int jcl = min(jb + col, T - 1);
+    // the tile's 32 key-mask values as one bit mask (one coalesced load instead of 16 per lane)
+    const unsigned kbits = (unsigned)__ballot(mb[jcl] != 0.f);
+    f32x16a sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+    for (int u0 = 0; u0 < NKS; u0 += 8) {
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int d = 2 * (u0 + u) + half;
+        a[u] = kb[(int64_t)(d < dk ? d : 0) * T + jcl];  // d >= dk meets qr = 0
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], qr[u0 + u], sc, 0, 0, 0);
+    }
+    float p[16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jl = (r & 3) + 8 * (r >> 2) + 4 * half;
+      float x = sc[r];
+      if (mi == 0.f || !((kbits >> jl) & 1u)) x = -1e4f;  // masked_fill(mask == 0, -1e4)
+      if (jb + jl >= T) x = -INFINITY;
+      p[r] = x;
+      tmax = fmaxf(tmax, x);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);  // finite: key jb < T is in this tile
+    const float scale = expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = expf(p[r] - m_new);
+      psum += p[r];
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * scale + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= scale;
+#pragma unroll
+    for (int s0 = 0; s0 < 16; s0 += 8) {
+      float av[NDB][8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = s0 + u;
+        const int jj = min(jb + (r & 3) + 8 * (r >> 2) + 4 * half, T - 1);  // p = 0 beyond T
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+          const int d = db * 32 + col;
+          av[db][u] = vb[(int64_t)jj * dk + (d < dk ? d : 0)] * (d < dk ? 1.f : 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[db][u], p[s0 + u], o[db], 0, 0, 0);
+    }
+  }
+
+  // merge the four key ranges: o = sum_w e_w o_w / sum_w e_w l_w,  e_w = exp(m_w - M)
+  if (half == 0) {
+    sm_m[wave][col] = m_run;
+    sm_l[wave][col] = l_run;
+  }
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sm_o[((wave * NR) + db * 16 + r) * 64 + lane] = o[db][r];
+  __syncthreads();
+  float M = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) M = fmaxf(M, sm_m[w][col]);
+  float e[4], L = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    e[w] = expf(sm_m[w][col] - M);  // a wave without keys has m = -inf, l = 0, o = 0
+    L += e[w] * sm_l[w][col];
+  }
+  const float inv = 1.f / L;
+#pragma unroll
+  for (int q4 = 0; q4 < NR / 4; ++q4) {
+    const int rr = wave * (NR / 4) + q4;
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc += e[w] * sm_o[((w * NR) + rr) * 64 + lane];
+    const int r = rr & 15;
+    const int dd = (rr >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (iok && dd < dk) out[((int64_t)bh * dk + dd) * T + i] = acc * inv;
+  }
+}
+
+static int attn_flash_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("WETTS_ATTN_FLASH");  // 0: scores / softmax / P.V as separate kernels
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
 int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t qkv_batch_stride,
                         const float* mask, const float* emb_rel_k, const float* emb_rel_v,
                         int window, int B, int n_heads, int dk, int T, float* scores, float* out,
@@ -266,6 +419,20 @@ int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t 
     // P after the P.V contraction.  Behind the scores the workspace holds the transposed v
     // (B*H*dk*T floats) and that table (B*H*(2w+1)*T).
     float* vT = scores + (int64_t)B * n_heads * T * T;
+    if (window < 0 && dk <= 96 && attn_flash_enabled()) {
+      const int64_t nv = (int64_t)B * n_heads * dk * T;
+      hipLaunchKernelGGL(attn_transpose_v_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0,
+                         s, v, n_heads, dk, T, qbs, vT, nv);
+      WETTS_LAUNCH_CHECK();
+      if (dk <= 48)
+        hipLaunchKernelGGL((attn_flash_kernel<24, 2>), dim3(cdiv(T, 32), B * n_heads), dim3(256), 0,
+                           s, q, k, vT, mask, n_heads, dk, T, qdiv, qbs, out);
+      else
+        hipLaunchKernelGGL((attn_flash_kernel<48, 3>), dim3(cdiv(T, 32), B * n_heads), dim3(256), 0,
+                           s, q, k, vT, mask, n_heads, dk, T, qdiv, qbs, out);
+      WETTS_LAUNCH_CHECK();
+      return WETTS_OK;
+    }
     float* rel = nullptr;
     const int nrel = 2 * window + 1;
     if (window >= 0) {
