@@ -343,7 +343,7 @@ def main():
             "kernel": ("conv_mfma_kernel (Vocos ConvNeXt pointwise GEMMs 512<->1536)"
                        if "vocos" in args.model else
                        "conv_mfma_kernel + resblock_pair32_kernel (MRF ResBlock convs; the C=32 "
-                       "stage runs as fused pairs)"),
+                       "stage and the k=3 pairs of C=64/128 run as fused pairs)"),
             "bound": "mfma", "achieved": mrf_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": mrf_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
             "traffic_unit": "HBM bytes per conv_mfma launch (2*FETCH_SIZE+WRITE_SIZE)*1024, PMC",
