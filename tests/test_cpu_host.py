@@ -159,3 +159,39 @@ def test_hparams_mirror(tmp_path):
     h = config.get_hparams_from_file(str(p))
     assert h.train.segment_size // h.data.hop_length == 32 and "resblock" in h.model.keys()
     assert dict(**h.model) == {"resblock": "1"}
+
+
+def test_cli_mirror_host_side(tmp_path):
+    """wetts_amd.inference keeps the reference CLI's flags / table format (inference.py:28-64) and
+    refuses to run without a HIP device instead of falling back to a CPU path."""
+    from wetts_amd import inference
+    (tmp_path / "phones.txt").write_text("sil 0\na 1\n\nb 2\n")
+    (tmp_path / "spk.txt").write_text("baker 0\n")
+    assert inference.read_table(str(tmp_path / "phones.txt")) == {"sil": 0, "a": 1, "b": 2}
+    with pytest.raises(AssertionError):
+        (tmp_path / "bad.txt").write_text("a 1 2\n")
+        inference.read_table(str(tmp_path / "bad.txt"))
+    args = inference.get_args(["--checkpoint", "G.pth", "--cfg", "c.json", "--outdir", "o",
+                               "--phone_table", "p", "--test_file", "t"])
+    assert (args.gpu, args.batch, args.seed) == (0, 1, None)
+    with pytest.raises(SystemExit):  # a required reference flag is missing
+        inference.get_args(["--cfg", "c.json"])
+    if not torch.cuda.is_available():
+        cfgp = tmp_path / "c.json"
+        import json
+        cfgp.write_text(json.dumps({"train": {"segment_size": 64}, "data": {
+            "hop_length": 8, "filter_length": 1024, "sampling_rate": 16000},
+            "model": config.MODEL_CONFIGS["tiny"]}))
+        hps = config.get_hparams_from_file(str(cfgp))
+        with pytest.raises(SystemExit, match="no CPU path"):
+            inference.build_model(args, {"a": 0, "b": 1}, {"s": 0}, hps)
+
+
+def test_unshard_inverts_shard_utterances():
+    from wetts_amd import sharding
+    lens = [5, 9, 3, 9, 1, 7, 2]
+    for world in (1, 2, 3):
+        shards = sharding.shard_utterances(lens, world)
+        per_rank = [[f"u{i}" for i in idxs] for idxs in shards]
+        assert sharding.unshard(shards, per_rank) == [f"u{i}" for i in range(len(lens))]
+        assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
