@@ -195,3 +195,29 @@ def test_unshard_inverts_shard_utterances():
         per_rank = [[f"u{i}" for i in idxs] for idxs in shards]
         assert sharding.unshard(shards, per_rank) == [f"u{i}" for i in range(len(lens))]
         assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+
+
+def test_ctypes_config_mirror_matches_the_c_struct(tmp_path):
+    """Field order, offsets and size of wetts_amd._lib.Config against wetts_config_t as the C
+    compiler lays it out (include/wetts_hip.h) -- a drifted mirror would silently shift fields."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    names = [n for n, _ in _lib.Config._fields_]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "wetts_hip.h"', 'int main(void) {',
+            '  printf("%zu\\n", sizeof(wetts_config_t));']
+    prog += [f'  printf("%zu\\n", offsetof(wetts_config_t, {n}));' for n in names]
+    prog += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(prog))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)])
+    out = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == C.sizeof(_lib.Config)
+    assert out[1:] == [getattr(_lib.Config, n).offset for n in names]
+    # and the header declares no field the mirror lacks
+    body = open(HEADER).read().split("typedef struct wetts_config {")[1].split("} wetts_config_t;")[0]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)  # comments mention other identifiers
+    declared = re.findall(r"int32_t\s+(\w+)", body)
+    assert declared == names
