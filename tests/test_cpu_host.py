@@ -221,3 +221,21 @@ def test_ctypes_config_mirror_matches_the_c_struct(tmp_path):
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)  # comments mention other identifiers
     declared = re.findall(r"int32_t\s+(\w+)", body)
     assert declared == names
+
+
+def test_split_bf16_error_estimate_backs_the_design_claim(capsys):
+    """six bf16 cross products accumulated in f32 are at least as accurate as
+    today's f32 MFMA chain; three stay far inside the 1e-3 gate (tools/split_bf16_error.py)."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(HEADER), "..", "tools", "split_bf16_error.py")
+    spec = importlib.util.spec_from_file_location("split_bf16_error", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main()
+    rows = {}
+    for line in capsys.readouterr().out.splitlines():
+        name, rest = line.split("rel rms err")
+        rows[name.strip()] = float(rest.split()[0])
+    assert rows["split bf16, 6 products, f32 acc"] <= rows["f32 MFMA chain (today)"]
+    assert rows["truncation alone (6 products)"] < 1e-7
+    assert rows["split bf16, 3 products, f32 acc"] < 1e-4
