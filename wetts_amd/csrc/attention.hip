@@ -419,17 +419,14 @@ int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t 
     // P after the P.V contraction.  Behind the scores the workspace holds the transposed v
     // (B*H*dk*T floats) and that table (B*H*(2w+1)*T).
     float* vT = scores + (int64_t)B * n_heads * T * T;
-    if (window < 0 && dk <= 96 && attn_flash_enabled()) {
+    // (heads wider than 48 channels -- none in the reference's configs -- keep the three-kernel path)
+    if (window < 0 && dk <= 48 && attn_flash_enabled()) {
       const int64_t nv = (int64_t)B * n_heads * dk * T;
       hipLaunchKernelGGL(attn_transpose_v_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0,
                          s, v, n_heads, dk, T, qbs, vT, nv);
       WETTS_LAUNCH_CHECK();
-      if (dk <= 48)
-        hipLaunchKernelGGL((attn_flash_kernel<24, 2>), dim3(cdiv(T, 32), B * n_heads), dim3(256), 0,
-                           s, q, k, vT, mask, n_heads, dk, T, qdiv, qbs, out);
-      else
-        hipLaunchKernelGGL((attn_flash_kernel<48, 3>), dim3(cdiv(T, 32), B * n_heads), dim3(256), 0,
-                           s, q, k, vT, mask, n_heads, dk, T, qdiv, qbs, out);
+      hipLaunchKernelGGL((attn_flash_kernel<24, 2>), dim3(cdiv(T, 32), B * n_heads), dim3(256), 0,
+                         s, q, k, vT, mask, n_heads, dk, T, qdiv, qbs, out);
       WETTS_LAUNCH_CHECK();
       return WETTS_OK;
     }

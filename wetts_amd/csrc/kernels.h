@@ -112,7 +112,7 @@ int32_t k_add(const float* a, const float* b, int64_t n, float* out, hipStream_t
 //   of the MFMA path) + B*H*(2*window+1)*T (relative-key table, window >= 0) floats
 //   q, k, v may be slices of one fused projection [B, 3*H*dk, T]: qkv_batch_stride is their
 //   batch stride in floats (H*dk*T when they are separate contiguous tensors)
-//   window < 0 (no relative terms; the VITS2 flow encoders): one flash-style kernel, the T*T
+//   window < 0 (no relative terms; the VITS2 flow encoders) and dk <= 48: one flash-style kernel, the T*T
 //   part of the workspace stays untouched (WETTS_ATTN_FLASH=0 selects the three-kernel path)
 int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t qkv_batch_stride,
                         const float* mask, const float* emb_rel_k, const float* emb_rel_v,
