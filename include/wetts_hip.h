@@ -30,13 +30,22 @@
 extern "C" {
 #endif
 
-#define WETTS_ABI_VERSION 4
+#define WETTS_ABI_VERSION 5
 
 #define WETTS_OK 0
 #define WETTS_E_INVALID (-1)   /* bad argument / unsupported configuration */
 #define WETTS_E_HIP (-2)       /* HIP runtime / launch error               */
 #define WETTS_E_WORKSPACE (-3) /* caller workspace too small               */
 #define WETTS_E_DOMAIN (-4)    /* reference would raise (spline domain...) */
+
+/* Device-side error flags: conditions only the data can reveal, where the reference raises from
+ * inside a module.  Kernels OR these bits into the int32 status word registered with
+ * wetts_set_status_word(); the host reads the word back together with y_lengths (the one D2H of
+ * infer()) and raises / returns like the reference does. */
+#define WETTS_STATUS_SPLINE_DOMAIN 1      /* `assert (discriminant >= 0).all()` transforms.py:171 */
+#define WETTS_STATUS_PHONE_ID_RANGE 2     /* nn.Embedding IndexError, encoders.py:48 */
+#define WETTS_STATUS_SPEAKER_ID_RANGE 4   /* emb_g IndexError, models.py:239 */
+#define WETTS_STATUS_DURATION_NONFINITE 8 /* NaN / inf durations reach .long(), models.py:256 */
 
 #define WETTS_MAX_STAGES 8
 #define WETTS_MAX_RB_KERNELS 8
@@ -123,6 +132,15 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
                      void* stream, wetts_model_t** out);
 void wetts_destroy(wetts_model_t* m);
 
+/* Registers the device int32 the stage calls below OR their WETTS_STATUS_* bits into (caller-owned;
+ * zeroed here, stream-ordered; NULL = flags are dropped, ids are still clamped for memory safety).
+ * wetts_infer() uses a word of its own workspace and maps it to its return code. */
+int32_t wetts_set_status_word(const wetts_model_t* m, int32_t* status_dev, void* stream);
+
+/* Seed of the model's own standard-normal stream (Philox4x32-10), used by wetts_infer() when
+ * eps_w / eps_z are NULL -- the reference draws them with torch.randn under torch.manual_seed. */
+int32_t wetts_set_seed(const wetts_model_t* m, uint64_t seed);
+
 /* total upsampling factor (prod upsample_rates) == hop length of the checkpoint. */
 int32_t wetts_hop_length(const wetts_model_t* m);
 
@@ -150,8 +168,9 @@ int32_t wetts_text_encoder(const wetts_model_t* m, const int64_t* x, const int64
 /* a8 StochasticDurationPredictor.forward(reverse=True) (duration_predictors.py:213-219,254-263;
  * transforms.py:47-187).  eps_w [B,2,Tx] is the caller's standard-normal draw (the reference
  * calls torch.randn at :257); it is scaled by noise_scale_w inside.  logw [B,Tx].
- * status_dev (int32[1], may be NULL) is set non-zero on the device if the reference would have
- * failed `assert (discriminant >= 0)` (transforms.py:171). */
+ * status_dev (int32[1], may be NULL = the word registered with wetts_set_status_word) gets
+ * WETTS_STATUS_SPLINE_DOMAIN OR-ed in on the device if the reference would have failed
+ * `assert (discriminant >= 0)` (transforms.py:171); it is NOT cleared here. */
 int32_t wetts_duration_sdp(const wetts_model_t* m, const float* x_enc, const float* x_mask,
                            const float* g, const float* eps_w, float noise_scale_w, int32_t B,
                            int32_t Tx, float* logw, int32_t* status_dev, void* workspace,
@@ -165,10 +184,11 @@ int32_t wetts_duration_dp(const wetts_model_t* m, const float* x_enc, const floa
 /* a10 durations -> lengths (models.py:254-256): w = exp(logw)*mask*length_scale,
  * w_ceil = ceil(w) [B,Tx], cum = inclusive cumsum(w_ceil) [B,Tx] (float, exact integers),
  * y_lengths = clamp_min(sum,1) [B] int64.  The caller reads y_lengths back (the one host sync
- * the reference also has: commons.py:114-115 `length.max()`). */
+ * the reference also has: commons.py:114-115 `length.max()`).  status_dev (may be NULL) gets
+ * WETTS_STATUS_DURATION_NONFINITE when a total is NaN / inf (y_lengths[b] is then 1). */
 int32_t wetts_durations_to_lengths(const float* logw, const float* x_mask, float length_scale,
                                    int32_t B, int32_t Tx, float* w_ceil, float* cum,
-                                   int64_t* y_lengths, void* stream);
+                                   int64_t* y_lengths, int32_t* status_dev, void* stream);
 
 /* a10-a12 sequence_mask + generate_path + prior expansion + sampling (models.py:257-267,
  * commons.py:113-136).  Ty = max(y_lengths) chosen by the caller.
@@ -224,13 +244,25 @@ int32_t wetts_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_x
 int32_t wetts_audio_to_int16(const float* audio, const int64_t* lengths_samples, int32_t B,
                              int64_t L, int16_t* pcm, void* stream);
 
+/* Standard-normal draws on the device (Philox4x32-10 + Box-Muller): what the reference gets from
+ * torch.randn (duration_predictors.py:257) / torch.randn_like (models.py:267).  Element i is a
+ * function of (seed, offset, i) only; a draw of n values consumes ceil(n/4) counter steps. */
+int32_t wetts_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* out[b,c,t] = x[b,c,t] * mask[b,t]  (`z * y_mask`, models.py:322). */
+int32_t wetts_mask_rows(const float* x, const float* mask, int32_t B, int32_t C, int32_t T,
+                        float* out, void* stream);
+
 /* a1 SynthesizerTrn.infer (models.py:228-280) composed for native hosts (the shape of
  * runtime/core/model/vits_model.h:37 Forward()).  Synchronises the stream once internally to
  * read y_lengths.  The caller provides capacity for max_frames frames; on return
  * *frames_out = max(y_lengths) (<= max_frames, else WETTS_E_WORKSPACE), y_lengths_host[B].
  * eps_w [B,2,Tx] and eps_z [B,inter,max_frames] (row stride max_frames) are standard-normal
- * draws.  audio needs capacity B*max_frames*hop floats and is written PACKED as
- * [B, (*frames_out)*hop].  workspace >= wetts_infer_workspace_bytes(). */
+ * draws; either may be NULL, in which case it is drawn here from the model's Philox stream
+ * (wetts_set_seed).  Errors the reference raises from inside its modules come back as return codes
+ * after that one synchronisation: WETTS_E_DOMAIN (spline discriminant, transforms.py:171; non-finite
+ * durations) and WETTS_E_INVALID (phoneme / speaker id outside its table).  audio needs capacity
+ * B*max_frames*hop floats and is written PACKED as [B, (*frames_out)*hop].  workspace >= wetts_infer_workspace_bytes(). */
 int64_t wetts_infer_workspace_bytes(const wetts_model_t* m, int32_t B, int32_t Tx,
                                     int32_t max_frames);
 int32_t wetts_infer(const wetts_model_t* m, const int64_t* x, const int64_t* x_lengths,

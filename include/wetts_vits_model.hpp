@@ -13,7 +13,6 @@
 
 #include <algorithm>
 #include <cstdint>
-#include <random>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -49,7 +48,7 @@ class VitsModel {
   // wetts_amd.checkpoint.pack_blob writes); scales follow vits_model.cc:44 {0.667, 1.0, 0.8}.
   VitsModel(const wetts_config_t& cfg, const std::vector<float>& blob, int chunk_size = 40,
             int pad_size = 10, uint64_t seed = 0)
-      : cfg_(cfg), chunk_size_(chunk_size), pad_size_(pad_size), rng_(seed) {
+      : cfg_(cfg), chunk_size_(chunk_size), pad_size_(pad_size), seed_(seed) {
     if ((int64_t)blob.size() != wetts_blob_numel(&cfg_))
       throw std::runtime_error(std::string("blob size mismatch: ") + wetts_last_error());
     DeviceBuffer tmp;
@@ -107,11 +106,6 @@ class VitsModel {
   static void Check(int32_t rc, const char* what) {
     if (rc != WETTS_OK) throw std::runtime_error(std::string(what) + ": " + wetts_last_error());
   }
-  void Normal(std::vector<float>* v) {
-    std::normal_distribution<float> n(0.f, 1.f);
-    for (auto& x : *v) x = n(rng_);
-  }
-
   // infer_encoder (models.py:282-331): everything up to z = flow^-1(z_p) * y_mask
   void Encode(const std::vector<int64_t>& phonemes, int sid) {
     const int Tx = (int)phonemes.size();
@@ -134,33 +128,45 @@ class VitsModel {
     float* cum = w_ceil + Tx;
     int64_t wsb = wetts_workspace_bytes(model_, 1, Tx, 0);
     void* ws = ws_.Reserve((size_t)wsb);
+    // [0] y_length, [1] low word = WETTS_STATUS_* bits the stage kernels OR in
+    int64_t* d_ylen = static_cast<int64_t*>(ylen_.Reserve(16));
+    int32_t* d_status = reinterpret_cast<int32_t*>(d_ylen + 1);
+    Check(hipMemset(d_ylen, 0, 16));
+    Check(wetts_set_status_word(model_, d_status, nullptr), "set_status_word");
     Check(wetts_speaker_embedding(model_, cfg_.n_speakers > 0 ? d_x + Tx + 1 : nullptr, 1, g_,
                                   nullptr), "speaker_embedding");
     const float* gp = cfg_.n_speakers > 0 ? g_ : nullptr;
     Check(wetts_text_encoder(model_, d_x, d_x + Tx, gp, 1, Tx, x_enc, stats, x_mask, ws, wsb,
                              nullptr), "text_encoder");
     if (cfg_.use_sdp) {
-      std::vector<float> h((size_t)2 * Tx);
-      Normal(&h);
-      float* d_eps = static_cast<float*>(epsw_.Reserve(h.size() * 4));
-      Check(hipMemcpy(d_eps, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+      // torch.randn(b, 2, t) of duration_predictors.py:257, drawn on the device
+      float* d_eps = static_cast<float*>(epsw_.Reserve((size_t)2 * Tx * 4));
+      Check(wetts_randn(d_eps, (int64_t)2 * Tx, seed_, rng_offset_, nullptr), "randn");
+      rng_offset_ += ((uint64_t)2 * Tx + 3) / 4;
       Check(wetts_duration_sdp(model_, x_enc, x_mask, gp, d_eps, noise_scale_w_, 1, Tx, logw,
-                               nullptr, ws, wsb, nullptr), "duration_sdp");
+                               d_status, ws, wsb, nullptr), "duration_sdp");
     } else {
       Check(wetts_duration_dp(model_, x_enc, x_mask, gp, 1, Tx, logw, ws, wsb, nullptr),
             "duration_dp");
     }
-    int64_t* d_ylen = static_cast<int64_t*>(ylen_.Reserve(8));
     Check(wetts_durations_to_lengths(logw, x_mask, length_scale_, 1, Tx, w_ceil, cum, d_ylen,
-                                     nullptr), "durations_to_lengths");
-    int64_t ylen = 0;
-    Check(hipMemcpy(&ylen, d_ylen, 8, hipMemcpyDeviceToHost));  // the one host sync
-    frames_ = (int)ylen;
+                                     d_status, nullptr), "durations_to_lengths");
+    int64_t back[2] = {0, 0};  // y_length + the status word: one D2H, the one host sync
+    Check(hipMemcpy(back, d_ylen, 16, hipMemcpyDeviceToHost));
+    Check(wetts_set_status_word(model_, nullptr, nullptr), "set_status_word");
+    const int32_t st = (int32_t)(back[1] & 0xffffffff);
+    // the reference aborts here too: IndexError from nn.Embedding / glog CHECK in vits_model.cc,
+    // `assert (discriminant >= 0).all()` in transforms.py:171
+    if (st & (WETTS_STATUS_PHONE_ID_RANGE | WETTS_STATUS_SPEAKER_ID_RANGE))
+      throw std::out_of_range("phoneme / speaker id outside the model's embedding tables");
+    if (st & (WETTS_STATUS_SPLINE_DOMAIN | WETTS_STATUS_DURATION_NONFINITE))
+      throw std::domain_error("duration predictor left its domain (spline discriminant < 0)");
+    frames_ = (int)back[0];
     const int Ty = frames_;
-    std::vector<float> hz((size_t)I * Ty);
-    Normal(&hz);
-    float* d_epsz = static_cast<float*>(epsz_.Reserve(hz.size() * 4));
-    Check(hipMemcpy(d_epsz, hz.data(), hz.size() * 4, hipMemcpyHostToDevice));
+    // torch.randn_like(m_p) of models.py:267, drawn on the device
+    float* d_epsz = static_cast<float*>(epsz_.Reserve((size_t)I * Ty * 4));
+    Check(wetts_randn(d_epsz, (int64_t)I * Ty, seed_, rng_offset_, nullptr), "randn");
+    rng_offset_ += ((uint64_t)I * Ty + 3) / 4;
     float* zb = static_cast<float*>(z_.Reserve(sizeof(float) * ((size_t)2 * I * Ty + 2 * (size_t)Ty) + 64));
     zp_ = zb;
     zz_ = zp_ + (size_t)I * Ty;
@@ -192,7 +198,7 @@ class VitsModel {
   wetts_model_t* model_ = nullptr;
   int hop_ = 256, chunk_size_, pad_size_;
   float noise_scale_ = 0.667f, length_scale_ = 1.0f, noise_scale_w_ = 0.8f;
-  std::mt19937_64 rng_;
+  uint64_t seed_ = 0, rng_offset_ = 0;  // Philox stream of the two standard-normal draws
   DeviceBuffer ids_, enc_, epsw_, epsz_, z_, ylen_, ws_, audio_;
   float *g_ = nullptr, *zp_ = nullptr, *zz_ = nullptr, *y_mask_ = nullptr;
   int64_t wsb_ = 0;

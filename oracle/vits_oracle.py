@@ -472,21 +472,27 @@ def hifigan_bf16sim(W, cfg, z, g):
 # infer  (model/models.py:228-280)
 # ------------------------------------------------------------------------------------------------
 def infer(W, cfg, x_ids, x_lengths, sid=None, noise_scale=1.0, length_scale=1.0,
-          noise_scale_w=1.0, max_len=None, eps_w=None, eps_z=None, return_stages=False):
+          noise_scale_w=1.0, max_len=None, eps_w=None, eps_z=None, return_stages=False,
+          timers=None):
     """eps_w [B,2,Tx] / eps_z [B,inter,Ty] replace the two torch.randn draws
     (duration_predictors.py:257, models.py:267); when None they are drawn here in the reference's
-    order from the global CPU generator."""
+    order from the global CPU generator.  `timers` (a dict) receives the four stage times the
+    reference prints (models.py:273-279): enc, dp, flow, dec seconds."""
+    import time as _time
     with torch.no_grad():
         g = None
         if cfg["n_speakers"] > 0:
             g = F.embedding(sid, W["emb_g.weight"]).unsqueeze(-1)
+        _t1 = _time.perf_counter()
         x, m_p, logs_p, x_mask = text_encoder(W, cfg, x_ids, x_lengths, g)
+        _t2 = _time.perf_counter()
         if cfg["use_sdp"]:
             if eps_w is None:
                 eps_w = torch.randn(x.size(0), 2, x.size(2))
             logw = sdp_reverse(W, cfg, x, x_mask, g, eps_w, noise_scale_w)
         else:
             logw = dp_forward(W, cfg, x, x_mask, g)
+        _t3 = _time.perf_counter()
         w_ceil, y_lengths = durations_to_lengths(logw, x_mask, length_scale)
         y_mask = sequence_mask(y_lengths, None).unsqueeze(1).to(x_mask.dtype)
         attn, f2p = generate_path(w_ceil, x_mask, y_mask)
@@ -495,8 +501,13 @@ def infer(W, cfg, x_ids, x_lengths, sid=None, noise_scale=1.0, length_scale=1.0,
         if eps_z is None:
             eps_z = torch.randn_like(m_e)
         z_p = m_e + eps_z * torch.exp(logs_e) * noise_scale
+        _t4 = _time.perf_counter()
         z = flow_reverse(W, cfg, z_p, y_mask, g)
+        _t5 = _time.perf_counter()
         o = decoder(W, cfg, (z * y_mask)[:, :, :max_len], g)
+        _t6 = _time.perf_counter()
+        if timers is not None:
+            timers.update(enc=_t2 - _t1, dp=_t3 - _t2, flow=_t5 - _t4, dec=_t6 - _t5)
     if return_stages:
         return dict(x=x, m_p=m_p, logs_p=logs_p, x_mask=x_mask, logw=logw, w_ceil=w_ceil,
                     y_lengths=y_lengths, y_mask=y_mask, attn=attn, f2p=f2p, m_p_exp=m_e,

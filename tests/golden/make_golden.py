@@ -43,6 +43,18 @@ CASES = {
     # the two options no checked-in recipe enables: "pre_conv2" flows + speaker-conditioned encoder
     "tiny_preconv2_spk_b3": ("tiny_preconv2_spk", 40, 3, 3, 11, [11, 5, 8], 17, 107, (0.667, 1.0, 0.8)),
 }
+# Full-size cases (BASELINE.json configs[1]/[2] phoneme counts): these switch on the kernels the tiny
+# cases never reach -- MFMA text-encoder attention (Tx >= 64), the flash attention of the VITS2 flows,
+# 128x128 / 64x256 conv tiles and fused ResBlock pairs with >= 128 time tiles.  To keep the fixtures
+# small the two standard-normal draws are INJECTED: torch.randn / torch.randn_like are patched for the
+# duration of the reference's infer() to return numpy RandomState(seed) draws (a frozen stream), so the
+# tests regenerate eps_w / eps_z from the seed instead of loading them (tests/util.py:big_case_noise).
+# Stored: inputs, logw, y_mask, bit-packed attn, z, audio.
+BIG_CASES = {
+    "v1_b4x128": ("v1", 256, 1, 4, 128, [128, 97, 113, 128], 31, 301, (0.667, 1.0, 0.8)),
+    "v3_b3x128": ("v3", 256, 2, 3, 128, [128, 97, 64], 32, 302, (0.667, 1.0, 0.8)),
+    "vits2_vocos_b2x64": ("vits2_vocos_v1", 128, 1, 2, 64, [64, 49], 34, 304, (0.667, 1.0, 0.8)),
+}
 ONLY = os.environ.get("WETTS_GOLDEN_ONLY")  # comma-separated case names (default: all)
 
 
@@ -84,6 +96,65 @@ def stage_probe(net, x, x_len, sid, scales, noise_seed):
         else:
             logw = net.dp(xe, x_mask, g=g)
     return xe, m_p, logs_p, x_mask, logw
+
+
+def big_noise(seed, shape, which):
+    """The frozen noise stream of the full-size cases (numpy RandomState never changes)."""
+    rs = np.random.RandomState(seed + (0 if which == "w" else 1))
+    return torch.from_numpy(rs.standard_normal(shape).astype(np.float32))
+
+
+def run_big_cases():
+    import unittest.mock as mock
+    for name, (mname, n_vocab, n_spk, B, Tx, lens, wseed, nseed, scales) in BIG_CASES.items():
+        if ONLY and name not in ONLY.split(","):
+            continue
+        cfg = config.make_config(config.MODEL_CONFIGS[mname], n_vocab, n_spk)
+        sd = synth.make_state_dict(cfg, wseed)
+        blob = checkpoint.pack_blob(cfg, sd)
+        net = build_reference(mname, n_vocab, n_spk, sd)
+        gi = torch.Generator().manual_seed(nseed + 7)
+        x = torch.randint(0, n_vocab, (B, Tx), generator=gi)
+        x_len = torch.tensor(lens, dtype=torch.long)
+        sid = torch.randint(0, n_spk, (B,), generator=gi)
+        ns, ls, nsw = scales
+        real_randn, real_randn_like = torch.randn, torch.randn_like
+
+        def fake_randn(*size, **kw):
+            size = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else size
+            assert size == (B, 2, Tx), size  # duration_predictors.py:257
+            return big_noise(nseed, size, "w")
+
+        def fake_randn_like(t, **kw):
+            assert t.dim() == 3 and t.shape[0] == B and t.shape[1] == cfg.inter_channels  # models.py:267
+            return big_noise(nseed, tuple(t.shape), "z")
+
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()), \
+                mock.patch.object(torch, "randn", fake_randn), \
+                mock.patch.object(torch, "randn_like", fake_randn_like):
+            o, attn, y_mask, (z, z_p, m_pe, logs_pe) = net.infer(
+                x, x_len, sid=sid, noise_scale=ns, length_scale=ls, noise_scale_w=nsw)
+            g = net.emb_g(sid).unsqueeze(-1) if net.n_speakers > 0 else None
+            xe, m_p, logs_p, x_mask = net.enc_p(x, x_len, g=g)
+            logw = net.dp(xe, x_mask, g=g, reverse=True, noise_scale=nsw) if net.use_sdp \
+                else net.dp(xe, x_mask, g=g)
+        assert torch.randn is real_randn and torch.randn_like is real_randn_like
+        w = torch.exp(logw) * x_mask * ls
+        frac = (torch.ceil(w) - w)[x_mask > 0]
+        margin = float(torch.minimum(frac, 1 - frac).min())
+        Ty = z.shape[2]
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"),
+            model=mname, n_vocab=n_vocab, n_speakers=n_spk, weight_seed=wseed, noise_seed=nseed,
+            noise="randomstate", scales=np.array(scales, np.float64),
+            blob_checksum=synth.blob_checksum(blob),
+            x=x.numpy(), x_lengths=x_len.numpy(), sid=sid.numpy(),
+            x_enc=xe.numpy(), m_p=m_p.numpy(), logs_p=logs_p.numpy(), x_mask=x_mask.numpy(),
+            logw=logw.numpy(), ceil_margin=margin,
+            attn_bits=np.packbits(attn.numpy().astype(np.uint8), axis=-1),
+            attn_shape=np.array(attn.shape), y_mask=y_mask.numpy(), z=z.numpy(), audio=o.numpy())
+        print(f"{name}: Ty={Ty} audio={tuple(o.shape)} rms={float(o.pow(2).mean().sqrt()):.4f} "
+              f"ceil_margin={margin:.2e} frames/phone={float(y_mask.sum() / x_mask.sum()):.2f}")
 
 
 def main():
@@ -135,6 +206,8 @@ def main():
         print(f"{name}: Ty={Ty} audio={tuple(o.shape)} rms={rms:.4f} ceil_margin={margin:.2e} "
               f"frames/phone={float(y_mask.sum() / x_mask.sum()):.2f}")
 
+    torch.set_num_threads(8)
+    run_big_cases()
     if ONLY:
         return
     # MAS known-answer vectors from the reference's maximum_path (numba stub => plain Python)
@@ -173,6 +246,40 @@ def main():
     np.savez_compressed(os.path.join(OUT, "generate_path_kat.npz"), durations=d.numpy(),
                         y_lengths=ylen.numpy(), attn=attn.numpy())
     print("generate_path_kat: ok")
+    chunk_kat()
+
+
+def chunk_kat():
+    """Known answers of the reference's streaming helpers get_chunks / depadding
+    (wetts/vits/inference_onnx.py:37-76): the two function definitions are lifted out of the file's
+    AST and executed as they are (the module itself imports onnxruntime, which is absent)."""
+    import ast
+    import math
+    src = open(os.path.join(ref_import.REF_VITS, "inference_onnx.py")).read()
+    tree = ast.parse(src)
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("get_chunks", "depadding")]
+    assert len(fns) == 2
+    ns = {"math": math, "np": np}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "inference_onnx.py", "exec"), ns)
+    rows = []
+    for L in (1, 7, 39, 40, 41, 50, 79, 80, 81, 100, 120, 333):
+        for block, pad in ((40, 10), (16, 4), (25, 0), (40, 60), (-1, 10)):
+            hop = 256 if block != 16 else 64
+            mel = np.arange(L, dtype=np.int64).reshape(1, L, 1)
+            with contextlib.redirect_stdout(io.StringIO()):
+                chunks = ns["get_chunks"](mel, block, pad)
+            for i, ch in enumerate(chunks):
+                a, b = int(ch[0, 0, 0]), int(ch[0, -1, 0]) + 1
+                n = (b - a) * hop
+                audio = np.arange(n, dtype=np.int64).reshape(1, n)
+                if block == -1:  # one window, nothing to discard (inference_onnx.py:152-158)
+                    lo, hi = 0, n
+                else:
+                    kept = ns["depadding"](audio, len(chunks), i, block, pad, hop)
+                    lo, hi = (int(kept[0, 0]), int(kept[0, -1]) + 1) if kept.shape[1] else (0, 0)
+                rows.append((L, block, pad, hop, len(chunks), i, a, b, lo, hi))
+    np.savez_compressed(os.path.join(OUT, "chunk_kat.npz"), rows=np.array(rows, np.int64))
+    print("chunk_kat:", len(rows), "windows")
 
 
 if __name__ == "__main__":

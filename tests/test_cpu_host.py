@@ -97,6 +97,42 @@ def test_pack_blob_roundtrip_and_errors():
     bad["enc_p.proj.bias"] = torch.zeros(3)
     with pytest.raises(ValueError):
         checkpoint.pack_blob(cfg, bad)
+    # non-strict: the reference's deterministic init values, not zeros, for what is missing
+    bad = dict(sd)
+    bad.pop("enc_p.encoder.norm_layers_1.0.gamma")
+    lay = {n: (off, numel) for n, off, numel, _ in checkpoint.blob_layout(cfg)}
+    off, numel = lay["enc_p.encoder.norm_layers_1.0.gamma"]
+    assert torch.equal(checkpoint.pack_blob(cfg, bad, strict=False)[off:off + numel],
+                       torch.ones(numel))
+
+
+def test_load_checkpoint_is_strict(tmp_path):
+    """A checkpoint that lacks tensors the config asks for (wrong n_layers / flow type / vocoder
+    pairing) must be refused, not zero-filled (round-1 ADVICE)."""
+    from wetts_amd import SynthesizerTrn, models
+    net = SynthesizerTrn(30, 513, 32, n_speakers=2, **config.MODEL_CONFIGS["tiny"])
+    sd = synth.make_state_dict(net.cfg, 1)
+    sd.pop("dec.conv_post.weight")
+    torch.save({"model": sd, "iteration": 7, "learning_rate": 1e-4}, tmp_path / "G_7.pth")
+    with pytest.raises(KeyError):
+        models.load_checkpoint(str(tmp_path / "G_7.pth"), net, None)
+
+
+def test_chunk_helpers_match_the_references_own_functions():
+    """tests/golden/chunk_kat.npz holds the outputs of get_chunks / depadding lifted out of the
+    reference's inference_onnx.py:37-76 (make_golden.py:chunk_kat) over 184 windows: lengths around
+    the block boundaries, pad > block, pad = 0, the single-window mode."""
+    from wetts_amd.session import depad_bounds, get_chunks
+    rows = np.load(os.path.join(util.GOLDEN, "chunk_kat.npz"))["rows"].tolist()
+    assert len(rows) > 100
+    for (L, block, pad, hop, n, i, a, b, lo, hi) in rows:
+        wins = get_chunks(L, block, pad)
+        assert len(wins) == n and wins[i] == (a, b), (L, block, pad, i)
+        if block == -1:
+            continue
+        g = depad_bounds(n, i, block, pad, hop, (b - a) * hop)
+        g = (g[0], g[1]) if g[1] > g[0] else (0, 0)
+        assert g == (lo, hi), (L, block, pad, i, g, (lo, hi))
 
 
 def test_config_validation_and_unsupported_options():
@@ -109,8 +145,11 @@ def test_config_validation_and_unsupported_options():
     # without speakers the reference's enc_gin_channels is 0 (models.py:87-90): option is a no-op
     assert config.make_config(dict(config.MODEL_CONFIGS["v1"], use_spk_conditioned_encoder=True),
                               10, 0).use_spk_conditioned_encoder == 0
-    assert config.make_config(dict(config.MODEL_CONFIGS["v1"], use_transformer_flows=True), 10,
-                              1).transformer_flows == 1  # default type "pre_conv"
+    # a config that omits transformer_flow_type gets the reference's default,
+    # "mono_layer_post_residual" (models.py:74-75) -- not implemented here, so it must raise rather
+    # than silently build pre_conv flows
+    with pytest.raises(NotImplementedError):
+        config.make_config(dict(config.MODEL_CONFIGS["v1"], use_transformer_flows=True), 10, 1)
     with pytest.raises(NotImplementedError):
         config.make_config(dict(config.MODEL_CONFIGS["v1"], vocoder_type="bigvgan"), 10, 1)
     vc = config.make_config(dict(config.MODEL_CONFIGS["v1"], vocoder_type="vocos"), 10, 1)

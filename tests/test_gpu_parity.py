@@ -56,9 +56,13 @@ def test_infer_matches_reference_golden(name):
     same_T = tuple(attn.shape) == tuple(case["attn"].shape)
     rows["attn_equal"] = bool(same_T and np.array_equal(attn.cpu().numpy().astype(np.uint8),
                                                         case["attn"]))
+    rows["w_err_x10_vs_ceil_margin"] = [
+        10 * float(np.abs(np.exp(st["logw"].cpu().numpy()) - np.exp(case["logw"][:, 0])).max()) * ls,
+        float(case["ceil_margin"])]
     if same_T:
-        rows["m_p_exp"] = util.rel_rms(m_p.cpu().numpy(), case["m_p_exp"])
-        rows["z_p"] = util.rel_rms(z_p.cpu().numpy(), case["z_p"])
+        if "z_p" in case:  # the compact full-size fixtures keep z and audio only
+            rows["m_p_exp"] = util.rel_rms(m_p.cpu().numpy(), case["m_p_exp"])
+            rows["z_p"] = util.rel_rms(z_p.cpu().numpy(), case["z_p"])
         rows["z"] = util.rel_rms(z.cpu().numpy(), case["z"])
         rows["audio_abs_rms"] = util.rms(o.cpu().numpy() - case["audio"])
         rows["audio_rel_rms"] = util.rel_rms(o.cpu().numpy(), case["audio"])
@@ -66,9 +70,12 @@ def test_infer_matches_reference_golden(name):
     _report(name, rows)
     print(name, rows)
     assert rows["x_enc"] < 1e-4 and rows["m_p"] < 1e-4 and rows["logs_p"] < 1e-4
-    assert rows["logw_maxabs"] < 1e-3
+    assert rows["logw_maxabs"] < 1e-4
+    # y_mask / attn equality is only a fair demand while the error in w = exp(logw)*length_scale is
+    # an order of magnitude inside the fixture's ceil() margin
+    assert rows["w_err_x10_vs_ceil_margin"][0] < rows["w_err_x10_vs_ceil_margin"][1]
     assert rows["y_mask_equal"] and rows["attn_equal"]
-    assert rows["z_p"] < 1e-4 and rows["z"] < 2e-4
+    assert rows.get("z_p", 0.0) < 1e-4 and rows["z"] < 2e-4
     assert rows["audio_abs_rms"] < ABS_RMS_OURS < ABS_RMS_GATE
     assert rows["audio_rel_rms"] < 2e-3
 

@@ -20,10 +20,17 @@ def test_infer_matches_reference(name):
                   eps_w=util.t(case["eps_w"]), eps_z=util.t(case["eps_z"]), return_stages=True)
     assert util.rel_rms(st["x"].numpy(), case["x_enc"]) < 2e-5
     assert util.rel_rms(st["m_p"].numpy(), case["m_p"]) < 2e-5
-    assert np.abs(st["logw"].numpy() - case["logw"]).max() < 2e-4
+    dlw = float(np.abs(st["logw"].numpy() - case["logw"]).max())
+    assert dlw < 2e-4
+    # ceil() margin stored with the fixture: the distance of w = exp(logw)*mask*length_scale to the
+    # nearest integer; equality of y_mask / attn is only a fair demand while the observed error in w
+    # stays an order of magnitude inside it
+    w_err = float(np.abs(np.exp(st["logw"].numpy()) - np.exp(case["logw"])).max()) * ls
+    assert float(case["ceil_margin"]) > 10 * w_err, (float(case["ceil_margin"]), w_err)
     assert np.array_equal(st["y_mask"].numpy(), case["y_mask"])
     assert np.array_equal(st["attn"].numpy().astype(np.uint8), case["attn"])
-    assert util.rel_rms(st["z_p"].numpy(), case["z_p"]) < 2e-5
+    if "z_p" in case:  # the compact full-size fixtures keep z and audio only
+        assert util.rel_rms(st["z_p"].numpy(), case["z_p"]) < 2e-5
     assert util.rel_rms(st["z"].numpy(), case["z"]) < 5e-5
     # the north-star gate is 1e-3 absolute RMS; the oracle sits ~100x inside it
     assert util.rms(st["o"].numpy() - case["audio"]) < 2e-5

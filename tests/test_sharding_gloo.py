@@ -72,3 +72,48 @@ def test_two_rank_broadcast_and_shard(tmp_path):
     assert [g["rank"] for g in got] == [0, 1]
     assert all(abs(g["sum"] - ref) < 1e-9 for g in got)  # every rank holds rank 0's weights
     assert sorted(got[0]["idx"] + got[1]["idx"]) == list(range(10))
+
+
+_RANK_SCRIPT = """
+import os, sys, torch
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from wetts_amd import sharding as sh
+rank, local_rank, world = sh.init_process_group(backend="gloo")
+blob = torch.arange(1000, dtype=torch.float32) if rank == 0 else torch.zeros(1000)
+sh.broadcast_blob(blob, src=0)
+mine = sh.shard_utterances(list(range(32, 48)), world)[rank]
+got = sh.gather_objects(dict(rank=rank, world=dist.get_world_size(), n=len(mine),
+                             s=float(blob.sum())), dst=0)
+if rank == 0:
+    torch.save(got, sys.argv[1])
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_launch_ranks_spawns_the_ranks_itself(tmp_path):
+    """The code path behind `python bench.py --gpus N` (no torchrun around it): launch_ranks
+    re-executes a script under torch.distributed.run; here with gloo and no GPU requirement."""
+    script = tmp_path / "rank_script.py"
+    script.write_text(_RANK_SCRIPT.format(root=ROOT))
+    out = tmp_path / "got.pt"
+    rc = sharding.launch_ranks(2, str(script), [str(out)], require_gpus=False)
+    assert rc == 0
+    got = torch.load(out, weights_only=False)
+    assert [g["rank"] for g in got] == [0, 1] and all(g["world"] == 2 for g in got)
+    assert all(g["n"] == 8 and g["s"] == 499500.0 for g in got)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 2` on a node with fewer than 2 GPUs must fail loudly instead of
+    printing a 1-GPU line (round-1 VERDICT item 1).  Here: no GPU at all => exit code 3."""
+    import subprocess
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("node has >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "WETTS_BENCH_SINGLE_DEVICE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3 and p.stdout.strip() == ""
+    assert "refusing" in p.stderr

@@ -10,12 +10,31 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 INFER_CASES = ["tiny_sdp_b3", "tiny_dp_b2", "tiny_sdp_nonoise", "tiny_sdp_single", "v1_b2", "v3_b2",
                "tiny_vocos_b2", "vocos_b2",  # VocosGenerator (decoders.py:251-308)
                "tiny_vits2_vocos_b2", "vits2_vocos_b2",  # + VITS2 pre_conv flows (flows.py:95-177)
-               "tiny_preconv2_spk_b3"]  # pre_conv2 flows (flows.py:16-92) + speaker-conditioned encoder
+               "tiny_preconv2_spk_b3",  # pre_conv2 flows (flows.py:16-92) + speaker-conditioned encoder
+               # BASELINE-size phoneme counts (make_golden.py BIG_CASES): MFMA / flash attention, the
+               # 128x128 and 64x256 conv tiles and fused ResBlock launches with >= 128 time tiles
+               "v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64"]
+BIG_CASES = ["v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64"]
+
+
+def big_case_noise(seed, shape, which):
+    """The injected standard-normal draws of the BIG cases: numpy RandomState (a frozen stream),
+    exactly as tests/golden/make_golden.py:big_noise fed them to the reference."""
+    rs = np.random.RandomState(int(seed) + (0 if which == "w" else 1))
+    return rs.standard_normal(shape).astype(np.float32)
 
 
 def load_case(name):
     d = np.load(os.path.join(GOLDEN, name + ".npz"))
-    return {k: d[k] for k in d.files}
+    c = {k: d[k] for k in d.files}
+    if "noise" in c and str(c["noise"]) == "randomstate":  # compact full-size fixture
+        B, Tx = c["x"].shape
+        I, Ty = c["z"].shape[1], c["z"].shape[2]
+        c["eps_w"] = big_case_noise(c["noise_seed"], (B, 2, Tx), "w")
+        c["eps_z"] = big_case_noise(c["noise_seed"], (B, I, Ty), "z")
+        shp = tuple(int(v) for v in c["attn_shape"])
+        c["attn"] = np.unpackbits(c["attn_bits"], axis=-1)[..., :shp[-1]].reshape(shp)
+    return c
 
 
 def case_model(case):

@@ -22,7 +22,7 @@ class WettsError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4  # WETTS_ABI_VERSION of include/wetts_hip.h this binding was written against
+ABI_VERSION = 5  # WETTS_ABI_VERSION of include/wetts_hip.h this binding was written against
 
 
 class Config(C.Structure):
@@ -88,7 +88,11 @@ SIGNATURES = {
     "wetts_text_encoder": (_I32, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _P]),
     "wetts_duration_sdp": (_I32, [_P, _P, _P, _P, _P, _F, _I32, _I32, _P, _P, _P, _I64, _P]),
     "wetts_duration_dp": (_I32, [_P, _P, _P, _P, _I32, _I32, _P, _P, _I64, _P]),
-    "wetts_durations_to_lengths": (_I32, [_P, _P, _F, _I32, _I32, _P, _P, _P, _P]),
+    "wetts_durations_to_lengths": (_I32, [_P, _P, _F, _I32, _I32, _P, _P, _P, _P, _P]),
+    "wetts_set_status_word": (_I32, [_P, _P, _P]),
+    "wetts_set_seed": (_I32, [_P, C.c_uint64]),
+    "wetts_randn": (_I32, [_P, _I64, C.c_uint64, C.c_uint64, _P]),
+    "wetts_mask_rows": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "wetts_length_regulate": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _I32, _I32, _I32,
                                      _P, _P, _P, _P, _P, _P, _P]),
     "wetts_flow_reverse": (_I32, [_P, _P, _P, _P, _I32, _I32, _P, _P, _I64, _P]),
@@ -112,6 +116,9 @@ SIGNATURES = {
                                      C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(_I32)]),
 }
+
+# WETTS_STATUS_* bits of include/wetts_hip.h
+STATUS_SPLINE_DOMAIN, STATUS_PHONE_ID_RANGE, STATUS_SPEAKER_ID_RANGE, STATUS_DURATION_NONFINITE = 1, 2, 4, 8
 
 _lib = None
 

@@ -82,11 +82,19 @@ def pack_blob(cfg, state_dict, strict=True):
             raise ValueError(f"{name}: checkpoint shape {tuple(t.shape)} != expected {shape}")
         blob[off:off + numel] = t.reshape(-1)
     if missing:
-        # the reference tolerates missing keys (task.py:44-49: keeps the init value); we have no
-        # random init to keep, so strict mode refuses and non-strict leaves zeros.
-        msg = f"{len(missing)} tensors missing from checkpoint, e.g. {missing[:4]}"
+        # the reference tolerates missing keys (task.py:44-49: keeps the module's init value).  There
+        # is no random init to keep here, so strict mode (the default, and what load_checkpoint uses)
+        # refuses; non-strict fills the DETERMINISTIC init values of the reference (LayerNorm
+        # gamma = 1, normalization.py:12; ConvNeXt scale = 1/num_layers, decoders.py:236-238), leaves
+        # the randomly initialised rest at zero, and reports every name.
+        msg = f"{len(missing)} tensors missing from checkpoint: {missing}"
         if strict:
             raise KeyError(msg)
+        for name, off, numel, shape in blob_layout(cfg):
+            if name in missing and name.endswith(".gamma"):
+                blob[off:off + numel] = 1.0
+            elif name in missing and name.endswith(".scale"):
+                blob[off:off + numel] = 1.0 / max(1, int(cfg.vocos_num_layers))
         logger.warning(msg)
     return blob
 

@@ -150,7 +150,9 @@ def make_config(model, n_vocab, n_speakers):
                                   "'vocos' (decoders.py:251-308) exist in the reference")
     c = _lib.Config()
     if _get(model, "use_transformer_flows", False):
-        ft = _get(model, "transformer_flow_type", "pre_conv")  # models.py:74-75 default
+        # models.py:74-75: kwargs.get("transformer_flow_type", "mono_layer_post_residual") -- a config
+        # that omits the key selects the mono-layer flows, which are not implemented here => raise
+        ft = _get(model, "transformer_flow_type", "mono_layer_post_residual")
         if ft not in ("pre_conv", "pre_conv2"):
             raise NotImplementedError(
                 f"transformer_flow_type={ft!r}: 'pre_conv' (flows.py:95-177, the type the "

@@ -404,6 +404,12 @@ static int attn_flash_enabled() {
   return v;
 }
 
+int64_t attn_score_elems(int window, int dk, int B, int n_heads, int T) {
+  const bool mfma_path = window < 0 || T >= 64;
+  if (mfma_path && window < 0 && dk <= 48 && attn_flash_enabled()) return 0;  // flash: no S in HBM
+  return (int64_t)B * n_heads * T * T;
+}
+
 int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t qkv_batch_stride,
                         const float* mask, const float* emb_rel_k, const float* emb_rel_v,
                         int window, int B, int n_heads, int dk, int T, float* scores, float* out,
@@ -418,7 +424,7 @@ int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t 
     // added inside the band by the score epilogue, the relative-value term a 2w+1-tap pass over
     // P after the P.V contraction.  Behind the scores the workspace holds the transposed v
     // (B*H*dk*T floats) and that table (B*H*(2w+1)*T).
-    float* vT = scores + (int64_t)B * n_heads * T * T;
+    float* vT = scores + attn_score_elems(window, dk, B, n_heads, T);
     // (heads wider than 48 channels -- none in the reference's configs -- keep the three-kernel path)
     if (window < 0 && dk <= 48 && attn_flash_enabled()) {
       const int64_t nv = (int64_t)B * n_heads * dk * T;

@@ -7,7 +7,8 @@ namespace wetts {
 
 // a3 emb lookup * sqrt(H) * mask + sequence_mask  (encoders.py:48-53, commons.py:113-117)
 int32_t k_embed_mask(const int64_t* ids, const int64_t* lengths, const float* emb, int n_vocab,
-                     int B, int H, int T, float* x_out, float* mask_out, hipStream_t s);
+                     int B, int H, int T, float* x_out, float* mask_out, int32_t* status,
+                     hipStream_t s);
 
 // a7 channel LayerNorm (normalization.py:16-19), fused with the surrounding elementwise ops:
 //   v = a (+ add);  y = LN(v)*gamma+beta;  if gelu: y = gelu_erf(y);  if res: y += res;
@@ -25,7 +26,7 @@ int32_t k_cond_linear(const float* g, const float* W, const float* bias, int B, 
                       float* out, hipStream_t s);
 
 int32_t k_gather_rows(const int64_t* idx, const float* table, int n_rows, int B, int C, float* out,
-                      hipStream_t s);
+                      int32_t* status, hipStream_t s);
 
 // x[b,c,t] += v[b,c]
 int32_t k_add_bias_b(float* x, const float* v, int B, int C, int T, hipStream_t s);
@@ -69,7 +70,7 @@ int32_t k_conv_post_tanh(const float* x, const float* w, int k, int B, int C, in
 // a10 (models.py:254-256)
 int32_t k_durations_to_lengths(const float* logw, const float* mask, float length_scale, int B,
                                int T, float* w_ceil, float* cum, int64_t* y_lengths,
-                               hipStream_t s);
+                               int32_t* status, hipStream_t s);
 
 // a10-a12 (models.py:257-267; commons.py:113-136)
 int32_t k_frame_index(const float* cum, const int64_t* y_lengths, int B, int Tx, int Ty,
@@ -118,6 +119,16 @@ int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t 
                         const float* mask, const float* emb_rel_k, const float* emb_rel_v,
                         int window, int B, int n_heads, int dk, int T, float* scores, float* out,
                         hipStream_t s);
+
+// scores-workspace floats k_rel_attention needs in FRONT of its vT / rel-table regions: B*H*T*T on
+// the three-kernel path, 0 on the flash path (shared by the workspace sizing in model.hip)
+int64_t attn_score_elems(int window, int dk, int B, int n_heads, int T);
+
+// standard-normal draws (Philox4x32-10 + Box-Muller); element i depends only on (seed, offset, i)
+int32_t k_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s);
+// out = x * mask[b,t]
+int32_t k_mask_rows(const float* x, const float* mask, int B, int C, int T, float* out,
+                    hipStream_t s);
 
 // a15 MAS
 int32_t k_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, int B, int Ty,

@@ -14,7 +14,7 @@ __global__ void embed_mask_kernel(const int64_t* __restrict__ ids,
                                   const int64_t* __restrict__ lengths,
                                   const float* __restrict__ emb, int n_vocab, int B, int H, int T,
                                   float scale, float* __restrict__ x_out,
-                                  float* __restrict__ mask_out) {
+                                  float* __restrict__ mask_out, int32_t* __restrict__ status) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t total = (int64_t)B * H * T;
   if (idx >= total) return;
@@ -25,8 +25,12 @@ __global__ void embed_mask_kernel(const int64_t* __restrict__ ids,
   float v = 0.f;
   if (valid) {
     int64_t id = ids[(int64_t)b * T + t];
-    if (id < 0) id = 0;
-    if (id >= n_vocab) id = n_vocab - 1;
+    // nn.Embedding raises IndexError here (encoders.py:48); the clamp keeps the access in bounds
+    // and the status bit lets the host raise
+    if (id < 0 || id >= n_vocab) {
+      if (status && c == 0) atomicOr(status, WETTS_STATUS_PHONE_ID_RANGE);
+      id = id < 0 ? 0 : n_vocab - 1;
+    }
     v = emb[id * H + c] * scale;
   }
   x_out[idx] = v;
@@ -34,12 +38,13 @@ __global__ void embed_mask_kernel(const int64_t* __restrict__ ids,
 }
 
 int32_t k_embed_mask(const int64_t* ids, const int64_t* lengths, const float* emb, int n_vocab,
-                     int B, int H, int T, float* x_out, float* mask_out, hipStream_t s) {
+                     int B, int H, int T, float* x_out, float* mask_out, int32_t* status,
+                     hipStream_t s) {
   int64_t n = (int64_t)B * H * T;
   if (n == 0) return WETTS_OK;
   float scale = (float)sqrt((double)H);  // math.sqrt(hidden_channels), encoders.py:48
   hipLaunchKernelGGL(embed_mask_kernel, grid1d(n, 256), dim3(256), 0, s, ids, lengths, emb,
-                     n_vocab, B, H, T, scale, x_out, mask_out);
+                     n_vocab, B, H, T, scale, x_out, mask_out, status);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -181,21 +186,24 @@ int32_t k_cond_linear(const float* g, const float* W, const float* bias, int B, 
 }
 
 __global__ void gather_rows_kernel(const int64_t* __restrict__ idx, const float* __restrict__ table,
-                                   int n_rows, int B, int C, float* __restrict__ out) {
+                                   int n_rows, int B, int C, float* __restrict__ out,
+                                   int32_t* __restrict__ status) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
   int b = i / C, c = i % C;
   int64_t r = idx[b];
-  if (r < 0) r = 0;
-  if (r >= n_rows) r = n_rows - 1;
+  if (r < 0 || r >= n_rows) {  // emb_g(sid) raises IndexError in the reference (models.py:239)
+    if (status && c == 0) atomicOr(status, WETTS_STATUS_SPEAKER_ID_RANGE);
+    r = r < 0 ? 0 : n_rows - 1;
+  }
   out[i] = table[r * C + c];
 }
 
 int32_t k_gather_rows(const int64_t* idx, const float* table, int n_rows, int B, int C, float* out,
-                      hipStream_t s) {
+                      int32_t* status, hipStream_t s) {
   if (B * C == 0) return WETTS_OK;
   hipLaunchKernelGGL(gather_rows_kernel, grid1d((int64_t)B * C, 256), dim3(256), 0, s, idx, table,
-                     n_rows, B, C, out);
+                     n_rows, B, C, out, status);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -352,7 +360,7 @@ __global__ void spline_inverse_kernel(float* __restrict__ z, int ch0, int ch1,
     const float qc = -in_delta * dx;
     const float disc = qb * qb - 4.f * qa * qc;
     if (!(disc >= 0.f)) {
-      if (status) atomicOr(status, 1);
+      if (status) atomicOr(status, WETTS_STATUS_SPLINE_DOMAIN);
     }
     const float root = (2.f * qc) / (-qb - sqrtf(disc));
     outv = root * in_bw + in_cw;
@@ -522,7 +530,8 @@ __global__ __launch_bounds__(64) void durations_kernel(const float* __restrict__
                                                        float length_scale, int B, int T,
                                                        float* __restrict__ w_ceil,
                                                        float* __restrict__ cum,
-                                                       int64_t* __restrict__ y_lengths) {
+                                                       int64_t* __restrict__ y_lengths,
+                                                       int32_t* __restrict__ status) {
   const int b = blockIdx.x, lane = threadIdx.x;
   float carry = 0.f;
   for (int t0 = 0; t0 < T; t0 += 64) {
@@ -545,16 +554,22 @@ __global__ __launch_bounds__(64) void durations_kernel(const float* __restrict__
   }
   if (lane == 0) {
     float tot = carry < 1.f ? 1.f : carry;  // clamp_min(sum, 1)
+    // NaN / inf durations (a spline-domain failure upstream, or exp overflow): the float -> int64
+    // cast is undefined for them; flag and fall back to the clamp value
+    if (!(tot <= 9.0e15f)) {
+      if (status) atomicOr(status, WETTS_STATUS_DURATION_NONFINITE);
+      tot = 1.f;
+    }
     y_lengths[b] = (int64_t)tot;
   }
 }
 
 int32_t k_durations_to_lengths(const float* logw, const float* mask, float length_scale, int B,
                                int T, float* w_ceil, float* cum, int64_t* y_lengths,
-                               hipStream_t s) {
+                               int32_t* status, hipStream_t s) {
   if (B == 0) return WETTS_OK;
   hipLaunchKernelGGL(durations_kernel, dim3(B), dim3(64), 0, s, logw, mask, length_scale, B, T,
-                     w_ceil, cum, y_lengths);
+                     w_ceil, cum, y_lengths, status);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -857,6 +872,73 @@ int32_t k_add_bias_b_mask(float* x, const float* v, const float* mask, int B, in
   int64_t n = (int64_t)B * C * T;
   if (n == 0) return WETTS_OK;
   hipLaunchKernelGGL(add_bias_b_mask_kernel, grid1d(n, 256), dim3(256), 0, s, x, v, mask, n, C, T);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Standard-normal draws on the device: Philox4x32-10 counter RNG (Salmon et al., SC'11) + Box-Muller.
+// Replaces the two torch.randn calls of the reference (duration_predictors.py:257, models.py:267);
+// element i of a draw depends only on (seed, offset + i/4), so results do not depend on the launch
+// geometry.  One thread produces four values.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 outputs
+  if (q * 4 >= n) return;
+  const uint64_t ctr = offset + (uint64_t)q;
+  uint32_t r[4];
+  philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  float v[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    // u1 in (0, 1], u2 in [0, 1): 24-bit mantissas, log(u1) finite
+    const float u1 = ((float)(r[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    const float u2 = (float)(r[2 * h + 1] >> 8) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u2, &sn, &cs);
+    v[2 * h] = rad * cs;
+    v[2 * h + 1] = rad * sn;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (q * 4 + i < n) out[q * 4 + i] = v[i];
+}
+
+int32_t k_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s) {
+  if (n <= 0) return WETTS_OK;
+  hipLaunchKernelGGL(randn_kernel, grid1d((n + 3) / 4, 256), dim3(256), 0, s, out, n, seed, offset);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// out[b,c,t] = x[b,c,t] * mask[b,t]   (`z * y_mask` of infer_encoder, models.py:322-331)
+__global__ void mask_rows_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                 int64_t total, int C, int T, float* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t b = idx / ((int64_t)C * T);
+  out[idx] = x[idx] * mask[b * T + idx % T];
+}
+
+int32_t k_mask_rows(const float* x, const float* mask, int B, int C, int T, float* out,
+                    hipStream_t s) {
+  const int64_t n = (int64_t)B * C * T;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(mask_rows_kernel, grid1d(n, 256), dim3(256), 0, s, x, mask, n, C, T, out);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

@@ -411,6 +411,10 @@ struct wetts_model {
                                   // (HBM-bound, +6..30 %); half of it at C >= 64 (profiles/r01_conv32_rb2_chain.txt)
   mutable std::vector<PackedConvB> b_ups;
   mutable std::vector<std::vector<PackedConvB>> b_c1, b_c2;  // per resblock
+  // device status word the stage calls OR their WETTS_STATUS_* bits into (wetts_set_status_word)
+  mutable int32_t* status_word = nullptr;
+  // the model's own standard-normal stream (wetts_infer with eps == NULL)
+  mutable uint64_t rng_seed = 0, rng_offset = 0;
   int mrf_streams = 1;
   hipStream_t aux_stream[WETTS_MAX_RB_KERNELS] = {};
   hipEvent_t ev_fork = nullptr, ev_chain[WETTS_MAX_RB_KERNELS] = {};
@@ -730,7 +734,11 @@ static int64_t ws_flow(const wetts_config_t* c, int B, int Ty) {
               A256(B * (I / 2) * Ty) + A256(B * 2 * H * c->flow_wn_layers);
   if (c->transformer_flows != 0) {
     const int64_t He = c->transformer_flows == 1 ? I / 2 : H;
-    n += 9 * A256(B * He * Ty) + A256((int64_t)B * 2 * Ty * Ty + B * He * Ty + (int64_t)B * 2 * 9 * Ty);
+    // the T*T score region only exists on the three-kernel attention path; the flash kernel (every
+    // reference config: window-less, dk = 48) needs the transposed v and nothing else
+    n += 9 * A256(B * He * Ty) +
+         A256(attn_score_elems(c->transformer_flows == 1 ? -1 : 4, (int)(He / 2), B, 2, Ty) + B * He * Ty +
+              (int64_t)B * 2 * 9 * Ty);
   }
   return n;
 }
@@ -908,7 +916,7 @@ int32_t wetts_speaker_embedding(const wetts_model_t* m, const int64_t* sid, int3
     return WETTS_OK;
   }
   WETTS_REQUIRE(sid != nullptr, "sid required when n_speakers > 0");
-  return k_gather_rows(sid, m->emb_g, m->cfg.n_speakers, B, gin, g_out, s);
+  return k_gather_rows(sid, m->emb_g, m->cfg.n_speakers, B, gin, g_out, m->status_word, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -990,7 +998,7 @@ int32_t wetts_text_encoder(const wetts_model_t* m, const int64_t* x, const int64
   }
   // x = emb(x)*sqrt(H), masked (encoders.py:48-53; Encoder.forward x = x * x_mask, attentions.py:72)
   float* xa = x_enc;  // current activations live in xa
-  WETTS_TRY(k_embed_mask(x, x_lengths, m->emb, c->n_vocab, B, H, Tx, xa, x_mask, s));
+  WETTS_TRY(k_embed_mask(x, x_lengths, m->emb, c->n_vocab, B, H, Tx, xa, x_mask, m->status_word, s));
   WETTS_TRY(run_enc_layers(m->enc, xa, x_mask, B, H, F, nh, c->window_size, Tx, q, k, v, att, y,
                            hid, sc, xb, s, spk_on ? spk : nullptr, 2));
   if (c->n_layers == 0) {
@@ -1046,7 +1054,7 @@ int32_t wetts_duration_sdp(const wetts_model_t* m, const float* x_enc, const flo
     set_error("duration_sdp: workspace too small");
     return WETTS_E_WORKSPACE;
   }
-  if (status_dev) WETTS_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(int32_t), s));
+  if (!status_dev) status_dev = m->status_word;
   // x = pre(x) + cond(g)
   {
     ConvParams p = conv_io(x_enc, H, Tx, xd, H, B);
@@ -1144,10 +1152,36 @@ int32_t wetts_duration_dp(const wetts_model_t* m, const float* x_enc, const floa
 
 int32_t wetts_durations_to_lengths(const float* logw, const float* x_mask, float length_scale,
                                    int32_t B, int32_t Tx, float* w_ceil, float* cum,
-                                   int64_t* y_lengths, void* stream) {
+                                   int64_t* y_lengths, int32_t* status_dev, void* stream) {
   WETTS_REQUIRE(logw && x_mask && w_ceil && cum && y_lengths, "null argument");
   return k_durations_to_lengths(logw, x_mask, length_scale, B, Tx, w_ceil, cum, y_lengths,
-                                (hipStream_t)stream);
+                                status_dev, (hipStream_t)stream);
+}
+
+int32_t wetts_set_status_word(const wetts_model_t* m, int32_t* status_dev, void* stream) {
+  WETTS_REQUIRE(m != nullptr, "null model");
+  if (status_dev)
+    WETTS_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(int32_t), (hipStream_t)stream));
+  m->status_word = status_dev;
+  return WETTS_OK;
+}
+
+int32_t wetts_set_seed(const wetts_model_t* m, uint64_t seed) {
+  WETTS_REQUIRE(m != nullptr, "null model");
+  m->rng_seed = seed;
+  m->rng_offset = 0;
+  return WETTS_OK;
+}
+
+int32_t wetts_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+  WETTS_REQUIRE(out != nullptr || n == 0, "null argument");
+  return k_randn(out, n, seed, offset, (hipStream_t)stream);
+}
+
+int32_t wetts_mask_rows(const float* x, const float* mask, int32_t B, int32_t C, int32_t T,
+                        float* out, void* stream) {
+  WETTS_REQUIRE(x && mask && out, "null argument");
+  return k_mask_rows(x, mask, B, C, T, out, (hipStream_t)stream);
 }
 
 int32_t wetts_length_regulate(const wetts_model_t* m, const float* stats, const float* cum,
@@ -1195,7 +1229,9 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
     tx0 = ws.take<float>(nh2); txm = ws.take<float>(nh2); tq = ws.take<float>(nh2);
     tk = ws.take<float>(nh2); tv = ws.take<float>(nh2); tatt = ws.take<float>(nh2);
     ty = ws.take<float>(nh2); thid = ws.take<float>(nh2); txb = ws.take<float>(nh2);
-    tsc = ws.take<float>((int64_t)B * 2 * Ty * Ty + nh2 + (int64_t)B * 2 * 9 * Ty);  // scores + vT + rel table
+    const int He = c->transformer_flows == 1 ? I / 2 : H;
+    tsc = ws.take<float>(attn_score_elems(c->transformer_flows == 1 ? -1 : 4, He / 2, B, 2, Ty) + nh2 +
+                         (int64_t)B * 2 * 9 * Ty);  // scores (three-kernel path only) + vT + rel table
   }
   if (!ws.ok) {
     set_error("flow_reverse: workspace too small");
@@ -1910,8 +1946,9 @@ int64_t wetts_infer_workspace_bytes(const wetts_model_t* m, int32_t B, int32_t T
   const int64_t H = c->hidden_channels, I = c->inter_channels;
   const int64_t gin = c->gin_channels > 0 ? c->gin_channels : 1;
   int64_t n = A256(B * gin) + A256(B * H * Tx) + A256(B * 2 * I * Tx) + 4 * A256((int64_t)B * Tx) +
-              align_up((int64_t)B * 8, 256) + 2 * A256((int64_t)B * max_frames) +
-              2 * A256(B * I * (int64_t)max_frames);
+              align_up((int64_t)(B + 1) * 8, 256) + 2 * A256((int64_t)B * max_frames) +
+              2 * A256(B * I * (int64_t)max_frames) +
+              A256((int64_t)B * 2 * Tx) + A256(B * I * (int64_t)max_frames);  // internal eps_w / eps_z
   return n + wetts_workspace_bytes(m, B, Tx, max_frames);
 }
 
@@ -1920,8 +1957,7 @@ int32_t wetts_infer(const wetts_model_t* m, const int64_t* x, const int64_t* x_l
                     float noise_scale, float length_scale, float noise_scale_w, int32_t B,
                     int32_t Tx, int32_t max_frames, float* audio, int64_t* y_lengths_host,
                     int32_t* frames_out, void* workspace, int64_t workspace_bytes, void* stream) {
-  WETTS_REQUIRE(m && x && x_lengths && eps_z && audio && y_lengths_host && frames_out,
-                "null argument");
+  WETTS_REQUIRE(m && x && x_lengths && audio && y_lengths_host && frames_out, "null argument");
   WETTS_REQUIRE(B > 0 && Tx > 0 && max_frames > 0, "empty batch");
   hipStream_t s = (hipStream_t)stream;
   const wetts_config_t* c = &m->cfg;
@@ -1936,7 +1972,10 @@ int32_t wetts_infer(const wetts_model_t* m, const int64_t* x, const int64_t* x_l
   float* logw = ws.take<float>((int64_t)B * Tx);
   float* w_ceil = ws.take<float>((int64_t)B * Tx);
   float* cum = ws.take<float>((int64_t)B * Tx);
-  int64_t* ylen = ws.take<int64_t>(B);
+  int64_t* ylen = ws.take<int64_t>(B + 1);  // [B] lengths + the status word: ONE D2H, one sync
+  int32_t* status = reinterpret_cast<int32_t*>(ylen + B);
+  float* own_eps_w = ws.take<float>((int64_t)B * 2 * Tx);
+  float* own_eps_z = ws.take<float>((int64_t)B * I * max_frames);
   int32_t* f2p = ws.take<int32_t>((int64_t)B * max_frames);
   float* y_mask = ws.take<float>((int64_t)B * max_frames);
   float* z_p = ws.take<float>((int64_t)B * I * max_frames);
@@ -1947,22 +1986,56 @@ int32_t wetts_infer(const wetts_model_t* m, const int64_t* x, const int64_t* x_l
   }
   void* scratch = (char*)workspace + ws.off;
   const int64_t scratch_bytes = workspace_bytes - ws.off;
+  // errors the reference raises from inside its modules are collected in a device word for the
+  // duration of this call and read back with y_lengths
+  struct StatusScope {
+    const wetts_model* m;
+    int32_t* saved;
+    ~StatusScope() { m->status_word = saved; }
+  } scope{m, m->status_word};
+  WETTS_HIP_CHECK(hipMemsetAsync(ylen + B, 0, sizeof(int64_t), s));
+  m->status_word = status;
+  // the two torch.randn draws of the reference (duration_predictors.py:257, models.py:267)
+  if (c->use_sdp && !eps_w) {
+    WETTS_TRY(k_randn(own_eps_w, (int64_t)B * 2 * Tx, m->rng_seed, m->rng_offset, s));
+    m->rng_offset += ((uint64_t)B * 2 * Tx + 3) / 4;
+    eps_w = own_eps_w;
+  }
+  if (!eps_z) {
+    WETTS_TRY(k_randn(own_eps_z, (int64_t)B * I * max_frames, m->rng_seed, m->rng_offset, s));
+    m->rng_offset += ((uint64_t)B * I * max_frames + 3) / 4;
+    eps_z = own_eps_z;
+  }
   WETTS_TRY(wetts_speaker_embedding(m, sid, B, g, stream));
   const float* gp = has_g(c) ? g : nullptr;
   WETTS_TRY(wetts_text_encoder(m, x, x_lengths, gp, B, Tx, x_enc, stats, x_mask, scratch,
                                scratch_bytes, stream));
   if (c->use_sdp) {
-    WETTS_REQUIRE(eps_w != nullptr, "eps_w required for the stochastic duration predictor");
-    WETTS_TRY(wetts_duration_sdp(m, x_enc, x_mask, gp, eps_w, noise_scale_w, B, Tx, logw, nullptr,
+    WETTS_TRY(wetts_duration_sdp(m, x_enc, x_mask, gp, eps_w, noise_scale_w, B, Tx, logw, status,
                                  scratch, scratch_bytes, stream));
   } else {
     WETTS_TRY(wetts_duration_dp(m, x_enc, x_mask, gp, B, Tx, logw, scratch, scratch_bytes, stream));
   }
   WETTS_TRY(wetts_durations_to_lengths(logw, x_mask, length_scale, B, Tx, w_ceil, cum, ylen,
-                                       stream));
-  WETTS_HIP_CHECK(hipMemcpyAsync(y_lengths_host, ylen, (size_t)B * sizeof(int64_t),
+                                       status, stream));
+  std::vector<int64_t> host((size_t)B + 1);
+  WETTS_HIP_CHECK(hipMemcpyAsync(host.data(), ylen, (size_t)(B + 1) * sizeof(int64_t),
                                  hipMemcpyDeviceToHost, s));
   WETTS_HIP_CHECK(hipStreamSynchronize(s));  // commons.py:114-115 `length.max()`
+  memcpy(y_lengths_host, host.data(), (size_t)B * sizeof(int64_t));
+  const int32_t st = (int32_t)(host[B] & 0xffffffff);
+  if (st & (WETTS_STATUS_PHONE_ID_RANGE | WETTS_STATUS_SPEAKER_ID_RANGE)) {
+    set_error("infer: %s id outside its embedding table (IndexError in the reference, %s)",
+              (st & WETTS_STATUS_PHONE_ID_RANGE) ? "phoneme" : "speaker",
+              (st & WETTS_STATUS_PHONE_ID_RANGE) ? "encoders.py:48" : "models.py:239");
+    return WETTS_E_INVALID;
+  }
+  if (st & (WETTS_STATUS_SPLINE_DOMAIN | WETTS_STATUS_DURATION_NONFINITE)) {
+    set_error("infer: %s", (st & WETTS_STATUS_SPLINE_DOMAIN)
+                               ? "spline inverse: negative discriminant (transforms.py:171 asserts)"
+                               : "non-finite predicted durations");
+    return WETTS_E_DOMAIN;
+  }
   int64_t Ty = 1;
   for (int b = 0; b < B; ++b)
     if (y_lengths_host[b] > Ty) Ty = y_lengths_host[b];

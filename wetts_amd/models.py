@@ -9,7 +9,13 @@ scope and raise.
 
 Extra, optional keyword arguments (not in the reference): `eps_w` / `eps_z` inject the two
 standard-normal draws the reference makes with torch.randn (duration_predictors.py:257,
-models.py:267) so results can be compared bit-for-noise with a CPU run.
+models.py:267) so results can be compared bit-for-noise with a CPU run.  Without them the draws
+come from the library's Philox kernel (`wetts_randn`), seeded from torch.initial_seed() so that
+torch.manual_seed() makes a run reproducible the way it does for the reference.
+
+One host synchronisation per infer(): y_lengths and the device status word (errors the reference
+raises from inside its modules: IndexError of nn.Embedding, the spline's discriminant assert) come
+back in ONE D2H copy.
 """
 import ctypes as C
 
@@ -69,6 +75,8 @@ class SynthesizerTrn:
         self._ws = _Workspace()
         self.quiet = True      # the reference prints stage timers on every call (:273-279)
         self.last_status = 0
+        self._rng_seed = None  # torch.initial_seed() the Philox offset below belongs to
+        self._rng_offset = 0
 
     # ---- nn.Module-shaped plumbing the reference's callers use -------------------------------
     def eval(self):
@@ -217,6 +225,36 @@ class SynthesizerTrn:
         B, Tx = x.shape
         H, I = self.hidden_channels, self.inter_channels
         s = _lib.current_stream_ptr()
+        # [B] y_lengths + one word of WETTS_STATUS_* bits: read back together, one sync
+        # (the library zeroes the low word it registers; the high word of that int64 is ignored)
+        meta = torch.empty(B + 1, dtype=torch.int64, device=dev)
+        y_lengths = meta[:B]
+        status_ptr = C.c_void_p(meta.data_ptr() + 8 * B)
+        _lib.check(lib.wetts_set_status_word(self._handle, status_ptr, s), "set_status_word")
+        try:
+            return self._encode_stages(lib, x, x_lengths, sid, noise_scale, length_scale,
+                                       noise_scale_w, eps_w, eps_z, meta, y_lengths, status_ptr, s)
+        finally:
+            lib.wetts_set_status_word(self._handle, None, s)
+
+    def _randn(self, *shape):
+        """Standard-normal tensor from the library's Philox kernel (replaces torch.randn)."""
+        lib = self._require()
+        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        if seed != self._rng_seed:
+            self._rng_seed, self._rng_offset = seed, 0
+        out = torch.empty(*shape, dtype=torch.float32, device=self.device)
+        n = out.numel()
+        _lib.check(lib.wetts_randn(_lib.ptr(out), n, seed, self._rng_offset,
+                                   _lib.current_stream_ptr()), "randn")
+        self._rng_offset += (n + 3) // 4
+        return out
+
+    def _encode_stages(self, lib, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w,
+                       eps_w, eps_z, meta, y_lengths, status_ptr, s):
+        dev = self.device
+        B, Tx = x.shape
+        H, I = self.hidden_channels, self.inter_channels
         g = self._speaker(sid, B)
         ws, nws = self._workspace(B, Tx, 0)
         x_enc = torch.empty(B, H, Tx, dtype=torch.float32, device=dev)
@@ -227,16 +265,13 @@ class SynthesizerTrn:
                                           _lib.ptr(x_enc), _lib.ptr(stats), _lib.ptr(x_mask),
                                           _lib.ptr(ws), nws, s), "text_encoder")
         logw = torch.empty(B, Tx, dtype=torch.float32, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
         if self.use_sdp:
-            if eps_w is None:
-                eps_w = torch.randn(B, 2, Tx, dtype=torch.float32, device=dev)
-            eps_w = self._f32(eps_w)
+            eps_w = self._randn(B, 2, Tx) if eps_w is None else self._f32(eps_w)
             if tuple(eps_w.shape) != (B, 2, Tx):
                 raise ValueError(f"eps_w must be [{B},2,{Tx}]")
             _lib.check(lib.wetts_duration_sdp(self._handle, _lib.ptr(x_enc), _lib.ptr(x_mask),
                                               _lib.ptr(g), _lib.ptr(eps_w), float(noise_scale_w),
-                                              B, Tx, _lib.ptr(logw), _lib.ptr(status),
+                                              B, Tx, _lib.ptr(logw), status_ptr,
                                               _lib.ptr(ws), nws, s), "duration_sdp")
         else:
             _lib.check(lib.wetts_duration_dp(self._handle, _lib.ptr(x_enc), _lib.ptr(x_mask),
@@ -244,20 +279,23 @@ class SynthesizerTrn:
                                              nws, s), "duration_dp")
         w_ceil = torch.empty(B, Tx, dtype=torch.float32, device=dev)
         cum = torch.empty(B, Tx, dtype=torch.float32, device=dev)
-        y_lengths = torch.empty(B, dtype=torch.int64, device=dev)
         _lib.check(lib.wetts_durations_to_lengths(_lib.ptr(logw), _lib.ptr(x_mask),
                                                   float(length_scale), B, Tx, _lib.ptr(w_ceil),
-                                                  _lib.ptr(cum), _lib.ptr(y_lengths), s),
-                   "durations_to_lengths")
+                                                  _lib.ptr(cum), _lib.ptr(y_lengths), status_ptr,
+                                                  s), "durations_to_lengths")
         # the one host sync of infer(): output length is data dependent (commons.py:114-115)
-        y_host = y_lengths.cpu()
-        if self.use_sdp and int(status.item()) != 0:
+        meta_host = meta.cpu()
+        y_host = meta_host[:B]
+        self.last_status = int(meta_host[B].item()) & 0xFFFFFFFF
+        if self.last_status & _lib.STATUS_PHONE_ID_RANGE:
+            raise IndexError("index out of range in self (phoneme id outside emb, encoders.py:48)")
+        if self.last_status & _lib.STATUS_SPEAKER_ID_RANGE:
+            raise IndexError("index out of range in self (sid outside emb_g, models.py:239)")
+        if self.last_status & (_lib.STATUS_SPLINE_DOMAIN | _lib.STATUS_DURATION_NONFINITE):
             # the reference dies on `assert (discriminant >= 0).all()` (transforms.py:171)
             raise AssertionError("spline inverse: negative discriminant (transforms.py:171)")
         Ty = int(y_host.max().item()) if B > 0 else 0
-        if eps_z is None:
-            eps_z = torch.randn(B, I, Ty, dtype=torch.float32, device=dev)
-        eps_z = self._f32(eps_z)
+        eps_z = self._randn(B, I, Ty) if eps_z is None else self._f32(eps_z)
         if tuple(eps_z.shape) != (B, I, Ty):
             raise ValueError(f"eps_z must be [{B},{I},{Ty}], got {tuple(eps_z.shape)}")
         f2p = torch.empty(B, Ty, dtype=torch.int32, device=dev)
@@ -315,7 +353,10 @@ class SynthesizerTrn:
         """models.py:282-331.  Returns (attn, y_mask, (z*y_mask, z_p, m_p, logs_p), g)."""
         st = self._encode(x, x_lengths, sid, float(noise_scale), float(length_scale),
                           float(noise_scale_w), eps_w, eps_z)
-        z = st["z"] * st["y_mask"].unsqueeze(1)
+        z = torch.empty_like(st["z"])
+        _lib.check(_lib.load().wetts_mask_rows(_lib.ptr(st["z"]), _lib.ptr(st["y_mask"]), st["B"],
+                                               self.inter_channels, st["Ty"], _lib.ptr(z),
+                                               _lib.current_stream_ptr()), "mask_rows")
         g = st["g"].unsqueeze(-1) if st["g"] is not None else None
         return (st["attn"].unsqueeze(1), st["y_mask"].unsqueeze(1),
                 (z, st["z_p"], st["m_p"], st["logs_p"]), g)
@@ -368,5 +409,8 @@ def load_checkpoint(checkpoint_path, model, optimizer=None):
     weight norm, uploads.  Returns (model, optimizer, learning_rate, iteration) like the
     reference."""
     sd, iteration, lr = checkpoint.load_state_dict_file(checkpoint_path)
-    model.load_state_dict(sd, strict=False)
+    # strict: a tensor the config asks for and the checkpoint lacks means the two do not belong
+    # together (wrong n_layers / flow type / vocoder); the reference would keep a random init value
+    # for it (task.py:44-49) and synthesise noise, here the blob slot would stay zero -- refuse.
+    model.load_state_dict(sd, strict=True)
     return model, optimizer, lr, iteration

@@ -30,6 +30,32 @@ def init_process_group(backend=None):
     return rank, local_rank, world
 
 
+def launch_ranks(n, script, argv, require_gpus=True):
+    """Starts `n` ranks of `script argv...` on THIS node, one process per GPU, by re-executing it
+    under torch.distributed.run with a 127.0.0.1 rendezvous on a free port; returns the exit code.
+    This is what `python bench.py --gpus N` does when it is not already running under torchrun.
+    With `require_gpus` it refuses (code 3, message on stderr, nothing launched) when the node
+    exposes fewer than `n` HIP devices -- a smaller job must never run under a larger label."""
+    import socket
+    import subprocess
+    import sys
+    if require_gpus:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < n:
+            sys.stderr.write(f"{os.path.basename(script)}: {n} ranks requested but this node exposes "
+                             f"{n_dev} HIP device(s); refusing to run a smaller job under a larger "
+                             "label\n")
+            return 3
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(script)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    return subprocess.call(cmd + list(argv), env=env)
+
+
 def shard_utterances(lengths, world_size):
     """Longest-processing-time-first deal of utterances to ranks.
 
