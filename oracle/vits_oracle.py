@@ -551,3 +551,46 @@ def maximum_path_numpy(neg_cent, t_ys, t_xs):
             if index != 0 and (index == y or value[y - 1, index] < value[y - 1, index - 1]):
                 index -= 1
     return paths
+
+
+# ------------------------------------------------------------------------------------------------
+# Philox4x32-10 + Box-Muller: CPU restatement of the library's noise kernel (kernels.hip:randn_kernel).
+# The reference itself draws with torch.randn (duration_predictors.py:257, models.py:267); only the
+# DISTRIBUTION is part of its contract, so this oracle pins (a) the counter RNG to the published
+# Random123 known-answer vectors and (b) the kernel to this restatement element by element.
+# ------------------------------------------------------------------------------------------------
+def philox4x32_10(ctr, key):
+    """ctr uint32[..., 4], key uint32[..., 2] -> uint32[..., 4]  (Salmon et al., SC'11)."""
+    c = [np.asarray(ctr[..., i], dtype=np.uint64) for i in range(4)]
+    k0 = np.asarray(key[..., 0], dtype=np.uint64)
+    k1 = np.asarray(key[..., 1], dtype=np.uint64)
+    M0, M1, m32 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & m32, p1 >> np.uint64(32), p1 & m32
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def philox_randn(n, seed, offset):
+    """n standard-normal float32 values: group q of four uses counter (offset + q), key = seed."""
+    nq = (n + 3) // 4
+    q = np.uint64(offset) + np.arange(nq, dtype=np.uint64)
+    ctr = np.zeros((nq, 4), dtype=np.uint32)
+    ctr[:, 0] = (q & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    ctr[:, 1] = (q >> np.uint64(32)).astype(np.uint32)
+    key = np.empty((nq, 2), dtype=np.uint32)
+    key[:, 0] = np.uint32(seed & 0xFFFFFFFF)
+    key[:, 1] = np.uint32((seed >> 32) & 0xFFFFFFFF)
+    r = philox4x32_10(ctr, key)
+    out = np.empty((nq, 4), dtype=np.float32)
+    for h in range(2):
+        u1 = ((r[:, 2 * h] >> 8).astype(np.float32) + np.float32(1.0)) * np.float32(1.0 / 16777216.0)
+        u2 = (r[:, 2 * h + 1] >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        rad = np.sqrt(np.float32(-2.0) * np.log(u1))
+        ang = np.float32(6.28318530717958647692) * u2
+        out[:, 2 * h] = rad * np.cos(ang)
+        out[:, 2 * h + 1] = rad * np.sin(ang)
+    return out.reshape(-1)[:n]

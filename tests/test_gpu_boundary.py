@@ -199,3 +199,97 @@ def test_vocos_needs_two_frames_like_reflection_pad():
     z2 = torch.randn(1, cfg.inter_channels, 2, device="cuda")
     out = net.hifigan(z2, None if net.n_speakers == 0 else torch.zeros(1, net.gin_channels, device="cuda"))
     assert out.shape == (1, 1, 2 * net.hop_length) and torch.isfinite(out).all()
+
+
+def test_status_word_domain_and_id_range_errors():
+    """Errors the reference raises from inside its modules come back through the device status
+    word with the ONE host sync of infer(): a NaN in the spline parameters fails
+    `assert (discriminant >= 0).all()` (transforms.py:171) => AssertionError in the Python twin,
+    WETTS_E_DOMAIN (-4) from wetts_infer; an id outside the embedding table is nn.Embedding's
+    IndexError => IndexError / WETTS_E_INVALID (-1)."""
+    from wetts_amd import SynthesizerTrn, _lib, config
+    case = util.load_case("tiny_sdp_b3")
+    cfg, sd, W, _ = util.case_model(case)
+    lib = _lib.load()
+
+    def native(net, x, xl, sid):
+        B, Tx = x.shape
+        cap = 200
+        nws = lib.wetts_infer_workspace_bytes(net._handle, B, Tx, cap)
+        ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+        audio = torch.zeros(B * cap * net.hop_length, dtype=torch.float32, device="cuda")
+        ylen = np.zeros(B, np.int64)
+        frames = C.c_int32()
+        # eps_w / eps_z = NULL: drawn by the library's Philox stream
+        rc = lib.wetts_infer(net._handle, _lib.ptr(x), _lib.ptr(xl), _lib.ptr(sid), None, None,
+                             0.667, 1.0, 0.8, B, Tx, cap, _lib.ptr(audio),
+                             ylen.ctypes.data_as(C.c_void_p), C.byref(frames), _lib.ptr(ws), nws,
+                             _lib.current_stream_ptr())
+        torch.cuda.synchronize()
+        return rc, frames.value, ylen
+
+    x = util.t(case["x"]).cuda()
+    xl = util.t(case["x_lengths"]).cuda()
+    sid = util.t(case["sid"]).cuda()
+    mk = lambda state: SynthesizerTrn(int(case["n_vocab"]), 513, 32, n_speakers=int(case["n_speakers"]),
+                                      **config.MODEL_CONFIGS[str(case["model"])]).load_state_dict(state).to("cuda")
+    # healthy model: native call with internal noise succeeds, deterministic under the seed
+    net = mk(sd)
+    lib.wetts_set_seed(net._handle, 77)
+    rc, fr, yl = native(net, x, xl, sid)
+    assert rc == 0 and fr == int(yl.max()) and (yl >= 1).all()
+    lib.wetts_set_seed(net._handle, 77)
+    rc2, fr2, yl2 = native(net, x, xl, sid)
+    assert rc2 == 0 and fr2 == fr and yl2.tolist() == yl.tolist()
+    # phoneme id out of range
+    xb = x.clone()
+    xb[0, 1] = int(case["n_vocab"])
+    with pytest.raises(IndexError):
+        net.infer(xb, xl, sid=sid)
+    rc, _, _ = native(net, xb, xl, sid)
+    assert rc == -1 and "phoneme" in _lib.last_error()
+    # speaker id out of range
+    sb = sid.clone()
+    sb[2] = int(case["n_speakers"]) + 3
+    with pytest.raises(IndexError):
+        net.infer(x, xl, sid=sb)
+    rc, _, _ = native(net, x, xl, sb)
+    assert rc == -1 and "speaker" in _lib.last_error()
+    # the model is still usable afterwards
+    o, *_ = net.infer(x, xl, sid=sid)
+    assert torch.isfinite(o).all()
+    # spline domain: NaN spline parameters (the last ConvFlow's projection bias)
+    bad = dict(sd)
+    key = [k for k in bad if k.startswith("dp.flows.") and k.endswith(".proj.bias")][-1]
+    bad[key] = torch.full_like(bad[key], float("nan"))
+    netb = mk(bad)
+    with pytest.raises(AssertionError):
+        netb.infer(x, xl, sid=sid)
+    rc, _, _ = native(netb, x, xl, sid)
+    assert rc == -4 and "discriminant" in _lib.last_error()
+
+
+def test_randn_kernel_is_philox_box_muller():
+    """wetts_randn against the CPU restatement (oracle.philox_randn, itself pinned to the Random123
+    known-answer vectors in the CPU tier): same uint32 stream, float32 Box-Muller within libm
+    round-off; offsets address the stream; moments of a large draw are standard normal."""
+    from oracle import vits_oracle as vo
+    from wetts_amd import _lib
+    lib = _lib.load()
+    n = 100003
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    _lib.check(lib.wetts_randn(_lib.ptr(out), n, 0x123456789ABCDEF, 5, None), "randn")
+    torch.cuda.synchronize()
+    ref = vo.philox_randn(n, 0x123456789ABCDEF, 5)
+    got = out.cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-5
+    # offset semantics: a draw at offset 5 + 10 equals the tail of the draw at offset 5
+    out2 = torch.empty(1000, dtype=torch.float32, device="cuda")
+    _lib.check(lib.wetts_randn(_lib.ptr(out2), 1000, 0x123456789ABCDEF, 15, None), "randn")
+    assert torch.equal(out2.cpu(), out[40:1040].cpu())
+    big = torch.empty(1 << 22, dtype=torch.float32, device="cuda")
+    _lib.check(lib.wetts_randn(_lib.ptr(big), big.numel(), 42, 0, None), "randn")
+    b = big.double()
+    m, v = float(b.mean()), float(b.var())
+    kurt = float(((b - m) ** 4).mean() / v ** 2)
+    assert abs(m) < 3e-3 and abs(v - 1) < 5e-3 and abs(kurt - 3) < 3e-2 and torch.isfinite(big).all()

@@ -108,3 +108,19 @@ def test_mas_c_oracle_known_answers_and_numpy_twin():
     t_y = np.array([60, 41, 33], np.int32)
     t_x = np.array([17, 9, 17], np.int32)
     assert np.array_equal(run(neg, t_y, t_x), vo.maximum_path_numpy(neg, t_y, t_x))
+
+
+def test_philox_oracle_matches_random123_known_answers():
+    """The counter RNG behind the library's noise kernel: the three Philox4x32-10 known-answer
+    vectors published with Random123 (kat_vectors), through the numpy restatement the GPU test
+    compares the kernel with."""
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for c, k, want in kat:
+        got = vo.philox4x32_10(np.array([c], dtype=np.uint32), np.array([k], dtype=np.uint32))[0]
+        assert [int(v) for v in got] == want
+    x = vo.philox_randn(200000, 9, 3)
+    assert abs(float(x.mean())) < 1e-2 and abs(float(x.std()) - 1) < 1e-2
+    assert np.array_equal(vo.philox_randn(64, 9, 5), vo.philox_randn(72, 9, 3)[8:])
