@@ -288,19 +288,6 @@ int32_t wetts_set_mrf_timing(const wetts_model_t* m, int32_t enable);
 int32_t wetts_read_mrf_timing(const wetts_model_t* m, double* mrf_ms, int64_t* conv_launches,
                               int32_t* hifigan_calls);
 
-/* Micro-benchmark of one Conv1d(Cin->Cout, k, dilation) on [B,Cin,T] with pseudo-random data
- * (allocates its own buffers; a measurement helper, not on the product path).
- * flags: 1 = leaky-relu prologue, 2 = residual add, 4 = accumulate into the output.
- * variant selects the kernel family (0 single-role, 1 wave-specialised). */
-int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int32_t B, int32_t T,
-                         int32_t flags, int32_t variant, int32_t iters, double* ms_out,
-                         double* checksum_out);
-int32_t wetts_set_conv_variant(int32_t variant);
-/* Calibration: sustained v_mfma_f32_32x32x2_f32 rate with `blocks_per_cu` 4-wave blocks per CU
- * and `nacc` (1,2,4) independent accumulators per wave, no memory traffic. */
-int32_t wetts_bench_mfma_peak(int32_t blocks_per_cu, int32_t nacc, int32_t iters, double* tflops,
-                              double* ms);
-
 /* Times `iters` launches of the dominant MRF conv kernel class (all ResBlock convs of the
  * decoder) with HIP events on `stream`; returns total ms and the number of conv launches.
  * Used by bench.py for roofline.achieved. */

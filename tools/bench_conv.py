@@ -18,9 +18,11 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import benchlib  # noqa: E402
 from wetts_amd import _lib  # noqa: E402
 
-lib = _lib.load()
+lib = benchlib.load()
 B, Ty = 16, 864
 variants = [int(v, 0) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,1").split(",")]
 shapes = []

@@ -2,8 +2,9 @@
 """Sustained f32-MFMA rate calibration (GPU box only)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from wetts_amd import _lib
-lib = _lib.load()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import benchlib
+lib = benchlib.load()
 def run(bpc, nacc, iters, note=""):
     tf, ms = C.c_double(), C.c_double()
     lib.wetts_bench_mfma_peak(bpc, nacc, iters, C.byref(tf), C.byref(ms))

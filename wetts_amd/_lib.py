@@ -107,11 +107,6 @@ SIGNATURES = {
                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "wetts_set_mrf_timing": (_I32, [_P, _I32]),
     "wetts_read_mrf_timing": (_I32, [_P, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I32)]),
-    "wetts_bench_conv": (_I32, [_I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
-                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "wetts_set_conv_variant": (_I32, [_I32]),
-    "wetts_bench_mfma_peak": (_I32, [_I32, _I32, _I32, C.POINTER(C.c_double),
-                                     C.POINTER(C.c_double)]),
     "wetts_profile_hifigan": (_I32, [_P, _P, _I64, _I64, _P, _I32, _I32, _P, _P, _I64, _P,
                                      C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(_I32)]),

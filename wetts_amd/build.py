@@ -9,8 +9,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libwetts_hip.so")
-SOURCES = ["conv_mfma.hip", "conv_bf16.hip", "resblock16.hip", "resblock32.hip", "kernels.hip", "attention.hip", "mas.hip", "model.hip", "bench_conv.hip"]
-HEADERS = ["common.h", "kernels.h", "conv_bf16.h", "conv16_dev.h", "resblock32.h", os.path.join("..", "..", "include", "wetts_hip.h"),
+SOURCES = ["conv_mfma.hip", "conv_bf16.hip", "resblock16.hip", "resblock32.hip", "kernels.hip", "attention.hip", "mas.hip", "model.hip"]
+# measurement tooling (tools/bench_*.py): its own library, linked against the product one
+BENCH_SOURCES = ["bench_conv.hip"]
+BENCH_LIB = os.path.join(LIBDIR, "libwetts_bench.so")
+HEADERS = ["bench_abi.h", "common.h", "kernels.h", "conv_bf16.h", "conv16_dev.h", "resblock32.h", os.path.join("..", "..", "include", "wetts_hip.h"),
            os.path.join("..", "..", "include", "wetts_vits_model.hpp"),
            os.path.join("..", "..", "tests", "native", "vits_model_main.cpp")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -25,7 +28,7 @@ def _hipcc():
 
 def _digest():
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS:
+    for f in SOURCES + BENCH_SOURCES + HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
@@ -43,7 +46,7 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     objs = []
     procs = []
-    for src in SOURCES:
+    for src in SOURCES + BENCH_SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
@@ -60,10 +63,14 @@ def build(force=False, verbose=True):
             sys.stderr.write(out.decode(errors="replace") if not verbose else "")
     if failed:
         raise RuntimeError("hipcc failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print("[wetts_amd.build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    bench_objs = objs[len(SOURCES):]
+    objs = objs[:len(SOURCES)]
+    for lib, obs, extra in ((LIB, objs, []),
+                            (BENCH_LIB, bench_objs, ["-L", LIBDIR, "-lwetts_hip", "-Wl,-rpath,$ORIGIN"])):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + obs + extra
+        if verbose:
+            print("[wetts_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     # native C++ host used by tests/test_gpu_native.py (twin of the reference's VitsModel class)
     native_src = os.path.join(HERE, "..", "tests", "native", "vits_model_main.cpp")
     if os.path.exists(native_src):

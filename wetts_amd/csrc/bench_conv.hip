@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/wetts_hip.h"
+#include "bench_abi.h"
 #include "common.h"
 #include "conv_bf16.h"
 #include "resblock32.h"
@@ -223,18 +224,20 @@ int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int3
         return launch_resblock_pair32(pc, pc2, pp, s);
       }
       ConvParams p1 = conv_io(x, Cin, T, ft, Cout, B);
-      p1.in_act = IN_LRELU; p1.in_slope = 0.1f;
+      p1.in_act = IN_LRELU; p1.in_slope = 0.1f; p1.tag = 1;
       if (rb2) { p1.res = x; p1.r_bs = (int64_t)Cout * T; p1.r_cs = T; }
       int32_t rc1 = launch_conv(pc, p1, s);
       if (rc1 != WETTS_OK) return rc1;
       ConvParams p2 = conv_io(ft, Cin, T, o, Cout, B);
-      p2.in_act = IN_LRELU; p2.in_slope = 0.1f;
+      p2.in_act = IN_LRELU; p2.in_slope = 0.1f; p2.tag = 1;
       p2.res = rb2 ? ft : x; p2.r_bs = (int64_t)Cout * T; p2.r_cs = T;
       p2.accum = (flags & 4) ? 1 : 0;
       p2.out_div = (flags & 8) ? 3.f : 1.f;
       return launch_conv(pc2, p2, s);
     };
     int32_t rc = WETTS_OK;
+    const int saved_variant = conv_variant();
+    set_conv_variant(0);
     for (int i = 0; i < 2 && rc == WETTS_OK; ++i) rc = run();
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
@@ -255,6 +258,7 @@ int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int3
       for (size_t i = 0; i < host.size(); ++i) hsh = (hsh ^ host[i]) * 1099511628211ull;
       *checksum_out = (double)(hsh >> 12);
     }
+    set_conv_variant(saved_variant);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     free_packed(&pc);
@@ -267,6 +271,7 @@ int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int3
   if (flags & 1) { p.in_act = IN_LRELU; p.in_slope = 0.1f; }
   if (flags & 2) { p.res = r; p.r_bs = (int64_t)Cout * T; p.r_cs = T; }
   if (flags & 4) { p.accum = 1; }
+  p.tag = 1;  // the MRF launch class (own kernel symbol)
   const int saved = conv_variant();
   set_conv_variant(variant & 0xff);
   p.ablate = variant >> 8;
@@ -296,6 +301,497 @@ int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int3
   free_packed(&pc);
   (void)hipFree(x); (void)hipFree(o); (void)hipFree(r); (void)hipFree(w); (void)hipFree(bias);
   return rc;
+}
+
+}  // extern "C"
+
+namespace wetts {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// ------------------------------------------------------------------------------------------
+// calibration: sustained rate of v_mfma_f32_32x32x2_f32 on this chip (no memory traffic)
+// ------------------------------------------------------------------------------------------
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, float a0, float b0) {
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a = a0 + (threadIdx.x & 7) * 1e-3f, b = b0 + (threadIdx.x & 3) * 1e-3f;
+  if (a0 < 0.f) {
+    // random-operand mode: 8 distinct pseudo-random A and B registers per lane (data toggling
+    // like a real conv), products have random sign so the accumulators random-walk
+    float ar[8], br[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      unsigned h = (threadIdx.x * 8 + u + blockIdx.x * 2048) * 2654435761u;
+      h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+      ar[u] = ((float)(h & 0xffff) / 32768.f - 1.f);
+      br[u] = ((float)((h >> 16) & 0xffff) / 32768.f - 1.f);
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[u], br[(u + i) & 7], acc[i], 0, 0, 0);
+      }
+    }
+  } else {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+      }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+int32_t bench_mfma_peak(int blocks_per_cu, int nacc, int iters, double* tflops, double* ms_out) {
+  const float a0 = nacc < 0 ? -1.f : 1.f;
+  nacc = nacc < 0 ? -nacc : nacc;
+  float* out = nullptr;
+  WETTS_HIP_CHECK(hipMalloc((void**)&out, 4096));
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const int grid = blocks_per_cu >= 1000 ? blocks_per_cu : 256 * blocks_per_cu;
+  auto launch = [&]() {
+    if (nacc == 1) hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(grid), dim3(256), 0, 0, out, iters, a0, 1.f);
+    else if (nacc == 2) hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(grid), dim3(256), 0, 0, out, iters, a0, 1.f);
+    else hipLaunchKernelGGL(mfma_peak_kernel<4>, dim3(grid), dim3(256), 0, 0, out, iters, a0, 1.f);
+  };
+  launch();
+  (void)hipEventRecord(e0, 0);
+  launch();
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const int na = nacc >= 4 ? 4 : nacc;
+  double flops = (double)grid * 4 /*waves*/ * (double)iters * 8 * na * 4096.0;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  *ms_out = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(out);
+  return WETTS_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// f32 matrix pipe + f32 vector pipe side by side
+// ------------------------------------------------------------------------------------------
+#define WETTS_VFMA(c, a, b) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+
+template <int NV>
+__global__ __launch_bounds__(256) void mfma_valu_interleaved_kernel(float* out, int iters, float a0) {
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float va[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) va[u] = 0.f;
+  const float a = a0 + (threadIdx.x & 7) * 1e-3f, b = 1.f + (threadIdx.x & 3) * 1e-3f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) WETTS_VFMA(va[(v + i) & 7], a, b);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s += va[u];
+  if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+// waves 0..3: MFMA only; waves 4..7: VALU only (nv FMAs per MFMA of the sibling wave)
+__global__ __launch_bounds__(512) void mfma_valu_split_kernel(float* out, int iters, int nv, float a0) {
+  const int wave = threadIdx.x >> 6;
+  const float a = a0 + (threadIdx.x & 7) * 1e-3f, b = 1.f + (threadIdx.x & 3) * 1e-3f;
+  float s = 0.f;
+  if (wave < 4) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][r];
+  } else {
+    float va[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) va[u] = 0.f;
+    const int n = iters * 2 * nv;  // 32 MFMAs per iteration on the sibling; 16 FMAs per inner pass
+    for (int it = 0; it < n; ++it) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) WETTS_VFMA(va[u], a, b);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += va[u];
+  }
+  if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// what does each ingredient of the conv inner loop cost the f32 MFMA stream?
+// MODE bits: 1 = B fragments from LDS (else constants in registers), 2 = A fragments streamed from
+// global / L2 (1 KB per wave per 16 MFMAs, else constants), 4 = __syncthreads() every 6 groups,
+// 8 = B reads software-pipelined one k-step ahead with sched_barriers (else: as the compiler places them),
+// 16 = 64 VALU instructions (v_fma) per group of 16 MFMAs (a stand-in for staging / epilogue ALU work)
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void mfma_loop_kernel(const float4* __restrict__ A, float* out,
+                                                        int groups, int iters, int Wp) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 32 * Wp; i += 256) sm[i] = (float)(i & 255) * 1e-3f;
+  __syncthreads();
+  const float* bcol = sm + (size_t)(lane >> 5) * Wp + wave * 128 + (lane & 31);
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const float4* ab = A + lane;
+  float va[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) va[u] = 0.f;
+  const float c0 = 1.f + (tid & 7) * 1e-3f;
+  for (int it = 0; it < iters; ++it) {
+    float4 aa[2];
+    aa[0] = (MODE & 2) ? ab[0] : make_float4(c0, c0 + 1e-3f, c0 + 2e-3f, c0 + 3e-3f);
+    aa[1] = (MODE & 2) ? ab[64] : aa[0];
+    float bv[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[0][j] = (MODE & 1) ? bcol[32 * j] : 0.5f + 1e-3f * j;
+    auto group = [&](float4& areg, const float4* anext, const float* cur, const float* nxt) {
+      const float4 av = areg;
+      if (MODE & 2) areg = *anext;
+      if (MODE & 8) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float a = s == 0 ? av.x : s == 1 ? av.y : s == 2 ? av.z : av.w;
+        if (MODE & 8) {
+          const float* src = s < 3 ? cur + (size_t)(2 * (s + 1)) * Wp : nxt;
+          if (MODE & 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[(s + 1) & 1][j] = src[32 * j];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[(MODE & 1) ? (s & 1) : 0][j], acc[j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          const float* src = cur + (size_t)(2 * s) * Wp;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float b = (MODE & 1) ? src[32 * j] : bv[0][j];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+          }
+        }
+        if (MODE & 16) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) WETTS_VFMA(va[u & 7], a, c0);
+        }
+      }
+    };
+    for (int g = 0; g < groups; g += 2) {
+      const int tap = (g >> 1) % 3, chunk = (g >> 1) / 3;
+      const float* r0 = bcol + (size_t)((chunk & 1) * 16) * Wp + tap;
+      const float* r1 = r0 + (size_t)8 * Wp;
+      group(aa[0], ab + (int64_t)(g + 2) * 64, r0, r1);
+      group(aa[1], ab + (int64_t)(g + 3) * 64, r1, r0 + 1);
+      if ((MODE & 4) && (g % 6) == 4) __syncthreads();
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[j][r];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s += va[u];
+  if (s == 12345.678f) out[tid] = s;
+}
+
+// Second decomposition: wave tile shape and operand paths.
+//   MB x NB 32x32 accumulators per wave; BM: 0 constants, 1 ds_read_b32 from [ch][col] rows (today's
+//   layout), 2 ds_read_b128 from a [col][16 ch + 4 pad] image (4 k-steps per read); AM: 0 constants,
+//   1 global_load_dwordx4 per m-block per group (today), 2 ds_read_b128 from LDS (A staged by someone
+//   else).  B reads are pipelined one k-step (BM 1) / one group (BM 2) ahead.
+template <int MB, int NB, int BM, int AM>
+__global__ __launch_bounds__(256) void mfma_loop2_kernel(const float4* __restrict__ A, float* out,
+                                                         int groups, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int Wp = 516;            // BM 1 row stride (floats)
+  constexpr int CS = 20;             // BM 2 column stride (floats): 16 channels + 4 pad
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 32 * Wp; i += 256) sm[i] = (float)(i & 255) * 1e-3f;
+  __syncthreads();
+  const int half = lane >> 5, l31 = lane & 31;
+  const float* b1 = sm + (size_t)half * Wp + (wave & 1) * (32 * NB) + l31;
+  const float* b2 = sm + (size_t)((wave & 1) * (32 * NB) + l31) * CS + half * 4;
+  const float4* alds = reinterpret_cast<const float4*>(sm) + lane;
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const float4* ab = A + lane;
+  const float c0 = 1.f + (tid & 7) * 1e-3f;
+  auto loadA = [&](int g, int i) -> float4 {
+    if (AM == 1) return ab[(int64_t)(g * MB + i) * 64];
+    if (AM == 2) return alds[((g * MB + i) & 31) * 64];
+    return make_float4(c0, c0 + 1e-3f, c0 + 2e-3f, c0 + 3e-3f);
+  };
+  for (int it = 0; it < iters; ++it) {
+    float4 aa[2][MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) { aa[0][i] = loadA(0, i); aa[1][i] = loadA(1, i); }
+    if (BM == 2) {
+      float4 bq[2][NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bq[0][j] = *reinterpret_cast<const float4*>(b2 + (size_t)(32 * j) * CS);
+      auto group = [&](int par, int g) {
+        float4 av[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) { av[i] = aa[par][i]; aa[par][i] = loadA(g + 2, i); }
+        const float* nx = b2 + ((g + 1) % 3) * CS + (((g + 1) / 3) & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) bq[par ^ 1][j] = *reinterpret_cast<const float4*>(nx + (size_t)(32 * j) * CS);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int i = 0; i < MB; ++i) {
+            const float a = s == 0 ? av[i].x : s == 1 ? av[i].y : s == 2 ? av[i].z : av[i].w;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+              const float4 q = bq[par][j];
+              const float b = s == 0 ? q.x : s == 1 ? q.y : s == 2 ? q.z : q.w;
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      for (int g = 0; g < groups; g += 2) { group(0, g); group(1, g + 1); }
+    } else {
+      float bv[2][NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bv[0][j] = BM ? b1[32 * j] : 0.5f + 1e-3f * j;
+      auto group = [&](int par, int g) {
+        float4 av[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) { av[i] = aa[par][i]; aa[par][i] = loadA(g + 2, i); }
+        const float* cur = b1 + (size_t)((g & 1) * 8 + ((g >> 1) & 1) * 16) * Wp + (g % 3);
+        const float* nxt = b1 + (size_t)(((g + 1) & 1) * 8) * Wp + ((g + 1) % 3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (BM) {
+            const float* src = s < 3 ? cur + (size_t)(2 * (s + 1)) * Wp : nxt;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bv[(s + 1) & 1][j] = src[32 * j];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < MB; ++i) {
+            const float a = s == 0 ? av[i].x : s == 1 ? av[i].y : s == 2 ? av[i].z : av[i].w;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[BM ? (s & 1) : 0][j], acc[i][j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      for (int g = 0; g < groups; g += 2) { group(0, g); group(1, g + 1); }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (s == 12345.678f) out[tid] = s;
+}
+}  // namespace wetts
+
+extern "C" {
+
+// cfg = MB*1000 + NB*100 + BM*10 + AM
+int32_t wetts_bench_mfma_loop2(int32_t cfg, int32_t lds_kb, int32_t groups, int32_t iters,
+                               double* tflops, double* ms_out) {
+  WETTS_REQUIRE(tflops && ms_out && groups > 0 && (groups & 1) == 0 && iters > 0, "bad argument");
+  float4* A = nullptr;
+  float* out = nullptr;
+  const size_t abytes = (size_t)(groups + 4) * 2 * 64 * sizeof(float4);
+  WETTS_HIP_CHECK(hipMalloc((void**)&A, abytes));
+  WETTS_HIP_CHECK(hipMemset(A, 0, abytes));
+  WETTS_HIP_CHECK(hipMalloc((void**)&out, 4096));
+  const size_t lds = (size_t)lds_kb * 1024 > (size_t)32 * 516 * 4 ? (size_t)lds_kb * 1024 : (size_t)32 * 516 * 4;
+  int per_cu = (int)(160 * 1024 / lds);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+  const int grid = 256 * per_cu;
+  const int MBv = cfg / 1000, NBv = (cfg / 100) % 10;
+  bool ok = true;
+#define WETTS_L2(MB_, NB_, BM_, AM_)                                                                  \
+  if (cfg == MB_ * 1000 + NB_ * 100 + BM_ * 10 + AM_) {                                               \
+    (void)hipFuncSetAttribute((const void*)mfma_loop2_kernel<MB_, NB_, BM_, AM_>,                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
+    hipLaunchKernelGGL((mfma_loop2_kernel<MB_, NB_, BM_, AM_>), dim3(grid), dim3(256), lds, 0, A, out, \
+                       groups, iters);                                                                 \
+    return;                                                                                            \
+  }
+  auto launch = [&]() {
+    WETTS_L2(1, 4, 0, 0) WETTS_L2(1, 4, 1, 0) WETTS_L2(1, 4, 2, 0) WETTS_L2(1, 4, 1, 1) WETTS_L2(1, 4, 2, 1)
+    WETTS_L2(1, 4, 1, 2) WETTS_L2(1, 4, 2, 2) WETTS_L2(2, 4, 0, 0) WETTS_L2(2, 4, 1, 0) WETTS_L2(2, 4, 2, 0)
+    WETTS_L2(2, 4, 1, 1) WETTS_L2(2, 4, 2, 1) WETTS_L2(2, 4, 2, 2) WETTS_L2(2, 2, 2, 1) WETTS_L2(2, 2, 1, 1)
+    WETTS_L2(1, 8, 2, 1) WETTS_L2(1, 8, 1, 1) WETTS_L2(1, 8, 0, 0)
+    ok = false;
+  };
+  launch();
+  WETTS_REQUIRE(ok, "unknown loop2 configuration %d", cfg);
+  WETTS_LAUNCH_CHECK();
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, 0);
+  launch();
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *tflops = (double)grid * 4 * (double)iters * groups * 16 * MBv * (NBv / 4.0) * 4096.0 / (ms * 1e-3) / 1e12;
+  *ms_out = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(A);
+  (void)hipFree(out);
+  return WETTS_OK;
+}
+
+int32_t wetts_bench_mfma_loop(int32_t mode, int32_t lds_kb, int32_t groups, int32_t iters,
+                              double* tflops, double* ms_out) {
+  WETTS_REQUIRE(tflops && ms_out && groups > 0 && (groups & 1) == 0 && iters > 0, "bad argument");
+  float4* A = nullptr;
+  float* out = nullptr;
+  const size_t abytes = (size_t)(groups + 4) * 64 * sizeof(float4);
+  WETTS_HIP_CHECK(hipMalloc((void**)&A, abytes));
+  WETTS_HIP_CHECK(hipMemset(A, 0, abytes));
+  WETTS_HIP_CHECK(hipMalloc((void**)&out, 4096));
+  const int Wp = 516;
+  const size_t lds = (size_t)lds_kb * 1024 > (size_t)32 * Wp * 4 ? (size_t)lds_kb * 1024 : (size_t)32 * Wp * 4;
+  const int per_cu = (int)(160 * 1024 / lds) > 0 ? (int)(160 * 1024 / lds) : 1;
+  const int grid = 256 * (per_cu > 4 ? 4 : per_cu);  // one resident wave of blocks
+#define WETTS_LOOP_CASE(M)                                                                          \
+  case M:                                                                                           \
+    (void)hipFuncSetAttribute((const void*)mfma_loop_kernel<M>,                                     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
+    hipLaunchKernelGGL(mfma_loop_kernel<M>, dim3(grid), dim3(256), lds, 0, A, out, groups, iters, Wp); \
+    break;
+  auto launch = [&]() {
+    switch (mode) {
+      WETTS_LOOP_CASE(0) WETTS_LOOP_CASE(1) WETTS_LOOP_CASE(9) WETTS_LOOP_CASE(2) WETTS_LOOP_CASE(3)
+      WETTS_LOOP_CASE(11) WETTS_LOOP_CASE(15) WETTS_LOOP_CASE(7) WETTS_LOOP_CASE(16) WETTS_LOOP_CASE(27)
+      WETTS_LOOP_CASE(4) WETTS_LOOP_CASE(13)
+      default: break;
+    }
+  };
+  launch();
+  WETTS_LAUNCH_CHECK();
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, 0);
+  launch();
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *tflops = (double)grid * 4 * (double)iters * groups * 16 * 4096.0 / (ms * 1e-3) / 1e12;
+  *ms_out = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(A);
+  (void)hipFree(out);
+  return WETTS_OK;
+}
+
+int32_t wetts_bench_mfma_valu(int32_t mode, int32_t nv, int32_t iters, double* tflops_mfma,
+                              double* tflops_valu, double* ms_out) {
+  WETTS_REQUIRE(tflops_mfma && tflops_valu && ms_out && iters > 0 && nv >= 0, "bad argument");
+  float* out = nullptr;
+  WETTS_HIP_CHECK(hipMalloc((void**)&out, 4096));
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const int grid = 256 * 2;
+  auto launch = [&]() {
+    if (mode == 1) {
+      hipLaunchKernelGGL(mfma_valu_split_kernel, dim3(grid), dim3(512), 0, 0, out, iters, nv, 1.f);
+      return;
+    }
+    switch (nv) {
+      case 0: hipLaunchKernelGGL(mfma_valu_interleaved_kernel<0>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f); break;
+      case 2: hipLaunchKernelGGL(mfma_valu_interleaved_kernel<2>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f); break;
+      case 4: hipLaunchKernelGGL(mfma_valu_interleaved_kernel<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f); break;
+      case 8: hipLaunchKernelGGL(mfma_valu_interleaved_kernel<8>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f); break;
+      case 12: hipLaunchKernelGGL(mfma_valu_interleaved_kernel<12>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f); break;
+      default: hipLaunchKernelGGL(mfma_valu_interleaved_kernel<16>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f); break;
+    }
+  };
+  launch();
+  (void)hipEventRecord(e0, 0);
+  launch();
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const double n_mfma = (double)grid * 4 * (double)iters * 32;  // per MFMA wave: 32 per iteration
+  const int nvi = (mode == 1 || nv == 0 || nv == 2 || nv == 4 || nv == 8 || nv == 12) ? nv : 16;
+  *tflops_mfma = n_mfma * 4096.0 / (ms * 1e-3) / 1e12;
+  *tflops_valu = n_mfma * nvi * 128.0 / (ms * 1e-3) / 1e12;
+  *ms_out = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(out);
+  return WETTS_OK;
 }
 
 int32_t wetts_bench_mfma_peak(int32_t blocks_per_cu, int32_t nacc, int32_t iters, double* tflops,

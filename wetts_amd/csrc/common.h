@@ -141,7 +141,6 @@ void free_packed(PackedConv* pc);
 // Launches the conv.  Fills geometry fields of `p` from `pc`; caller fills the I/O fields.
 int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream);
 
-int32_t bench_mfma_peak(int blocks_per_cu, int nacc, int iters, double* tflops, double* ms_out);
 int conv_variant();
 void set_conv_variant(int v);
 

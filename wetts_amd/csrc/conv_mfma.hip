@@ -520,85 +520,6 @@ void conv_mfma_kernel(const ConvParams p) {
 }
 
 
-// ------------------------------------------------------------------------------------------
-// calibration: sustained rate of v_mfma_f32_32x32x2_f32 on this chip (no memory traffic)
-// ------------------------------------------------------------------------------------------
-template <int NACC>
-__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, float a0, float b0) {
-  f32x16 acc[NACC];
-#pragma unroll
-  for (int i = 0; i < NACC; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  float a = a0 + (threadIdx.x & 7) * 1e-3f, b = b0 + (threadIdx.x & 3) * 1e-3f;
-  if (a0 < 0.f) {
-    // random-operand mode: 8 distinct pseudo-random A and B registers per lane (data toggling
-    // like a real conv), products have random sign so the accumulators random-walk
-    float ar[8], br[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      unsigned h = (threadIdx.x * 8 + u + blockIdx.x * 2048) * 2654435761u;
-      h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-      ar[u] = ((float)(h & 0xffff) / 32768.f - 1.f);
-      br[u] = ((float)((h >> 16) & 0xffff) / 32768.f - 1.f);
-    }
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-#pragma unroll
-        for (int i = 0; i < NACC; ++i)
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[u], br[(u + i) & 7], acc[i], 0, 0, 0);
-      }
-    }
-  } else {
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-#pragma unroll
-        for (int i = 0; i < NACC; ++i)
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
-      }
-    }
-  }
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < NACC; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s += acc[i][r];
-  if (s == 12345.678f) out[threadIdx.x] = s;
-}
-
-int32_t bench_mfma_peak(int blocks_per_cu, int nacc, int iters, double* tflops, double* ms_out) {
-  const float a0 = nacc < 0 ? -1.f : 1.f;
-  nacc = nacc < 0 ? -nacc : nacc;
-  float* out = nullptr;
-  WETTS_HIP_CHECK(hipMalloc((void**)&out, 4096));
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
-  const int grid = blocks_per_cu >= 1000 ? blocks_per_cu : 256 * blocks_per_cu;
-  auto launch = [&]() {
-    if (nacc == 1) hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(grid), dim3(256), 0, 0, out, iters, a0, 1.f);
-    else if (nacc == 2) hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(grid), dim3(256), 0, 0, out, iters, a0, 1.f);
-    else hipLaunchKernelGGL(mfma_peak_kernel<4>, dim3(grid), dim3(256), 0, 0, out, iters, a0, 1.f);
-  };
-  launch();
-  (void)hipEventRecord(e0, 0);
-  launch();
-  (void)hipEventRecord(e1, 0);
-  (void)hipEventSynchronize(e1);
-  float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, e0, e1);
-  const int na = nacc >= 4 ? 4 : nacc;
-  double flops = (double)grid * 4 /*waves*/ * (double)iters * 8 * na * 4096.0;
-  *tflops = flops / (ms * 1e-3) / 1e12;
-  *ms_out = ms;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipFree(out);
-  return WETTS_OK;
-}
-
 static int g_conv_variant = -1;  // -1: read WETTS_CONV_VARIANT once; 0 single-role, 1 wave-specialised
 
 int conv_variant() {

@@ -74,9 +74,9 @@ void resblock_pair32_kernel(const ResPair32Params p) {
   const int G = NCH * p.ktaps * 2;
   const float4* abase1 = reinterpret_cast<const float4*>(p.wpk1) + ((int64_t)wm * G) * 64 + lane;
   const float4* abase2 = reinterpret_cast<const float4*>(p.wpk2) + ((int64_t)wm * G) * 64 + lane;
-  float4 aa[2];
+  float4 aa[2];  // A fragments of the groups g (aa[g & 1]) and g + 1, prefetched two groups ahead
   aa[0] = abase1[0];
-  aa[1] = aa[0];
+  aa[1] = abase1[64];
 
   // Raw residual, requested first so that it is the oldest load in flight.  ResBlock1: x at c2's
   // output columns (time n0 + col), consumed after c1.  ResBlock2: x at c1's columns (time
@@ -160,32 +160,52 @@ void resblock_pair32_kernel(const ResPair32Params p) {
       for (int r = 0; r < 16; ++r) acc[j][r] = rres[j][r];
   }
 
-  // 16 MFMAs of one group: k-steps s = 0..3 are channels chunk*16 + hp*8 + 2s + half
-  auto mma_group = [&](const float4& av, int chunk, int tap, int hp, int dil) {
-    const float* brow = bcol + (size_t)(chunk * kConvCK + hp * 8) * Wp + tap * dil;
-    if (DBG && (ab & 16)) return;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float a = s == 0 ? av.x : s == 1 ? av.y : s == 2 ? av.z : av.w;
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[(size_t)(2 * s) * Wp + 32 * j], acc[j],
-                                                     0, 0, 0);
-    }
-  };
+  // One group = 16 MFMAs: k-steps s = 0..3 are channels chunk*16 + hp*8 + 2s + half, each feeding
+  // the NB column blocks.  The B fragments are software-pipelined ONE k-step ahead in registers
+  // (bv[parity][j]): without this the compiler places every ds_read directly in front of the MFMAs
+  // that use it (`ds_read2_b32; s_waitcnt lgkmcnt(0); 2 x v_mfma`), i.e. one exposed LDS round trip
+  // per 128 MFMA cycles -- at the two waves per SIMD this kernel's LDS tile allows, that alone held
+  // the MFMA + LDS part of a C = 32, k = 3 pair at 89 TF/s (profiles/r02_pair32_ablation.txt).
+  // sched_barriers pin the order: [A prefetch] [B reads of step s+1] [MFMAs of step s].
   // The A prefetch is issued unconditionally (group G exists: next m-block / zero tail of the
-  // packed buffer) and pinned a whole group ahead by sched_barriers, so the compiler's vmcnt waits
-  // are exact (a 4-slot ring with 3 groups of cover measured 2-4 % slower).
+  // packed buffer) a whole group ahead, so the compiler's vmcnt waits are exact (a 4-slot ring with
+  // 3 groups of cover measured 2-4 % slower).
   auto conv_loop = [&](const float4* abase, int dil) {
+    const int G = NCH * p.ktaps * 2;
+    float bv[2][NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bv[0][j] = bcol[32 * j];  // group 0, step 0 (chunk 0, tap 0, hp 0)
+    // one (chunk, tap) iteration = two groups (hp = 0, 1): aa[0] / aa[1] without dynamic indexing
+    auto group = [&](float4& areg, const float4* anext, const float* cur, const float* nxt) {
+      const float4 av = areg;
+      if (!(DBG && (ab & 4))) areg = *anext;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float* src = s < 3 ? cur + (size_t)(2 * (s + 1)) * Wp : nxt;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) bv[(s + 1) & 1][j] = src[32 * j];
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG && (ab & 16))) {
+          const float a = s == 0 ? av.x : s == 1 ? av.y : s == 2 ? av.z : av.w;
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[s & 1][j], acc[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
     int g = 0;
     for (int chunk = 0; chunk < NCH; ++chunk) {
       for (int tap = 0; tap < p.ktaps; ++tap) {
-        if (!(DBG && (ab & 4))) aa[1] = abase[(int64_t)(g + 1) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-        mma_group(aa[0], chunk, tap, 0, dil);
-        if (!(DBG && (ab & 4))) aa[0] = abase[(int64_t)(g + 2) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-        mma_group(aa[1], chunk, tap, 1, dil);
+        const float* r0 = bcol + (size_t)(chunk * kConvCK) * Wp + tap * dil;  // hp = 0 rows
+        const float* r1 = r0 + (size_t)8 * Wp;                                // hp = 1 rows
+        // first rows of the next (chunk, tap); the very last prefetch re-reads this group's rows
+        int ntap = tap + 1, nchunk = chunk;
+        if (ntap == p.ktaps) { ntap = 0; ++nchunk; }
+        const float* rn = (g + 2 < G) ? bcol + (size_t)(nchunk * kConvCK) * Wp + ntap * dil : r1;
+        group(aa[0], abase + (int64_t)(g + 2) * 64, r0, r1);
+        group(aa[1], abase + (int64_t)(g + 3) * 64, r1, rn);
         g += 2;
       }
     }
@@ -193,7 +213,8 @@ void resblock_pair32_kernel(const ResPair32Params p) {
 
   // ---- 2. c1 ---------------------------------------------------------------------------------
   conv_loop(abase1, p.dil);
-  aa[0] = abase2[0];  // c2's first group; lands during step 3
+  aa[0] = abase2[0];  // c2's first two groups; they land during step 3
+  aa[1] = abase2[64];
 
   // ---- 3. ft = lrelu(c1 + b1) over the x tile (zero outside [0,T): c2 pads ITS input) ---------
   {
