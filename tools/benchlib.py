@@ -17,6 +17,8 @@ def load():
     lib.wetts_bench_conv.restype = _I32
     lib.wetts_set_conv_variant.argtypes = [_I32]
     lib.wetts_bench_mfma_peak.argtypes = [_I32, _I32, _I32, _D, _D]
+    lib.wetts_bench_resblock.argtypes = [_I32] * 9 + [_D, _D]
+    lib.wetts_bench_resblock.restype = _I32
     lib.wetts_bench_mfma_loop.argtypes = [_I32, _I32, _I32, _I32, _D, _D]
     lib.wetts_bench_mfma_loop2.argtypes = [_I32, _I32, _I32, _I32, _D, _D]
     lib.wetts_bench_mfma_valu.argtypes = [_I32, _I32, _I32, _D, _D, _D]

@@ -14,6 +14,12 @@ int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int3
                          int32_t flags, int32_t variant, int32_t iters, double* ms_out,
                          double* checksum_out);
 int32_t wetts_set_conv_variant(int32_t variant);
+// ResBlock1 of `npairs` (c1 at dilation first_dil / 3 / 5, c2 at 1) pairs at f32.  mode 0: conv by
+// conv; 1: resblock_pair32_kernel per pair; 2: resblock_chain32_kernel per pair; 3: the chain kernel
+// once for all pairs.  flags: 4 accumulate into out, 8 divide by 3.  checksum = full-tensor hash.
+int32_t wetts_bench_resblock(int32_t C, int32_t k, int32_t npairs, int32_t first_dil, int32_t B,
+                             int32_t T, int32_t flags, int32_t mode, int32_t iters, double* ms_out,
+                             double* checksum_out);
 // Sustained v_mfma_f32_32x32x2_f32 rate with `blocks_per_cu` 4-wave blocks per CU (>= 1000: that
 // many blocks) and |nacc| (1,2,4) independent accumulators per wave (< 0: random operands).
 int32_t wetts_bench_mfma_peak(int32_t blocks_per_cu, int32_t nacc, int32_t iters, double* tflops,

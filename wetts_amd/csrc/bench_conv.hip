@@ -794,6 +794,141 @@ int32_t wetts_bench_mfma_valu(int32_t mode, int32_t nv, int32_t iters, double* t
   return WETTS_OK;
 }
 
+// ResBlock1 (k, dilations 1/3/5 in front of c1, c2 at 1) on [B,C,T], npairs = 1..3 pairs, at f32.
+// mode 0: conv by conv (2 launches per pair); 1: resblock_pair32_kernel per pair; 2: the chain kernel
+// per pair; 3: the chain kernel once for all pairs.  flags: 4 accumulate into out, 8 divide by 3.
+int32_t wetts_bench_resblock(int32_t C, int32_t k, int32_t npairs, int32_t first_dil, int32_t B, int32_t T,
+                             int32_t flags, int32_t mode, int32_t iters, double* ms_out,
+                             double* checksum_out) {
+  WETTS_REQUIRE(ms_out && C > 0 && k > 0 && npairs >= 1 && npairs <= 3 && B > 0 && T > 0 && iters > 0,
+                "bad argument");
+  hipStream_t s = nullptr;
+  const int64_t n = (int64_t)B * C * T, nw = (int64_t)C * C * k;
+  float *x = nullptr, *o = nullptr, *r = nullptr, *ft = nullptr, *pp[2] = {nullptr, nullptr};
+  float *w[6] = {}, *bias[6] = {};
+  WETTS_HIP_CHECK(hipMalloc((void**)&x, n * 4));
+  WETTS_HIP_CHECK(hipMalloc((void**)&o, n * 4));
+  WETTS_HIP_CHECK(hipMalloc((void**)&r, n * 4));
+  WETTS_HIP_CHECK(hipMalloc((void**)&ft, n * 4));
+  WETTS_HIP_CHECK(hipMalloc((void**)&pp[0], n * 4));
+  WETTS_HIP_CHECK(hipMalloc((void**)&pp[1], n * 4));
+  WETTS_TRY(fill_pseudo(x, n, 1, 1.f, s));
+  WETTS_TRY(fill_pseudo(r, n, 2, 1.f, s));
+  WETTS_HIP_CHECK(hipMemsetAsync(o, 0, n * 4, s));
+  PackedConv c1[3], c2[3];
+  const int dils[3] = {first_dil, first_dil == 1 ? 3 : first_dil, first_dil == 1 ? 5 : first_dil};
+  for (int i = 0; i < 2 * npairs; ++i) {
+    WETTS_HIP_CHECK(hipMalloc((void**)&w[i], nw * 4));
+    WETTS_HIP_CHECK(hipMalloc((void**)&bias[i], (int64_t)C * 4));
+    WETTS_TRY(fill_pseudo(w[i], nw, 10 + i, 0.5f / sqrtf((float)C * k), s));
+    WETTS_TRY(fill_pseudo(bias[i], C, 20 + i, 0.1f, s));
+    const int d = (i & 1) ? 1 : dils[i >> 1];
+    WETTS_TRY(pack_conv_weight(w[i], bias[i], C, C, k, d, (k - 1) / 2 * d, 0, 0, s,
+                               (i & 1) ? &c2[i >> 1] : &c1[i >> 1]));
+  }
+  const int accum = (flags & 4) ? 1 : 0;
+  const float odiv = (flags & 8) ? 3.f : 1.f;
+  auto run = [&]() -> int32_t {
+    if (mode == 3) {
+      ResChain32Params cp;
+      memset(&cp, 0, sizeof(cp));
+      cp.x = x; cp.out = o; cp.T = T; cp.B = B; cp.accum = accum; cp.out_div = odiv; cp.slope = 0.1f;
+      return launch_resblock_chain32(c1, c2, npairs, cp, s);
+    }
+    const float* cur = x;
+    for (int pr = 0; pr < npairs; ++pr) {
+      const bool last = pr == npairs - 1;
+      float* dst = last ? o : pp[pr & 1];
+      if (mode == 2) {
+        ResChain32Params cp;
+        memset(&cp, 0, sizeof(cp));
+        cp.x = cur; cp.out = dst; cp.T = T; cp.B = B; cp.accum = last ? accum : 0;
+        cp.out_div = last ? odiv : 1.f; cp.slope = 0.1f;
+        WETTS_TRY(launch_resblock_chain32(&c1[pr], &c2[pr], 1, cp, s));
+      } else if (mode == 1) {
+        ResPair32Params q;
+        memset(&q, 0, sizeof(q));
+        q.x = cur; q.out = dst; q.T = T; q.B = B; q.accum = last ? accum : 0;
+        q.out_div = last ? odiv : 1.f; q.slope = 0.1f;
+        WETTS_TRY(launch_resblock_pair32(c1[pr], c2[pr], q, s));
+      } else {
+        ConvParams p1 = conv_io(cur, C, T, ft, C, B);
+        p1.in_act = IN_LRELU; p1.in_slope = 0.1f; p1.tag = 1;
+        WETTS_TRY(launch_conv(c1[pr], p1, s));
+        ConvParams p2 = conv_io(ft, C, T, dst, C, B);
+        p2.in_act = IN_LRELU; p2.in_slope = 0.1f; p2.tag = 1;
+        p2.res = cur; p2.r_bs = (int64_t)C * T; p2.r_cs = T;
+        p2.accum = last ? accum : 0;
+        p2.out_div = last ? odiv : 1.f;
+        WETTS_TRY(launch_conv(c2[pr], p2, s));
+      }
+      cur = dst;
+    }
+    return WETTS_OK;
+  };
+  int32_t rc = WETTS_OK;
+  for (int i = 0; i < 3 && rc == WETTS_OK; ++i) rc = run();
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < iters && rc == WETTS_OK; ++i) rc = run();
+  (void)hipEventRecord(e1, s);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *ms_out = ms / iters;
+  if (checksum_out && rc == WETTS_OK) {  // full-tensor hash of ONE application on a known `out`
+    (void)hipMemcpyAsync(o, r, n * 4, hipMemcpyDeviceToDevice, s);
+    rc = run();
+    std::vector<uint32_t> host((size_t)n);
+    (void)hipMemcpy(host.data(), o, host.size() * 4, hipMemcpyDeviceToHost);
+    uint64_t hsh = 1469598103934665603ull;
+    for (size_t i = 0; i < host.size(); ++i) hsh = (hsh ^ host[i]) * 1099511628211ull;
+    *checksum_out = (double)(hsh >> 12);
+    // numeric comparison with the previous call's output (diagnostics: where do two forms differ?)
+    static std::vector<uint32_t> prev;
+    if (prev.size() == host.size() && getenv("WETTS_BENCH_DIFF")) {
+      double mx = 0, mxref = 0;
+      int64_t nbad = 0, first = -1, last = -1;
+      for (size_t i = 0; i < host.size(); ++i) {
+        float a, b2;
+        memcpy(&a, &host[i], 4);
+        memcpy(&b2, &prev[i], 4);
+        double d = fabs((double)a - (double)b2);
+        if (!(d <= mx)) mx = d;
+        if (fabs(b2) > mxref) mxref = fabs(b2);
+        if (host[i] != prev[i]) { ++nbad; if (first < 0) first = (int64_t)i; last = (int64_t)i; }
+      }
+      for (int64_t row : {0, 5, 31}) {
+        for (int64_t t : {0, 1, 2, 3, 100, 509, 510, 511, 512, 1000}) {
+          float a, b2;
+          size_t i = (size_t)(row * T + t);
+          memcpy(&a, &host[i], 4);
+          memcpy(&b2, &prev[i], 4);
+          fprintf(stderr, " r%lld t%lld: %.5f / %.5f;", (long long)row, (long long)t, a, b2);
+        }
+        fprintf(stderr, "\n");
+      }
+      fprintf(stderr, "[diff vs previous call] max|d| %.3e (ref max %.3e), %lld of %lld differ, first idx %lld "
+              "(t=%lld row=%lld) last %lld (t=%lld)\n", mx, mxref, (long long)nbad, (long long)host.size(),
+              (long long)first, (long long)(first % T), (long long)(first / T), (long long)last,
+              (long long)(last % T));
+    }
+    prev = host;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  for (int i = 0; i < 2 * npairs; ++i) {
+    free_packed((i & 1) ? &c2[i >> 1] : &c1[i >> 1]);
+    (void)hipFree(w[i]);
+    (void)hipFree(bias[i]);
+  }
+  (void)hipFree(x); (void)hipFree(o); (void)hipFree(r); (void)hipFree(ft); (void)hipFree(pp[0]);
+  (void)hipFree(pp[1]);
+  return rc;
+}
+
 int32_t wetts_bench_mfma_peak(int32_t blocks_per_cu, int32_t nacc, int32_t iters, double* tflops,
                               double* ms) {
   WETTS_REQUIRE(tflops && ms && blocks_per_cu > 0 && iters > 0, "bad argument");

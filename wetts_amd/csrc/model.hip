@@ -407,6 +407,13 @@ struct wetts_model {
                                   // short on MFMA work per byte (C=64 +10 %, C=128 +3 %; WETTS_FUSE32_KWIDE)
   int fuse2_maxc = 128;           // widest stage whose f32 ResBlock2 chains run fused (WETTS_FUSE2_MAXC)
   int fuse_min_blocks = 128;      // fused pair kernels need this many tiles (else: small unfused tiles)
+  // ResBlock1 chain kernel (resblock_chain32.hip; profiles/r02_resblock_chain.txt): a whole ResBlock1
+  // in one launch where the chain's halo discards at most this share of the tile (C = 32: k = 3, 7;
+  // C = 64: k = 3), single pairs at C = 32 (every k) and for k <= chain_pair_kmax at any width
+  int chain_whole_waste_pct = 15; // WETTS_CHAIN_WHOLE_PCT (0 disables whole-ResBlock launches)
+  int chain_whole_maxc = 64;      // WETTS_CHAIN_WHOLE_MAXC
+  int chain_pair_maxc = 32;       // WETTS_CHAIN_PAIR_MAXC: widest stage whose pairs all run on the chain kernel
+  int chain_pair_kmax = 3;        // WETTS_CHAIN_PAIR_KMAX: ... and pairs with at most this many taps at any width
   int fuse2_waste_pct = 15;       // ResBlock2 chains: max % of tile columns lost to c2's halo at C = 32
                                   // (HBM-bound, +6..30 %); half of it at C >= 64 (profiles/r01_conv32_rb2_chain.txt)
   mutable std::vector<PackedConvB> b_ups;
@@ -852,6 +859,14 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     if (fm) m->fuse_min_blocks = atoi(fm);
     const char* fw2 = getenv("WETTS_FUSE2_WASTE_PCT");
     if (fw2) m->fuse2_waste_pct = atoi(fw2);
+    const char* cw = getenv("WETTS_CHAIN_WHOLE_PCT");
+    if (cw) m->chain_whole_waste_pct = atoi(cw);
+    const char* cwc = getenv("WETTS_CHAIN_WHOLE_MAXC");
+    if (cwc) m->chain_whole_maxc = atoi(cwc);
+    const char* cpc = getenv("WETTS_CHAIN_PAIR_MAXC");
+    if (cpc) m->chain_pair_maxc = atoi(cpc);
+    const char* cpk = getenv("WETTS_CHAIN_PAIR_KMAX");
+    if (cpk) m->chain_pair_kmax = atoi(cpk);
     (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
     for (int j = 0; j < cfg->n_resblock_kernels; ++j) {
       (void)hipEventCreateWithFlags(&m->ev_chain[j], hipEventDisableTiming);
@@ -1461,6 +1476,29 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
       float* fb = chain_buf[j][1];
       float* ft = chain_buf[j][2];
       const float* rx = xu;  // current resblock x
+      // a whole ResBlock1 in one launch (resblock_chain32.hip): x read once, the MRF sum written once
+      if (c->resblock == 1 && !m->dec_unfused && !forked && nd <= RESCHAIN32_MAX_PAIRS &&
+          ch <= m->chain_whole_maxc && m->chain_whole_waste_pct > 0 && len % 4 == 0 &&
+          resblock_chain32_supported(rb.c1.data(), rb.c2.data(), nd, m->fuse32_lds / 2,
+                                     m->chain_whole_waste_pct)) {
+        int dl[RESCHAIN32_MAX_PAIRS];
+        for (int d = 0; d < nd; ++d) dl[d] = rb.c1[d].dil;
+        if (cdiv(len, resblock_chain32_nto(ch, rb.c1[0].ktaps, dl, nd)) * B >= m->fuse_min_blocks) {
+          ResChain32Params cp;
+          memset(&cp, 0, sizeof(cp));
+          cp.x = rx;
+          cp.out = xsum;
+          cp.T = len;
+          cp.B = B;
+          cp.accum = (j > 0) ? 1 : 0;
+          cp.out_div = (j == nk - 1) ? (float)nk : 1.f;  // x = xs / self.num_kernels
+          cp.slope = 0.1f;
+          WETTS_TRY(launch_resblock_chain32(rb.c1.data(), rb.c2.data(), nd, cp, sj));
+          if (tm && tm->on) tm->launches += 1;
+          if (m->mrf_timing) m->mrf_launches += 1;
+          continue;
+        }
+      }
       for (int d = 0; d < nd; ++d) {
         const bool last_d = (d == nd - 1);
         float* outp;
@@ -1502,6 +1540,28 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
         // window (50-60 frames) would be 25 blocks of 150 us each; the small unfused tiles spread
         // it over 4x as many CUs (bench.py --stream: 3.4 -> 2.8 ms per window)
         const int pair_tiles = cdiv(len, pair_nto(ch, rb.c1[d].ktaps)) * B;
+        // one (c1, c2) pair on the chain kernel: every pair of the C = 32 stage, k = 3 pairs at any width
+        const bool chain1 = c->resblock == 1 && !m->dec_unfused && len % 4 == 0 &&
+                            (ch <= m->chain_pair_maxc || rb.c1[d].ktaps <= m->chain_pair_kmax) &&
+                            resblock_chain32_supported(&rb.c1[d], &rb.c2[d], 1, m->fuse32_lds / 2, 100) &&
+                            pair_tiles >= m->fuse_min_blocks;
+        if (chain1) {
+          if (forked && last_d && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
+          ResChain32Params cp;
+          memset(&cp, 0, sizeof(cp));
+          cp.x = rx;
+          cp.out = outp;
+          cp.T = len;
+          cp.B = B;
+          cp.accum = accum;
+          cp.out_div = odiv;
+          cp.slope = 0.1f;
+          WETTS_TRY(launch_resblock_chain32(&rb.c1[d], &rb.c2[d], 1, cp, sj));
+          if (tm && tm->on) tm->launches += 1;
+          if (m->mrf_timing) m->mrf_launches += 1;
+          rx = outp;
+          continue;
+        }
         const bool fuse32 = c->resblock == 1 && !m->dec_unfused &&
                             resblock_pair32_supported(rb.c1[d], rb.c2[d], m->fuse32_lds) &&
                             !(ch >= 128 && rb.c1[d].ktaps >= m->fuse32_kmax128) &&

@@ -35,4 +35,31 @@ bool resblock2_chain32_supported(const PackedConv& c1, const PackedConv& c2, int
 int32_t launch_resblock2_chain32(const PackedConv& c1, const PackedConv& c2, ResPair32Params p,
                                  hipStream_t stream);
 
+// ---- ResBlock1 chains (resblock_chain32.hip): npairs (c1, c2) pairs in one launch ----------------
+constexpr int RESCHAIN32_MAX_PAIRS = 3;  // a whole ResBlock1 (decoders.py:157-170)
+constexpr int RESCHAIN32_MAX_M = 28;     // widest half-width (k-1)/2 * dilation the tile margins hold
+
+struct ResChain32Params {
+  const float* x;  // [B][C][T] residual stream (16-byte aligned rows: T % 4 == 0)
+  float* out;      // [B][C][T] (never aliases x)
+  const float* wpk[2 * RESCHAIN32_MAX_PAIRS];   // pack_conv_weight layouts: c1_0, c2_0, c1_1, ...
+  const float* bias[2 * RESCHAIN32_MAX_PAIRS];
+  int dil[RESCHAIN32_MAX_PAIRS];                // dilation of c1_p (c2_p runs at 1)
+  int npairs, ktaps;
+  int T, B;
+  int accum;       // add the previous contents of out (running MRF sum)
+  float out_div;
+  float slope;
+  int S, Mmin, NTO, ntiles, nblocks, Wp;  // filled by the launcher
+  int dbg;
+};
+
+// c1 / c2: npairs descriptors each.  max_waste_pct bounds the share of tile columns the chain's halo
+// discards (2 S of NTC); max_lds_bytes the tile (80 KB keeps two blocks per CU).
+bool resblock_chain32_supported(const PackedConv* c1, const PackedConv* c2, int npairs,
+                                int max_lds_bytes, int max_waste_pct);
+int resblock_chain32_nto(int C, int ktaps, const int* dil, int npairs);  // valid outputs per tile
+int32_t launch_resblock_chain32(const PackedConv* c1, const PackedConv* c2, int npairs,
+                                ResChain32Params p, hipStream_t stream);
+
 }  // namespace wetts
