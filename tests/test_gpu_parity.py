@@ -213,18 +213,18 @@ def test_hifigan_bf16_mode_matches_its_numerics_spec(name):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("L", [1, 37, 200])
 def test_fused_resblock_pair_bit_identical(dtype, L, cname):
-    """The fused ResBlock1 kernels (resblock32.hip at f32, resblock16.hip at 16 bit) perform the
+    """The fused ResBlock kernels (resblock_chain32.hip / resblock32.hip at f32, resblock16.hip at 16 bit) perform the
     arithmetic of two conv launches in the same order with the same rounding points: outputs must
     be EQUAL, including at tile seams
     (L*hop spans several time tiles), sequence ends (zero padding of c2's input) and L=1."""
     case = util.load_case(cname)  # v1: ResBlock1 pairs; v3: ResBlock2 chains (RB2 instantiations)
-    os.environ["WETTS_FUSE_MIN_BLOCKS"] = "0"  # also fuse launches too small to fill the chip
-    os.environ["WETTS_FUSE2_WASTE_PCT"] = "100"  # and ResBlock2 shapes with a wide second halo
+    # also fuse launches too small to fill the chip, ResBlock2 shapes with a wide second halo, and whole
+    # ResBlock1 chains whatever their halo costs (every fused kernel must be exercised here)
+    os.environ["WETTS_TUNE"] = "fuse_min_blocks=0,fuse2_waste_pct=100,chain_whole_pct=100,chain_whole_maxc=128"
     try:
         net, cfg, W = _model(case)
     finally:
-        del os.environ["WETTS_FUSE_MIN_BLOCKS"]
-        del os.environ["WETTS_FUSE2_WASTE_PCT"]
+        del os.environ["WETTS_TUNE"]
     torch.manual_seed(5)
     z = torch.randn(2, cfg.inter_channels, L)
     g = torch.nn.functional.embedding(util.t(case["sid"]), W["emb_g.weight"])

@@ -4,9 +4,8 @@ measurement entry point wetts_bench_conv (wetts_amd/csrc/bench_conv.hip).
 
     python tools/bench_conv.py [variants]        variants: comma-separated ints, default "0,1"
 
-Each variant is `variant | ablate << 8`: low byte 16 = fused pair / chain kernel, 32 = the same pair
-as two launches (pair mode), 8 = force two LDS buffers (16-bit conv); high bits are the ablation
-masks of the DBG instantiations (see the kernels).  Environment:
+Variant 16 = fused pair / chain kernel, 32 = the same pair as two launches (pair mode); other values
+select a conv tile shape (WETTS_CONV_VARIANT).  Environment:
     WETTS_CONV_FLAGS=16|32   16-bit decoder kernels (bf16 | f16) instead of f32
     WETTS_PAIR=1             ResBlock1 pairs (c1 at dilation d, c2 at 1): compare variants 32 and 16
     WETTS_RB2=1              with WETTS_PAIR: ResBlock2 chains (both convs residual, c2 at 2d)

@@ -8,8 +8,8 @@ extern "C" {
 // One Conv1d(Cin->Cout, k, dilation) on [B,Cin,T] with pseudo-random data.
 // flags: 1 = leaky-relu prologue, 2 = residual add, 4 = accumulate into the output, 8 = MRF mean
 // division, 16 / 32 = bf16 / f16 decoder kernels, 64 = ResBlock2 chain (pair modes).
-// variant: low byte = kernel family / tile override (16 = fused pair, 32 = the same pair as two
-// launches), high bits = ablation mask of the DBG instantiations.
+// variant: low byte = tile override (WETTS_CONV_VARIANT values) or 16 = fused pair, 32 = the same
+// pair as two launches.
 int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int32_t B, int32_t T,
                          int32_t flags, int32_t variant, int32_t iters, double* ms_out,
                          double* checksum_out);

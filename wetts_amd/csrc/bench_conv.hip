@@ -37,10 +37,9 @@ static int32_t fill_pseudo(float* p, int64_t n, unsigned seed, float scale, hipS
 }
 }  // namespace wetts
 
-// 16-bit decoder conv microbench (flags & 16: bf16, & 32: f16); variant low byte: 1 half-width tiles,
-// 2 two chunks in flight, 4 permuted rows (16-byte epilogue), 8 force two LDS buffers; variant >> 8:
-// ablation bits of the DBG instantiation (1 no stores, 2 no residual loads, 4 no A loads, 8 no
-// staging loads after chunk 0, 16 no MFMA, 32 no staging loads at all, 64 nothing = DBG overhead)
+// 16-bit decoder conv microbench (flags & 16: bf16, & 32: f16); variant 16 = fused pair kernel,
+// 32 = the same pair as two launches.  (The round-1 ablation instantiations are gone; their results
+// are kept in profiles/r01_conv16_ablation.txt.)
 static int32_t bench_conv_16bit(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int32_t B,
                                 int32_t T, int32_t flags, int32_t variant, int32_t iters,
                                 double* ms_out, double* checksum_out) {
@@ -80,7 +79,6 @@ static int32_t bench_conv_16bit(int32_t Cin, int32_t Cout, int32_t k, int32_t di
         memset(&pp, 0, sizeof(pp));
         pp.x = x; pp.out = o; pp.T = T; pp.B = B; pp.accum = (flags & 4) ? 1 : 0;
         pp.out_div = (flags & 8) ? 3.f : 1.f; pp.slope = 0.1f;
-        pp.ablate = variant >> 8;
         return launch_resblock_pair16(pc, pc2, pp, s);
       }
       ConvBParams p1;
@@ -132,8 +130,6 @@ static int32_t bench_conv_16bit(int32_t Cin, int32_t Cout, int32_t k, int32_t di
   if (flags & 1) { p.in_act = IN_LRELU; p.in_slope = 0.1f; }
   if (flags & 2) { p.res = r; p.r_bs = (int64_t)Cout * T; }
   if (flags & 4) p.accum = 1;
-  p.variant = variant & 0xff;
-  p.ablate = variant >> 8;
   int32_t rc = WETTS_OK;
   for (int i = 0; i < 2 && rc == WETTS_OK; ++i) rc = launch_conv_bf16(pc, p, s);
   hipEvent_t e0, e1;
@@ -220,7 +216,6 @@ int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int3
         memset(&pp, 0, sizeof(pp));
         pp.x = x; pp.out = o; pp.T = T; pp.B = B; pp.accum = (flags & 4) ? 1 : 0;
         pp.out_div = (flags & 8) ? 3.f : 1.f; pp.slope = 0.1f;
-        pp.ablate = variant >> 8;
         return launch_resblock_pair32(pc, pc2, pp, s);
       }
       ConvParams p1 = conv_io(x, Cin, T, ft, Cout, B);
@@ -274,7 +269,6 @@ int32_t wetts_bench_conv(int32_t Cin, int32_t Cout, int32_t k, int32_t dil, int3
   p.tag = 1;  // the MRF launch class (own kernel symbol)
   const int saved = conv_variant();
   set_conv_variant(variant & 0xff);
-  p.ablate = variant >> 8;
   int32_t rc = WETTS_OK;
   for (int i = 0; i < 2 && rc == WETTS_OK; ++i) rc = launch_conv(pc, p, s);
   hipEvent_t e0, e1;

@@ -94,7 +94,6 @@ struct ConvParams {
   int accum;             // 1: add the previous contents of out
   float out_div;         // final true division (MRF mean: xs / num_kernels), 1 = none
   int B;
-  int ablate;            // microbenchmark-only ablation mask (see conv_mfma_kernel DBG)
   int tag;               // 1: MRF ResBlock launch (separate kernel symbol for profiles)
 };
 

@@ -30,8 +30,6 @@ struct ConvBParams {
   int accum;
   float out_div;
   int B;
-  int variant;  // microbench only: 8 = always allocate two LDS staging buffers
-  int ablate;   // microbench only (DBG instantiation)
 };
 
 // fused ResBlock1 pair (resblock16.hip): out = (x + c2(lrelu(c1(lrelu(x)))) [+ out]) / div
@@ -48,8 +46,6 @@ struct ResPairParams {
   float out_div;
   float slope;     // leaky-relu slope in front of both convs
   int ntiles, nblocks;
-  int ablate;      // microbench only (DBG instantiation): 1 no stores, 2 no residual loads, 4 no A
-                   // loads, 8 no x loads, 16 no MFMA / B reads, 32 no lrelu in staging
 };
 bool resblock_pair16_supported(const PackedConvB& c1, const PackedConvB& c2);
 int32_t launch_resblock_pair16(const PackedConvB& c1, const PackedConvB& c2, ResPairParams p,

@@ -97,7 +97,7 @@ void free_packed_bf16(PackedConvB* pc) {
 // ------------------------------------------------------------------------------------------
 // the conv kernel: 4 waves (WM x WN), each wave one 32-row m-block x NB 32-column n-blocks
 // ------------------------------------------------------------------------------------------
-template <int NB, int WM, int WN, int CKB, bool F16, bool DBG>
+template <int NB, int WM, int WN, int CKB, bool F16>
 // three waves per SIMD where the register allocation reaches it without heavy spilling (the compiler
 // otherwise spreads over VGPRs + AGPRs and settles at two)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CKB == 32 || WM == 4) ? 3 : 1)))
@@ -112,7 +112,6 @@ void conv_bf16_kernel(const ConvBParams p) {
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
 
-  const int ab = DBG ? p.ablate : 0;  // microbench ablation bits (DBG instantiation only)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,7 +142,6 @@ void conv_bf16_kernel(const ConvBParams p) {
     const int t = n0 + p.off_lo + row;
     urow[i] = row;
     uok[i] = (row < W) && (t >= 0) && (t < p.Tin);
-    if (DBG && (ab & 32)) uok[i] = false;
   }
   const int useg = tid % SEG;  // 256 % SEG == 0, so the piece index does not depend on i
   uint4 st0[MAXU];
@@ -190,7 +188,7 @@ void conv_bf16_kernel(const ConvBParams p) {
   const bool rows_ok = mrow_blk + 32 <= p.M;
 
   // residual / running sum folded into the accumulator init (plain convs only)
-  if (p.up == 0 && (p.res || p.accum) && rows_ok && !(DBG && (ab & 2))) {
+  if (p.up == 0 && (p.res || p.accum) && rows_ok) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int t = wcol0 + 32 * j + (lane & 31);
@@ -249,22 +247,20 @@ void conv_bf16_kernel(const ConvBParams p) {
     for (int par = 0; par < 2; ++par) {  // ping-pong A register sets, statically indexed
       const int gg = g + par;
       if (gg < G) {
-        if (gg + 1 < G && !(DBG && (ab & 4))) {
+        if (gg + 1 < G) {
 #pragma unroll
           for (int s = 0; s < KS; ++s) aa[par ^ 1][s] = abase[((int64_t)(gg + 1) * KS + s) * 64];
         }
-        if (tap == 0 && chunk + 1 < p.nchunks && !(DBG && (ab & 8))) load_chunk(chunk + 1, st0);
+        if (tap == 0 && chunk + 1 < p.nchunks) load_chunk(chunk + 1, st0);
         const unsigned char* cur = (chunk & 1) ? buf1 : buf0;
         const unsigned char* bb = cur + (size_t)(brow0 + tap * p.dil) * RS + half * 16;
-        if (!(DBG && (ab & 16))) {
 #pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            const uint4 av = aa[par][s];
+        for (int s = 0; s < KS; ++s) {
+          const uint4 av = aa[par][s];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-              const uint4 bw = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
-              acc[j] = mfma16<F16>(av, bw, acc[j]);
-            }
+          for (int j = 0; j < NB; ++j) {
+            const uint4 bw = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
+            acc[j] = mfma16<F16>(av, bw, acc[j]);
           }
         }
         if (++tap == p.ktaps) {
@@ -281,7 +277,6 @@ void conv_bf16_kernel(const ConvBParams p) {
   if (!rows_ok) return;  // M is a multiple of 32 in every decoder conv; guard only
   const bool dodiv = p.out_div != 1.f;
   unsigned short* ob = p.out + (int64_t)b * p.o_bs;
-  const bool nostore = DBG && (ab & 1);
   // lane rows = two runs of 8 consecutive channels (see pack_bf16_kernel) -> 16-byte stores
   float bia[16];
 #pragma unroll
@@ -307,7 +302,6 @@ void conv_bf16_kernel(const ConvBParams p) {
       uint4 o;
       o.x = pk2<F16>(v[0], v[1]); o.y = pk2<F16>(v[2], v[3]);
       o.z = pk2<F16>(v[4], v[5]); o.w = pk2<F16>(v[6], v[7]);
-      if (nostore && v[0] != 1.2345e30f) continue;
       *reinterpret_cast<uint4*>(ob + (int64_t)t * p.cout + co_blk + 16 * i + 8 * half) = o;
     }
   }
@@ -320,15 +314,13 @@ static int32_t launch_b(const ConvBParams& p, hipStream_t stream, bool f16) {
   if (blocks <= 0) return WETTS_OK;
   WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
   // one staging buffer is enough when the whole reduction is a single channel chunk
-  const int nbuf = (p.nchunks > 1 || (p.variant & 8)) ? 2 : 1;
+  const int nbuf = p.nchunks > 1 ? 2 : 1;
   size_t lds = (size_t)nbuf * (NT + p.span) * RS;
   const dim3 grid((unsigned)blocks), blk(256);
-  if (p.ablate)  // microbench instrumentation (bf16 storage only)
-    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, true>), grid, blk, lds, stream, p);
-  else if (f16)
-    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, false>), grid, blk, lds, stream, p);
+  if (f16)
+    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true>), grid, blk, lds, stream, p);
   else
-    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, false>), grid, blk, lds, stream, p);
+    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false>), grid, blk, lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

@@ -111,18 +111,18 @@ void free_packed(PackedConv* pc) {
 // the conv kernel
 // ------------------------------------------------------------------------------------------
 // EPI: 0 = generic epilogue (runtime activation / masks / late residual), 1 = plain
-// (acc + bias [+ per-utterance bias]), 2 = plain followed by the MRF mean division.
-// OPT (experiment bits): 1 = stagger the staging-load issue point across co-resident blocks, 2 = ping-pong A registers,
-// compile-time ablations for the microbenchmark: 4 no A loads, 8 no LDS B reads, 16 no staging
-// loads/stores, 32 no per-chunk barrier; 64 = name tag of the MRF launches (no code change).
+// (acc + bias [+ per-utterance bias]), 2 = plain followed by the MRF mean division, 3 = polyphase
+// ConvTranspose1d store.  MRF = name tag of the ResBlock launches (no code difference): rocprofv3
+// --stats then separates bench.py's dominant-kernel class from the flow / encoder convs that share
+// the tile shape.
 // Four 32x32 accumulators per wave (64 AGPRs) plus ~105 VGPRs sat one allocation granule above the
 // three-waves-per-SIMD budget (168 registers): asking for three waves makes the compiler fit, and
 // the extra resident wave hides the staging / A-fragment waits of the chunked loop.
-template <int MB, int NB, int WM, int WN, bool PF, bool DBG = false, int EPI = 0, int OPT = 0>
+// (The ablation / experiment switches this kernel carried in round 1 are gone from the product; their
+// measurements are kept under profiles/r01_conv_ablation*.txt.)
+template <int MB, int NB, int WM, int WN, int EPI = 0, bool MRF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB * NB >= 4 && WN < 4) ? 3 : 1)))
 void conv_mfma_kernel(const ConvParams p) {
-  // DBG instantiations honour p.ablate (microbenchmark only): 1 no MFMA, 2 no staging loads,
-  // 4 no A loads, 8 no epilogue stores, 16 no LDS B reads
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int CK = kConvCK;
   constexpr int MT = 32 * MB * WM;
@@ -177,11 +177,7 @@ void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
       for (int i = 0; i < MAXCI; ++i) {
         float v = 0.f;
-        if (DBG && (p.ablate & 2)) {
-          v = 0.25f;
-        } else if (cok && tcol[i] >= 0) {
-          v = xr[tcol[i]];
-        }
+        if (cok && tcol[i] >= 0) v = xr[tcol[i]];
         stage[r][i] = v;  // raw: no use of the value here, so the loads stay in flight
       }
     }
@@ -280,16 +276,12 @@ void conv_mfma_kernel(const ConvParams p) {
     abase[i] = reinterpret_cast<const float4*>(p.wpk) + ((int64_t)mt32 * G) * 64 + lane;
   }
 
-  float4 a_nxt[MB];
+  // A fragments ping-pong between two register sets: a_nxt holds the even groups, a_alt the odd ones
+  float4 a_nxt[MB], a_alt[MB];
 #pragma unroll
   for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][0];
-  float4 a_alt[MB];
 #pragma unroll
   for (int i = 0; i < MB; ++i) a_alt[i] = a_nxt[i];
-  const bool no_a = DBG && (p.ablate & 4);
-  const bool no_mfma = DBG && (p.ablate & 1);
-  const bool no_b = DBG && (p.ablate & 16);
-  float dbg_sink = 0.f;
 
   load_chunk(0);
   store_chunk(buf0);
@@ -298,111 +290,51 @@ void conv_mfma_kernel(const ConvParams p) {
   const int half = lane >> 5;
   const int bcol0 = wn * (32 * NB) + (lane & 31) - p.pad - p.off_lo;
   int g = 0;
-  const int stag_tap = (int)((blockIdx.x >> 8) % 3u) * p.ktaps / 4;
   for (int c = 0; c < p.nchunks; ++c) {
     const float* cur = (c & 1) ? buf1 : buf0;
     const bool more = (c + 1) < p.nchunks;
-    if (!(OPT & 1)) {
-      if (more && !(OPT & 16)) load_chunk(c + 1);
-    }
+    if (more) load_chunk(c + 1);
     for (int tap = 0; tap < p.ktaps; ++tap) {
-      if (OPT & 1) {
-        // co-resident blocks issue their staging loads at different taps so that the in-order
-        // vmcnt stall behind them does not hit every wave of the CU at the same moment
-        if (tap == stag_tap && more) load_chunk(c + 1);
-      }
       const int coff = bcol0 + tap * p.dil;
 #pragma unroll
       for (int hp = 0; hp < 2; ++hp) {
         float4 a_cur[MB];
-        if ((OPT & 2) && !DBG) {
-          // ping-pong: a_nxt holds the even groups, a_alt the odd ones; no register copies
-          ++g;
-          if (hp == 0) {
-#pragma unroll
-            for (int i = 0; i < MB; ++i) a_cur[i] = a_nxt[i];
-            // unconditional (group G exists: next m-block / zero tail): a conditional load makes
-            // the compiler's waitcnt insertion assume it may not be pending and emit vmcnt(0)
-            if (!(OPT & 4)) {
-#pragma unroll
-              for (int i = 0; i < MB; ++i) a_alt[i] = abase[i][(int64_t)g * 64];
-              __builtin_amdgcn_sched_barrier(0);  // keep the prefetch a whole group ahead of its use
-            }
-          } else {
-#pragma unroll
-            for (int i = 0; i < MB; ++i) a_cur[i] = a_alt[i];
-            if (!(OPT & 4)) {
-#pragma unroll
-              for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][(int64_t)g * 64];
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-        } else {
+        ++g;
+        // the prefetch is unconditional (group G exists: next m-block / zero tail): a conditional load
+        // makes the compiler's waitcnt insertion assume it may not be pending and emit vmcnt(0)
+        if (hp == 0) {
 #pragma unroll
           for (int i = 0; i < MB; ++i) a_cur[i] = a_nxt[i];
-          ++g;
-          if (g < G && !no_a) {
 #pragma unroll
-            for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][(int64_t)g * 64];
-          }
+          for (int i = 0; i < MB; ++i) a_alt[i] = abase[i][(int64_t)g * 64];
+        } else {
+#pragma unroll
+          for (int i = 0; i < MB; ++i) a_cur[i] = a_alt[i];
+#pragma unroll
+          for (int i = 0; i < MB; ++i) a_nxt[i] = abase[i][(int64_t)g * 64];
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch a whole group ahead of its use
         const float* brow0 = cur + (hp * 8 + half) * W + coff;
         float bv[2][NB];
-        if (PF) {
-#pragma unroll
-          for (int j = 0; j < NB; ++j) bv[0][j] = brow0[32 * j];
-        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          if (PF) {
-            if (s < 3) {
 #pragma unroll
-              for (int j = 0; j < NB; ++j) bv[(s + 1) & 1][j] = brow0[(s + 1) * 2 * W + 32 * j];
-            }
-          } else {
-            if (no_b || (OPT & 8)) {
-#pragma unroll
-              for (int j = 0; j < NB; ++j) bv[s & 1][j] = 0.5f + 0.001f * (float)(s + j);
-            } else {
-#pragma unroll
-              for (int j = 0; j < NB; ++j) bv[s & 1][j] = brow0[s * 2 * W + 32 * j];
-            }
-          }
+          for (int j = 0; j < NB; ++j) bv[s & 1][j] = brow0[s * 2 * W + 32 * j];
 #pragma unroll
           for (int i = 0; i < MB; ++i) {
             const float av = s == 0 ? a_cur[i].x : s == 1 ? a_cur[i].y : s == 2 ? a_cur[i].z
                                                                                  : a_cur[i].w;
-            if (no_mfma) {
 #pragma unroll
-              for (int j = 0; j < NB; ++j) dbg_sink += av * bv[s & 1][j];
-            } else {
-#pragma unroll
-              for (int j = 0; j < NB; ++j)
-                acc[i][j] =
-                    __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s & 1][j], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < NB; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s & 1][j], acc[i][j], 0, 0, 0);
           }
         }
       }
     }
-    if (!(DBG && (p.ablate & 32))) {
-      if (more && !(OPT & 16)) store_chunk((c & 1) ? buf0 : buf1);
-      if (!(OPT & 32)) __syncthreads();
-    }
+    if (more) store_chunk((c & 1) ? buf0 : buf1);
+    __syncthreads();
   }
 
-  if (DBG && no_mfma) acc[0][0][0] += dbg_sink;
-  if (DBG && (p.ablate & 64)) {
-    float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
-    if (sacc == 123.456f) p.out[0] = sacc;
-    return;
-  }
   // ---- epilogue ---------------------------------------------------------------------------
   const int64_t ob = (int64_t)b * p.o_bs;
   const int64_t rb = (int64_t)b * p.r_bs;
@@ -509,11 +441,7 @@ void conv_mfma_kernel(const ConvParams p) {
           if (p.accum) v += *dst;
         }
         if (p.out_div != 1.f) v = v / p.out_div;
-        if (DBG && (p.ablate & 8)) {
-          if (v == 123.456f + dbg_sink) *dst = v;  // keeps v live, practically never stores
-        } else {
-          *dst = v;
-        }
+        *dst = v;
       }
     }
   }
@@ -531,48 +459,32 @@ int conv_variant() {
 }
 void set_conv_variant(int v) { g_conv_variant = v; }
 
-template <int MB, int NB, int WM, int WN, bool PF = false>
+template <int MB, int NB, int WM, int WN>
 static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
   constexpr int MT = 32 * MB * WM, NT = 32 * NB * WN;
   int ntiles = cdiv(p.N, NT), mtiles = cdiv(p.M, MT);
   int64_t blocks = (int64_t)ntiles * mtiles * p.B;
   if (blocks <= 0) return WETTS_OK;
   WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
-  size_t lds = (size_t)2 * kConvCK * (NT + p.span) * sizeof(float);
-  if (p.ablate) {
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, true, 0>), dim3((unsigned)blocks),
-                       dim3(256), lds, stream, p);
-    WETTS_LAUNCH_CHECK();
-    return WETTS_OK;
-  }
+  const size_t lds = (size_t)2 * kConvCK * (NT + p.span) * sizeof(float);
+  const dim3 grid((unsigned)blocks), blk(256);
   // epilogue specialisation: residual / running sum are folded into the accumulator init
   // whenever there is no output activation or mask, which leaves "acc + bias [/ div]"
   const bool plain = p.up == 0 && p.out_act == OUT_NONE && p.out_mask == nullptr;
   if (p.up > 0 && p.up_shift >= 0 && p.out_act == OUT_NONE && !p.out_mask && !p.res && !p.accum &&
       !p.bias_b && p.out_div == 1.f) {
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 3, 2>), dim3((unsigned)blocks),
-                       dim3(256), lds, stream, p);
-    WETTS_LAUNCH_CHECK();
-    return WETTS_OK;
-  }
-  if (plain && p.tag) {
-    // MRF ResBlock launches get their own symbol (OPT bit 64 changes nothing but the name) so that
-    // rocprofv3 --stats separates bench.py's dominant-kernel class from the flow / encoder convs
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 3, false>), grid, blk, lds, stream, p);
+  } else if (plain && p.tag) {  // MRF ResBlock launches: own kernel symbol
     if (p.out_div == 1.f)
-      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 1, 2 | 64>),
-                         dim3((unsigned)blocks), dim3(256), lds, stream, p);
+      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 1, true>), grid, blk, lds, stream, p);
     else
-      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 2, 2 | 64>),
-                         dim3((unsigned)blocks), dim3(256), lds, stream, p);
+      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 2, true>), grid, blk, lds, stream, p);
   } else if (plain && p.out_div == 1.f) {
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 1, 2>), dim3((unsigned)blocks),
-                       dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 1, false>), grid, blk, lds, stream, p);
   } else if (plain) {
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 2, 2>), dim3((unsigned)blocks),
-                       dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 2, false>), grid, blk, lds, stream, p);
   } else {
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, PF, false, 0, 2>), dim3((unsigned)blocks),
-                       dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 0, false>), grid, blk, lds, stream, p);
   }
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;

@@ -839,34 +839,42 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
                      hipMemcpyDeviceToDevice, s);
   int32_t r = (e == hipSuccess) ? build_model(m, s) : WETTS_E_HIP;
   {
-    const char* env = getenv("WETTS_MRF_STREAMS");
-    m->mrf_streams = env ? atoi(env) : 1;  // opt-in: +2 % at cfg 2, but kernels then overlap in profiles
+    // A/B switches for measurements (none is needed in production): ONE variable,
+    // WETTS_TUNE="name=value,name=value", names as in the table below
+    struct Knob { const char* name; int* field; };
+    const Knob knobs[] = {
+        {"mrf_streams", &m->mrf_streams},         {"fuse32_lds", &m->fuse32_lds},
+        {"fuse32_kmax128", &m->fuse32_kmax128},   {"fuse32_maxc", &m->fuse32_maxc},
+        {"fuse32_kmax", &m->fuse32_kmax},         {"fuse32_kwide", &m->fuse32_kwide},
+        {"fuse2_maxc", &m->fuse2_maxc},           {"fuse2_waste_pct", &m->fuse2_waste_pct},
+        {"fuse_min_blocks", &m->fuse_min_blocks}, {"chain_whole_pct", &m->chain_whole_waste_pct},
+        {"chain_whole_maxc", &m->chain_whole_maxc}, {"chain_pair_maxc", &m->chain_pair_maxc},
+        {"chain_pair_kmax", &m->chain_pair_kmax},
+    };
+    if (const char* env = getenv("WETTS_TUNE")) {
+      std::string all(env);
+      size_t pos = 0;
+      while (pos < all.size()) {
+        size_t end = all.find(',', pos);
+        if (end == std::string::npos) end = all.size();
+        const std::string item = all.substr(pos, end - pos);
+        const size_t eq = item.find('=');
+        bool known = false;
+        if (eq != std::string::npos)
+          for (const Knob& k : knobs)
+            if (item.compare(0, eq, k.name) == 0 && strlen(k.name) == eq) {
+              *k.field = atoi(item.c_str() + eq + 1);
+              known = true;
+            }
+        if (!known && !item.empty()) {
+          set_error("WETTS_TUNE: unknown setting '%s'", item.c_str());
+          r = WETTS_E_INVALID;
+        }
+        pos = end + 1;
+      }
+    }
     if (m->mrf_streams < 1) m->mrf_streams = 1;
     if (m->mrf_streams > cfg->n_resblock_kernels) m->mrf_streams = cfg->n_resblock_kernels;
-    const char* fl = getenv("WETTS_FUSE32_LDS");  // experiment knob: f32 pair tiles above this run unfused
-    if (fl) m->fuse32_lds = atoi(fl);
-    const char* fk = getenv("WETTS_FUSE32_KMAX128");
-    if (fk) m->fuse32_kmax128 = atoi(fk);
-    const char* fc = getenv("WETTS_FUSE32_MAXC");
-    if (fc) m->fuse32_maxc = atoi(fc);
-    const char* f2c = getenv("WETTS_FUSE2_MAXC");
-    if (f2c) m->fuse2_maxc = atoi(f2c);
-    const char* fkm = getenv("WETTS_FUSE32_KMAX");
-    if (fkm) m->fuse32_kmax = atoi(fkm);
-    const char* fkw = getenv("WETTS_FUSE32_KWIDE");
-    if (fkw) m->fuse32_kwide = atoi(fkw);
-    const char* fm = getenv("WETTS_FUSE_MIN_BLOCKS");
-    if (fm) m->fuse_min_blocks = atoi(fm);
-    const char* fw2 = getenv("WETTS_FUSE2_WASTE_PCT");
-    if (fw2) m->fuse2_waste_pct = atoi(fw2);
-    const char* cw = getenv("WETTS_CHAIN_WHOLE_PCT");
-    if (cw) m->chain_whole_waste_pct = atoi(cw);
-    const char* cwc = getenv("WETTS_CHAIN_WHOLE_MAXC");
-    if (cwc) m->chain_whole_maxc = atoi(cwc);
-    const char* cpc = getenv("WETTS_CHAIN_PAIR_MAXC");
-    if (cpc) m->chain_pair_maxc = atoi(cpc);
-    const char* cpk = getenv("WETTS_CHAIN_PAIR_KMAX");
-    if (cpk) m->chain_pair_kmax = atoi(cpk);
     (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
     for (int j = 0; j < cfg->n_resblock_kernels; ++j) {
       (void)hipEventCreateWithFlags(&m->ev_chain[j], hipEventDisableTiming);

@@ -32,7 +32,7 @@ namespace wetts {
 // c2 shares c1's column -> time mapping, so the rounded t1 a lane needs as c2's residual is what its
 // accumulators just produced; lrelu(t1) is written h2 rows down the tile, valid outputs are the
 // middle columns [h2, NTC - h2)  (see resblock32.hip).
-template <int C, bool F16, int NR, int OCC, bool DBG, bool RB2>
+template <int C, bool F16, int NR, int OCC, bool RB2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 void resblock_pair16_kernel(const ResPairParams p) {
   constexpr int WM = C / 32, WN = 4 / WM, NB = 4;
@@ -46,7 +46,6 @@ void resblock_pair16_kernel(const ResPairParams p) {
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
 
-  const int ab = DBG ? p.ablate : 0;  // microbench ablation bits
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,7 +96,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int t = n0 - h2 + wcol + 32 * j;
-      const bool ok = t >= 0 && t < p.T && !(DBG && (ab & 2));
+      const bool ok = t >= 0 && t < p.T;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -116,7 +115,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
       const int row = (tid + 256 * i) / SEG;
       const int t = tx0 + row;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (row < W1 && t >= 0 && t < p.T && !(DBG && (ab & 8)))
+      if (row < W1 && t >= 0 && t < p.T)
         v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + useg * 8);
       st[i] = v;
     }
@@ -125,10 +124,8 @@ void resblock_pair16_kernel(const ResPairParams p) {
       const int row = (tid + 256 * i) / SEG;
       if (row < W1) {
         uint4 v = st[i];
-        if (!(DBG && (ab & 32))) {
         v.x = lrelu_pk<F16>(v.x, p.slope); v.y = lrelu_pk<F16>(v.y, p.slope);
         v.z = lrelu_pk<F16>(v.z, p.slope); v.w = lrelu_pk<F16>(v.w, p.slope);
-        }
         *reinterpret_cast<uint4*>(smem_r + (size_t)row * RS + useg * 16) = v;
       }
     }
@@ -163,7 +160,6 @@ void resblock_pair16_kernel(const ResPairParams p) {
   // group.  Straight-line issue gives exact counts (vmcnt((NR-1)*KS) ... ).
   auto mma_group = [&](const uint4* av, int tap, int chunk, int dil) {
     const unsigned char* bb = bcol + (size_t)(tap * dil) * RS + chunk * (CKB * 2);
-    if (!(DBG && (ab & 16)))
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -180,10 +176,8 @@ void resblock_pair16_kernel(const ResPairParams p) {
       for (int par = 0; par < NR; ++par) {
         int gn = g + par + NR - 1;
         gn = gn < G ? gn : G - 1;
-        if (!(DBG && (ab & 4))) {
 #pragma unroll
-          for (int s = 0; s < KS; ++s) aa[(par + NR - 1) % NR][s] = abase[((int64_t)gn * KS + s) * 64];
-        }
+        for (int s = 0; s < KS; ++s) aa[(par + NR - 1) % NR][s] = abase[((int64_t)gn * KS + s) * 64];
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch at the top of its group
         mma_group(aa[par], tap, chunk, dil);
         if (++tap == p.ktaps) { tap = 0; ++chunk; }
@@ -207,7 +201,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
   for (int j = 0; j < NB; ++j) {
     const int col = wcol + 32 * j;
     const int t = n0 + col;
-    const bool ok = !RB2 && col < NTO && t < p.T && !(DBG && (ab & 2));
+    const bool ok = !RB2 && col < NTO && t < p.T;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -300,7 +294,6 @@ void resblock_pair16_kernel(const ResPairParams p) {
       uint4 o;
       o.x = pk2<F16>(v[0], v[1]); o.y = pk2<F16>(v[2], v[3]);
       o.z = pk2<F16>(v[4], v[5]); o.w = pk2<F16>(v[6], v[7]);
-      if (DBG && (ab & 1) && v[0] != 1.2345e30f) continue;
       *reinterpret_cast<uint4*>(ob + (int64_t)t * C + co_blk + 16 * i + 8 * half) = o;
     }
   }
@@ -320,12 +313,10 @@ static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream
   p.nblocks = (int)nb;
   const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);
   const size_t lds = (size_t)(NTC + 2 * (h1 > h2 ? h1 : h2)) * RS;
-  if (p.ablate)  // microbench instrumentation (bf16 storage only)
-    hipLaunchKernelGGL((resblock_pair16_kernel<C, false, NR, OCC, true, RB2>), dim3(grid), dim3(256), lds, stream, p);
-  else if (f16)
-    hipLaunchKernelGGL((resblock_pair16_kernel<C, true, NR, OCC, false, RB2>), dim3(grid), dim3(256), lds, stream, p);
+  if (f16)
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, true, NR, OCC, RB2>), dim3(grid), dim3(256), lds, stream, p);
   else
-    hipLaunchKernelGGL((resblock_pair16_kernel<C, false, NR, OCC, false, RB2>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, false, NR, OCC, RB2>), dim3(grid), dim3(256), lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

@@ -18,8 +18,6 @@ struct ResPair32Params {
   float out_div;
   float slope;     // leaky-relu slope in front of both convs
   int ntiles, nblocks, Wp;  // filled by the launcher
-  int ablate;      // microbench only (DBG instantiation): 1 no stores, 2 no residual loads,
-                   // 4 no A loads, 8 no x loads, 16 no MFMA
 };
 
 // max_lds_bytes: largest x tile the caller accepts (80 KB keeps two blocks per CU)
@@ -51,7 +49,6 @@ struct ResChain32Params {
   float out_div;
   float slope;
   int S, Mmin, NTO, ntiles, nblocks, Wp;  // filled by the launcher
-  int dbg;
 };
 
 // c1 / c2: npairs descriptors each.  max_waste_pct bounds the share of tile columns the chain's halo

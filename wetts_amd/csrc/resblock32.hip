@@ -33,7 +33,7 @@ struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };  // dword-
 // columns (c2 reads column c + tap*dil2); valid outputs are the middle columns [h2, NTC-h2).
 // (A first version kept the tile raw and applied leaky-relu at the B read: the two VALU ops in
 // front of every MFMA made it slower than two launches.)
-template <int C, bool DBG, bool RB2>
+template <int C, bool RB2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void resblock_pair32_kernel(const ResPair32Params p) {
   constexpr int WM = C / 32, WN = 4 / WM, NB = 4;
@@ -45,7 +45,6 @@ void resblock_pair32_kernel(const ResPair32Params p) {
 
   extern __shared__ __attribute__((aligned(16))) float smem_p[];
 
-  const int ab = DBG ? p.ablate : 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,7 +87,7 @@ void resblock_pair32_kernel(const ResPair32Params p) {
   for (int j = 0; j < NB; ++j) {
     const int col = wcol + 32 * j;
     const int t = RB2 ? n0 - h2 + col : n0 + col;
-    const bool ok = (RB2 ? t >= 0 : col < NTO) && t < p.T && !(DBG && (ab & 2));
+    const bool ok = (RB2 ? t >= 0 : col < NTO) && t < p.T;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float v = 0.f;
@@ -112,7 +111,7 @@ void resblock_pair32_kernel(const ResPair32Params p) {
           const int seg = lane + 64 * q;
           const int t = tx0 + 4 * seg;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (seg < ppr && !(DBG && (ab & 8))) {
+          if (seg < ppr) {
             if (t >= 0 && t + 3 < p.T) {
               const f4u u = *reinterpret_cast<const f4u*>(xr + t);
               v = make_float4(u.x, u.y, u.z, u.w);
@@ -178,7 +177,7 @@ void resblock_pair32_kernel(const ResPair32Params p) {
     // one (chunk, tap) iteration = two groups (hp = 0, 1): aa[0] / aa[1] without dynamic indexing
     auto group = [&](float4& areg, const float4* anext, const float* cur, const float* nxt) {
       const float4 av = areg;
-      if (!(DBG && (ab & 4))) areg = *anext;
+      areg = *anext;
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -186,12 +185,10 @@ void resblock_pair32_kernel(const ResPair32Params p) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) bv[(s + 1) & 1][j] = src[32 * j];
         __builtin_amdgcn_sched_barrier(0);
-        if (!(DBG && (ab & 16))) {
-          const float a = s == 0 ? av.x : s == 1 ? av.y : s == 2 ? av.z : av.w;
+        const float a = s == 0 ? av.x : s == 1 ? av.y : s == 2 ? av.z : av.w;
 #pragma unroll
-          for (int j = 0; j < NB; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[s & 1][j], acc[j], 0, 0, 0);
-        }
+        for (int j = 0; j < NB; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[s & 1][j], acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -243,8 +240,7 @@ void resblock_pair32_kernel(const ResPair32Params p) {
   for (int j = 0; j < NB; ++j) {
     const int col = wcol + 32 * j;
     const int t = RB2 ? n0 - h2 + col : n0 + col;
-    const bool ok = (RB2 ? (col >= h2 && col < NTC - h2 && t >= 0) : col < NTO) && t < p.T &&
-                    !(DBG && (ab & 2));
+    const bool ok = (RB2 ? (col >= h2 && col < NTC - h2 && t >= 0) : col < NTO) && t < p.T;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float v = RB2 ? acc[j][r] : rres[j][r];
@@ -270,7 +266,6 @@ void resblock_pair32_kernel(const ResPair32Params p) {
     for (int r = 0; r < 16; ++r) {
       float v = acc[j][r] + bia[r];
       if (dodiv) v = v / p.out_div;
-      if (DBG && (ab & 1) && v != 1.2345e30f) continue;
       ob[(int64_t)(co_blk + (r & 3) + 8 * (r >> 2) + 4 * half) * p.T + t] = v;
     }
   }
@@ -292,21 +287,15 @@ static int32_t launch_pair32(const ResPair32Params& p0, hipStream_t stream) {
   p.nblocks = (int)nb;
   const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);
   const size_t lds = (size_t)C * p.Wp * sizeof(float);
-  static bool attr_done[2] = {false, false};
-  const int dbg = p.ablate ? 1 : 0;
-  if (!attr_done[dbg]) {  // tiles above the default 64 KB dynamic-LDS limit
-    if (dbg)
-      WETTS_HIP_CHECK(hipFuncSetAttribute((const void*)resblock_pair32_kernel<C, true, RB2>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    else
-      WETTS_HIP_CHECK(hipFuncSetAttribute((const void*)resblock_pair32_kernel<C, false, RB2>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done[dbg] = true;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  static bool attr_done[64] = {};  // per device: tiles above the default 64 KB dynamic-LDS limit
+  if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+    WETTS_HIP_CHECK(hipFuncSetAttribute((const void*)resblock_pair32_kernel<C, RB2>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done[dev] = true;
   }
-  if (dbg)
-    hipLaunchKernelGGL((resblock_pair32_kernel<C, true, RB2>), dim3(grid), dim3(256), lds, stream, p);
-  else
-    hipLaunchKernelGGL((resblock_pair32_kernel<C, false, RB2>), dim3(grid), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((resblock_pair32_kernel<C, RB2>), dim3(grid), dim3(256), lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

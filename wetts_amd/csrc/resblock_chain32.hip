@@ -26,8 +26,6 @@
 // outputs, S = sum_{i>=1} h_i.  Positions outside [0, T) are written as zeros at every stage (each
 // conv pads ITS input).  Operation order and rounding points per output element equal the
 // conv-by-conv path (same packed weights, same group order), so results are bit-identical to it.
-#include <stdlib.h>
-
 #include "common.h"
 #include "resblock32.h"
 
@@ -136,12 +134,8 @@ void resblock_chain32_kernel(const ResChain32Params p) {
             const int seg = lane + 64 * q;
             st[r][q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (seg < ppr) {
-              if (p.dbg & 1) {
-                st[r][q] = *reinterpret_cast<const float4*>(xb + (int64_t)(wave + 4 * (r0 + r)) * T + tx0 + 4 * seg);
-              } else {
-                const f32x4v u = __builtin_amdgcn_raw_buffer_load_b128(rsx, lane * 16 + q * 1024, soff, 0);
-                st[r][q] = make_float4(u.x, u.y, u.z, u.w);
-              }
+              const f32x4v u = __builtin_amdgcn_raw_buffer_load_b128(rsx, lane * 16 + q * 1024, soff, 0);
+              st[r][q] = make_float4(u.x, u.y, u.z, u.w);
             }
           }
         }
@@ -411,7 +405,6 @@ static int32_t launch_chain(ResChain32Params p, hipStream_t stream) {
   // the staged window starts on a 16-byte boundary only if rows do
   WETTS_REQUIRE(p.T % 4 == 0 && ((uintptr_t)p.x & 15) == 0, "chain kernel needs 16-byte aligned rows");
   p.nblocks = (int)nb;
-  { const char* e = getenv("WETTS_CHAIN_DBG"); p.dbg = e ? atoi(e) : 0; }
   const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);
   const size_t lds = (size_t)C * p.Wp * sizeof(float);
   int dev = 0;
