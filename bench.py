@@ -56,8 +56,8 @@ def parse_args():
                          "SURVEY 8e: each rank buckets its length-sorted shard)")
     ap.add_argument("--decoder-dtype", default=None, choices=["f32", "bf16", "f16"],
                     help="HiFi-GAN arithmetic; the headline metric is quoted at f32")
-    ap.add_argument("--flow-dtype", default="f32", choices=["f32", "bf16"],
-                    help="arithmetic of the flow's WN convs and the text encoder's FFN convs")
+    ap.add_argument("--flow-dtype", default=None, choices=["f32", "bf16", "f16"],
+                    help="arithmetic of the flow's WaveNet layers (wetts_set_flow_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2, help="utterances in the CPU sample")
     # secondary mode: streaming (chunked decoder) latency at B = 1 instead of the throughput step
@@ -176,17 +176,17 @@ def stream_bench(args):
 PRESETS = {
     # configs[1]: Baker v1, B = 16 x 128 phonemes, fp32, 22.05 kHz, single speaker
     "baker": dict(model="v1", batch=16, phonemes=128, ragged=False, n_speakers=1, sr=22050,
-                  decoder_dtype="f32", tag="BASELINE.json configs[1]"),
+                  decoder_dtype="f32", flow_dtype="f32", tag="BASELINE.json configs[1]"),
     # configs[2]: multilingual v3, B = 64, bf16, two speakers (baker + ljspeech, multilingual/run.sh:23-27)
     "multilingual": dict(model="v3", batch=64, phonemes=128, ragged=False, n_speakers=2, sr=16000,
-                         decoder_dtype="bf16", tag="BASELINE.json configs[2]"),
+                         decoder_dtype="bf16", flow_dtype="bf16", tag="BASELINE.json configs[2]"),
     # configs[3]: AISHELL-3 v1 (examples/aishell-3/configs/v1.json: baker v1 at sampling_rate 44100),
     # 218-row speaker table, 64 ragged utterances per GPU (512 over 8 GPUs)
     "aishell3": dict(model="v1", batch=64, phonemes=128, ragged=True, n_speakers=218, sr=44100,
-                     decoder_dtype="f32", tag="BASELINE.json configs[3]"),
+                     decoder_dtype="f32", flow_dtype="f32", tag="BASELINE.json configs[3]"),
     # configs[4]: builder-defined 48 kHz stress shape (no such reference recipe), fp16
     "stress48k": dict(model="stress48k", batch=16, phonemes=128, ragged=False, n_speakers=1,
-                      sr=48000, decoder_dtype="f16", tag="BASELINE.json configs[4]"),
+                      sr=48000, decoder_dtype="f16", flow_dtype="f16", tag="BASELINE.json configs[4]"),
 }
 
 
@@ -272,6 +272,7 @@ def main():
     phonemes = args.phonemes or pre["phonemes"]
     ragged = args.ragged or pre["ragged"]
     ddtype = args.decoder_dtype or pre["decoder_dtype"]
+    fdtype = args.flow_dtype or (pre["flow_dtype"] if not args.decoder_dtype else "f32")
     n_speakers = args.speakers or pre["n_speakers"]
     sr = pre["sr"] if not args.model else config.SAMPLING_RATES[mname]
     n_vocab = 256  # synthetic phone table
@@ -297,8 +298,8 @@ def main():
     net.load_blob(blob)
     if ddtype != "f32":
         net.set_decoder_dtype(ddtype)
-    if args.flow_dtype != "f32":
-        net.set_flow_dtype(args.flow_dtype)
+    if fdtype != "f32":
+        net.set_flow_dtype(fdtype)
 
     # ---- inputs: global utterance list, LPT-dealt to ranks, resident on the device
     total = batch * world
@@ -455,13 +456,13 @@ def main():
     backend = dist.get_backend() if world > 1 else "none"
     observed_world = dist.get_world_size() if world > 1 else 1
     prec = ("fp32" if ddtype == "f32" else ddtype + " decoder") + \
-        ("" if args.flow_dtype == "f32" else f" + {args.flow_dtype} flow/encoder convs")
+        ("" if fdtype == "f32" else f" + {fdtype} flow WaveNet layers")
     out = {
         "metric": "audio samples/sec + RTF @22.05 kHz, VITS-Baker, 1/2/4/8 MI355X",
         "value": value, "unit": "samples/s", "n_gpus": observed_world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if ddtype == "f32" and args.flow_dtype == "f32" else
+        "dtype": "f32" if ddtype == "f32" and fdtype == "f32" else
                  f"{prec} (f32 accumulate)",
         "data": "synthetic (seeded phoneme ids, seeded random-init weights, ~6.5 frames/phoneme, "
                 "Philox noise drawn on the device)",

@@ -230,6 +230,13 @@ int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_st
 #define WETTS_DECODER_UNFUSED 0x10
 int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision);
 
+/* Arithmetic of the flow's WaveNet layers (modules.py:60-87: in_layers k = 5, the gate, res_skip 1x1,
+ * the residual / skip update): 0 = float32 (default, the parity-gated path), 1 = bfloat16,
+ * 2 = IEEE half activations / weights with f32 accumulation and an f32 skip sum; pre / post /
+ * cond_layer convs, the coupling and everything else stay f32.  BASELINE.json configs[2] ("bf16")
+ * precision for the part of the step that dominates at B = 64.  Weights are re-packed on first use. */
+int32_t wetts_set_flow_precision(const wetts_model_t* m, int32_t precision);
+
 /* a15 monotonic_align.maximum_path (utils/monotonic_align.py:6-57).  Needs no model.
  *   neg_cent [B,Ty,Tx] float32 (not modified), t_ys / t_xs int32[B] (the mask sums the
  *   reference derives at :16-17), path [B,Ty,Tx] int32 (zero-filled then the 1s written),

@@ -296,9 +296,36 @@ def wn(W, pre, x, x_mask, g, hidden, n_layers, k):
     return out * x_mask
 
 
-def flow_reverse(W, cfg, z_p, y_mask, g):
+def wn_16bit_sim(W, pre, x, x_mask, g, hidden, n_layers, k, dtype):
+    """Numerics spec of the 16-bit WaveNet mode (wetts_set_flow_precision): the graph of `wn` with
+    the in_layers / res_skip weights and every activation between the element-wise steps rounded to
+    the 16-bit type, f32 accumulation, f32 bias / conditioning adds before the one rounding per
+    stored value, the skip sum kept in f32."""
+    q = lambda t: t.to(dtype).to(torch.float32)
+    out = torch.zeros_like(x)
+    gc = conv1d(W, pre + ".cond_layer", g) if g is not None else None
+    x = q(x)
+    for i in range(n_layers):
+        x_in = F.conv1d(x, q(W[f"{pre}.in_layers.{i}.weight"]), W[f"{pre}.in_layers.{i}.bias"],
+                        padding=(k - 1) // 2)
+        if gc is not None:
+            x_in = x_in + gc[:, i * 2 * hidden:(i + 1) * 2 * hidden]
+        x_in = q(x_in)
+        acts = q(torch.tanh(x_in[:, :hidden]) * torch.sigmoid(x_in[:, hidden:]))
+        rs = q(F.conv1d(acts, q(W[f"{pre}.res_skip_layers.{i}.weight"]),
+                        W[f"{pre}.res_skip_layers.{i}.bias"]))
+        if i < n_layers - 1:
+            x = q((x + rs[:, :hidden]) * x_mask)
+            out = out + rs[:, hidden:]
+        else:
+            out = out + rs
+    return out * x_mask
+
+
+def flow_reverse(W, cfg, z_p, y_mask, g, wn_dtype=None):
     """ResidualCouplingTransformersBlock.forward(reverse=True): reversed [(RCL, Flip) x n]
-    (flows.py:442-449); RCL reverse with mean_only (flows.py:494-513)."""
+    (flows.py:442-449); RCL reverse with mean_only (flows.py:494-513).  wn_dtype (torch.bfloat16 /
+    torch.float16): the 16-bit WaveNet numerics spec instead of the f32 graph."""
     H, I = cfg["hidden_channels"], cfg["inter_channels"]
     half = I // 2
     x = z_p
@@ -319,7 +346,11 @@ def flow_reverse(W, cfg, z_p, y_mask, g):
                                   cfg["flow_kernel_size"])
         else:
             h = conv1d(W, pre + ".pre", x0) * y_mask
-        h = wn(W, pre + ".enc", h, y_mask, g, H, cfg["flow_wn_layers"], cfg["flow_kernel_size"])
+        if wn_dtype is None:
+            h = wn(W, pre + ".enc", h, y_mask, g, H, cfg["flow_wn_layers"], cfg["flow_kernel_size"])
+        else:
+            h = wn_16bit_sim(W, pre + ".enc", h, y_mask, g, H, cfg["flow_wn_layers"],
+                             cfg["flow_kernel_size"], wn_dtype)
         m = conv1d(W, pre + ".post", h) * y_mask
         x1 = (x1 - m) * y_mask
         x = torch.cat([x0, x1], 1)

@@ -235,3 +235,39 @@ def test_fused_resblock_pair_bit_identical(dtype, L, cname):
     net.set_decoder_dtype(torch.float32)
     assert a.shape == b.shape and np.isfinite(a).all()
     assert np.array_equal(a, b), f"max |diff| {np.abs(a - b).max()}"
+
+
+@pytest.mark.parametrize("name,dtype", [("v3_b3x128", torch.bfloat16), ("v3_b3x128", torch.float16),
+                                        ("v1_b4x128", torch.bfloat16)])
+def test_flow_16bit_mode_matches_its_numerics_spec(name, dtype):
+    """16-bit WaveNet layers of the flow (wetts_set_flow_precision; BASELINE configs[2] precision for
+    the part of the step that dominates at B = 64): against oracle.wn_16bit_sim (same rounding
+    points, f32 accumulation) and, loosely, against the reference's f32 z.  The alignment (duration
+    path) must not move at all; switching back restores the exact-f32 flow."""
+    from oracle import vits_oracle as vo
+    case = util.load_case(name)
+    net, cfg, W = _model(case)
+    cd = util.cfg_dict(cfg)
+    ns, ls, nsw = [float(v) for v in case["scales"]]
+    args = dict(sid=util.t(case["sid"]).cuda(), noise_scale=ns, length_scale=ls, noise_scale_w=nsw,
+                eps_w=util.t(case["eps_w"]).cuda(), eps_z=util.t(case["eps_z"]).cuda())
+    x, xl = util.t(case["x"]).cuda(), util.t(case["x_lengths"]).cuda()
+    o32, attn32, ym32, (z32, zp32, _, _) = net.infer(x, xl, **args)
+    net.set_flow_dtype(dtype)
+    o16, attn16, ym16, (z16, zp16, _, _) = net.infer(x, xl, **args)
+    net.set_flow_dtype(torch.float32)
+    o_back, *_ = net.infer(x, xl, **args)
+    assert torch.equal(attn16, attn32) and torch.equal(ym16, ym32) and torch.equal(zp16, zp32)
+    assert torch.equal(o_back, o32)
+    sid = util.t(case["sid"])
+    g = torch.nn.functional.embedding(sid, W["emb_g.weight"]).unsqueeze(-1) if cfg.n_speakers > 0 else None
+    with torch.no_grad():
+        spec = vo.flow_reverse(W, cd, zp32.cpu(), ym32.cpu(), g, wn_dtype=dtype)
+    valid = ym32.cpu().bool().expand_as(z16.cpu()).numpy()
+    r_spec = util.rel_rms(z16.cpu().numpy()[valid], spec.numpy()[valid])
+    r_f32 = util.rel_rms(z16.cpu().numpy()[valid], case["z"][valid])
+    r_audio = util.rel_rms(o16.cpu().numpy(), case["audio"])
+    print(name, dtype, "z vs 16-bit spec", r_spec, "z vs reference f32", r_f32, "audio vs reference", r_audio)
+    tol_spec, tol_f32 = (1e-2, 3e-2) if dtype == torch.bfloat16 else (2e-3, 5e-3)
+    assert np.isfinite(z16.cpu().numpy()).all()
+    assert r_spec < tol_spec and r_f32 < tol_f32

@@ -1,10 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_b.json 2>gpurun_out/bench_b.err; python - <<'PY'
-import json; d=json.load(open('gpurun_out/bench_b.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['launches'], d['roofline']['avg_launch_ms'], d['roofline']['mrf_share_of_step'])
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "flow_16bit or v3_b3x128 or tiny_sdp_b3" 2>&1 | tail -12
+for fd in f32 bf16; do python bench.py --config multilingual --flow-dtype $fd --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_cfg2_flow_$fd.json 2>gpurun_out/bench_cfg2.err; python - <<PY
+import json; d=json.load(open('gpurun_out/bench_cfg2_flow_$fd.json')); print("$fd", d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['mrf_share_of_step'], d['dtype'])
 PY
-python bench.py --config aishell3 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_cfg3_aishell3.json 2>/dev/null; python - <<'PY'
-import json; d=json.load(open('gpurun_out/bench_cfg3_aishell3.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['config']['workload'])
-PY
-WETTS_TUNE="bogus=1" python bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
+done

@@ -20,6 +20,8 @@ struct ConvBParams {
   float in_slope;
   const unsigned short* wpk;
   const float* bias;
+  const float* bias_b;   // [B][bias_b_stride] per-utterance f32 bias (speaker conditioning) or null
+  int64_t bias_b_stride;
   int M, N, ktaps, dil, pad, off_lo, span, nchunks;
   unsigned short* out;  // [B][Tout][cout]
   int64_t o_bs;
@@ -62,6 +64,17 @@ void free_packed_bf16(PackedConvB* pc);
 int32_t launch_conv_bf16(const PackedConvB& pc, ConvBParams p, hipStream_t stream);
 int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, int f16,
                        hipStream_t s);
+// ---- 16-bit WaveNet layers of the flow (wn16.hip), channel-last like the 16-bit decoder ----------
+// acts[row][c] = tanh(xin[row][c]) * sigmoid(xin[row][H + c])   (commons.py:98-105), rows = B*T
+int32_t k_gate_cl16(const unsigned short* xin, unsigned short* acts, int64_t rows, int H, int f16,
+                    hipStream_t s);
+// WN residual / skip update (modules.py:79-86) on channel-last tensors: h 16-bit, skip f32;
+// mask [rows] (B*T).  rs has 2H channels (H when `last`).
+int32_t k_wn_update_cl16(const unsigned short* rs, unsigned short* h, float* skip, const float* mask,
+                         int last, int first, int64_t rows, int H, int f16, hipStream_t s);
+// f32 channel-last [B][T][C] -> f32 channel-first [B][C][T]
+int32_t k_cl32_to_cf32(const float* x, float* out, int B, int C, int T, hipStream_t s);
+
 int32_t k_conv_post_bf16(const unsigned short* x, const float* w, int k, int B, int C, int T,
                          float* out, int f16, hipStream_t s);
 

@@ -282,6 +282,11 @@ void conv_bf16_kernel(const ConvBParams p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r)
     bia[r] = p.bias ? p.bias[co_blk + 16 * (r >> 3) + 8 * half + (r & 7)] : 0.f;
+  if (p.bias_b) {
+    const float* bb = p.bias_b + (int64_t)b * p.bias_b_stride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bia[r] += bb[co_blk + 16 * (r >> 3) + 8 * half + (r & 7)];
+  }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int col = wcol0 + 32 * j + (lane & 31);

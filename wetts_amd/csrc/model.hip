@@ -416,6 +416,9 @@ struct wetts_model {
   int chain_pair_kmax = 3;        // WETTS_CHAIN_PAIR_KMAX: ... and pairs with at most this many taps at any width
   int fuse2_waste_pct = 15;       // ResBlock2 chains: max % of tile columns lost to c2's halo at C = 32
                                   // (HBM-bound, +6..30 %); half of it at C >= 64 (profiles/r01_conv32_rb2_chain.txt)
+  // 16-bit WaveNet layers of the flow (opt-in, wetts_set_flow_precision): weights packed on first use
+  mutable int flow_precision = 0;  // 0 = f32, 1 = bf16, 2 = f16
+  mutable std::vector<std::vector<PackedConvB>> b_wn_in, b_wn_rs;  // [flow][layer]
   mutable std::vector<PackedConvB> b_ups;
   mutable std::vector<std::vector<PackedConvB>> b_c1, b_c2;  // per resblock
   // device status word the stage calls OR their WETTS_STATUS_* bits into (wetts_set_status_word)
@@ -739,6 +742,9 @@ static int64_t ws_flow(const wetts_config_t* c, int B, int Ty) {
   const int64_t H = c->hidden_channels, I = c->inter_channels;
   int64_t n = 2 * A256(B * I * Ty) + 3 * A256(B * H * Ty) + 2 * A256(B * 2 * H * Ty) +
               A256(B * (I / 2) * Ty) + A256(B * 2 * H * c->flow_wn_layers);
+  // 16-bit WN mode: channel-last h, gate output (H), in_layer / res_skip outputs (2H) at 16 bit,
+  // the skip sum at f32 channel-last
+  n += 2 * align_up(B * H * Ty * 2, 256) + 2 * align_up(B * 2 * H * Ty * 2, 256) + A256(B * H * Ty);
   if (c->transformer_flows != 0) {
     const int64_t He = c->transformer_flows == 1 ? I / 2 : H;
     // the T*T score region only exists on the three-kernel attention path; the flash kernel (every
@@ -903,6 +909,8 @@ void wetts_destroy(wetts_model_t* m) {
   for (auto& pc : m->b_ups) free_packed_bf16(&pc);
   for (auto& v : m->b_c1) for (auto& pc : v) free_packed_bf16(&pc);
   for (auto& v : m->b_c2) for (auto& pc : v) free_packed_bf16(&pc);
+  for (auto& v : m->b_wn_in) for (auto& pc : v) free_packed_bf16(&pc);
+  for (auto& v : m->b_wn_rs) for (auto& pc : v) free_packed_bf16(&pc);
   for (int j = 0; j < WETTS_MAX_RB_KERNELS; ++j) {
     if (m->aux_stream[j]) (void)hipStreamDestroy(m->aux_stream[j]);
     if (m->ev_chain[j]) (void)hipEventDestroy(m->ev_chain[j]);
@@ -1226,6 +1234,42 @@ int32_t wetts_length_regulate(const wetts_model_t* m, const float* stats, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+namespace wetts {
+// 16-bit copies of the WN conv weights (in_layers k = 5, res_skip 1x1) of every coupling layer
+static int32_t pack_flow_bf16(const wetts_model* m, hipStream_t s) {
+  const int f16 = m->flow_precision == 2 ? 1 : 0;
+  if (!m->b_wn_in.empty() && m->b_wn_in[0][0].f16 == f16) return WETTS_OK;
+  for (auto& v : m->b_wn_in) for (auto& pc : v) free_packed_bf16(&pc);
+  for (auto& v : m->b_wn_rs) for (auto& pc : v) free_packed_bf16(&pc);
+  const wetts_config_t* c = &m->cfg;
+  const int H = c->hidden_channels, NL = c->flow_wn_layers, fk = c->flow_kernel_size;
+  m->b_wn_in.assign(c->flow_n_flows, std::vector<PackedConvB>(NL));
+  m->b_wn_rs.assign(c->flow_n_flows, std::vector<PackedConvB>(NL));
+  for (int f = 0; f < c->flow_n_flows; ++f) {
+    const std::string p = S("flow.flows.%d", 2 * f);
+    for (int i = 0; i < NL; ++i) {
+      WETTS_TRY(pack_conv_weight_bf16(m->T(p + S(".enc.in_layers.%d.weight", i)),
+                                      m->T(p + S(".enc.in_layers.%d.bias", i)), 2 * H, H, fk, 1,
+                                      (fk - 1) / 2, 0, 0, f16, s, &m->b_wn_in[f][i]));
+      const int rs = (i < NL - 1) ? 2 * H : H;
+      WETTS_TRY(pack_conv_weight_bf16(m->T(p + S(".enc.res_skip_layers.%d.weight", i)),
+                                      m->T(p + S(".enc.res_skip_layers.%d.bias", i)), rs, H, 1, 1, 0,
+                                      0, 0, f16, s, &m->b_wn_rs[f][i]));
+    }
+  }
+  return WETTS_OK;
+}
+}  // namespace wetts
+
+int32_t wetts_set_flow_precision(const wetts_model_t* m, int32_t precision) {
+  WETTS_REQUIRE(m != nullptr, "null model");
+  WETTS_REQUIRE(precision >= 0 && precision <= 2, "precision must be 0 (f32), 1 (bf16) or 2 (f16)");
+  WETTS_REQUIRE(precision == 0 || m->cfg.hidden_channels % 32 == 0,
+                "the 16-bit flow needs hidden_channels to be a multiple of 32");
+  m->flow_precision = precision;
+  return WETTS_OK;
+}
+
 int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float* y_mask,
                            const float* g, int32_t B, int32_t Ty, float* z_out, void* workspace,
                            int64_t workspace_bytes, void* stream) {
@@ -1244,6 +1288,13 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
   float* rs = ws.take<float>((int64_t)B * 2 * H * Ty);
   float* mm = ws.take<float>((int64_t)B * (I / 2) * Ty);
   float* gl = ws.take<float>((int64_t)B * 2 * H * NL);
+  unsigned short* h16 = ws.take<unsigned short>((int64_t)B * H * Ty);
+  unsigned short* acts16 = ws.take<unsigned short>((int64_t)B * H * Ty);
+  unsigned short* xin16 = ws.take<unsigned short>((int64_t)B * 2 * H * Ty);
+  unsigned short* rs16 = ws.take<unsigned short>((int64_t)B * 2 * H * Ty);
+  float* skip_cl = ws.take<float>((int64_t)B * H * Ty);
+  const int wn16 = m->flow_precision;  // 0: f32 WN, 1 / 2: bf16 / f16 convs and activations
+  if (wn16) WETTS_TRY(pack_flow_bf16(m, s));
   float *tx0 = nullptr, *txm = nullptr, *tq = nullptr, *tk = nullptr, *tv = nullptr,
         *tatt = nullptr, *ty = nullptr, *thid = nullptr, *txb = nullptr, *tsc = nullptr;
   if (c->transformer_flows != 0) {
@@ -1296,6 +1347,35 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
     const bool use_g = has_g(c) && g;
     if (use_g)
       WETTS_TRY(k_cond_linear(g, fw.cond_w, fw.cond_b, B, 2 * H * NL, c->gin_channels, gl, s));
+    if (wn16) {
+      // WN at 16 bit (wn16.hip): channel-last activations, f32 accumulation, the skip sum in f32
+      const int f16 = wn16 == 2 ? 1 : 0;
+      const int64_t rows = (int64_t)B * Ty;
+      WETTS_TRY(k_cf32_to_cl16(h, h16, B, H, Ty, f16, s));
+      for (int i = 0; i < NL; ++i) {
+        const bool last = (i == NL - 1);
+        ConvBParams p1;
+        memset(&p1, 0, sizeof(p1));
+        p1.x = h16; p1.x_bs = (int64_t)H * Ty; p1.Cin = H; p1.Tin = Ty; p1.in_act = IN_NONE;
+        p1.out = xin16; p1.o_bs = (int64_t)2 * H * Ty; p1.cout = 2 * H; p1.Tout = Ty;
+        p1.out_div = 1.f; p1.B = B;
+        if (use_g) {
+          p1.bias_b = gl + (int64_t)i * 2 * H;
+          p1.bias_b_stride = (int64_t)2 * H * NL;
+        }
+        WETTS_TRY(launch_conv_bf16(m->b_wn_in[f][i], p1, s));
+        WETTS_TRY(k_gate_cl16(xin16, acts16, rows, H, f16, s));
+        const int RC = last ? H : 2 * H;
+        ConvBParams p2;
+        memset(&p2, 0, sizeof(p2));
+        p2.x = acts16; p2.x_bs = (int64_t)H * Ty; p2.Cin = H; p2.Tin = Ty; p2.in_act = IN_NONE;
+        p2.out = rs16; p2.o_bs = (int64_t)RC * Ty; p2.cout = RC; p2.Tout = Ty;
+        p2.out_div = 1.f; p2.B = B;
+        WETTS_TRY(launch_conv_bf16(m->b_wn_rs[f][i], p2, s));
+        WETTS_TRY(k_wn_update_cl16(rs16, h16, skip_cl, y_mask, last ? 1 : 0, i == 0 ? 1 : 0, rows, H, f16, s));
+      }
+      WETTS_TRY(k_cl32_to_cf32(skip_cl, skip, B, H, Ty, s));
+    } else
     for (int i = 0; i < NL; ++i) {
       {
         ConvParams p = conv_io(h, H, Ty, xin, 2 * H, B);  // x_in = in_layer(h) (+ g_l)

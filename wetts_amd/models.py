@@ -116,6 +116,18 @@ class SynthesizerTrn:
                        "set_decoder_precision")
         return self
 
+    def set_flow_dtype(self, dtype):
+        """Arithmetic of the flow's WaveNet layers: torch.float32 (default, parity-gated),
+        torch.bfloat16 or torch.float16 (16-bit activations / weights, f32 accumulation, f32 skip
+        sum).  BASELINE.json configs[2] precision for the flow."""
+        prec = {torch.float32: 0, "f32": 0, "fp32": 0, torch.bfloat16: 1, "bf16": 1,
+                torch.float16: 2, "f16": 2, "fp16": 2}[dtype]
+        self._flow_precision = prec
+        if self._handle is not None:
+            _lib.check(_lib.load().wetts_set_flow_precision(self._handle, prec),
+                       "set_flow_precision")
+        return self
+
     def blob_layout(self):
         return checkpoint.blob_layout(self.cfg)
 
@@ -158,6 +170,9 @@ class SynthesizerTrn:
             if getattr(self, "_decoder_precision", 0):
                 _lib.check(lib.wetts_set_decoder_precision(h, self._decoder_precision),
                            "set_decoder_precision")
+            if getattr(self, "_flow_precision", 0):
+                _lib.check(lib.wetts_set_flow_precision(h, self._flow_precision),
+                           "set_flow_precision")
 
     def _destroy(self):
         if self._handle is not None:
