@@ -54,8 +54,9 @@ def parse_args():
     ap.add_argument("--buckets", type=int, default=0,
                     help="padded sub-batches per step (0 = auto: 1 for equal lengths, 4 for ragged batches; "
                          "SURVEY 8e: each rank buckets its length-sorted shard)")
-    ap.add_argument("--decoder-dtype", default=None, choices=["f32", "bf16", "f16"],
-                    help="HiFi-GAN arithmetic; the headline metric is quoted at f32")
+    ap.add_argument("--decoder-dtype", default=None, choices=["f32", "bf16", "f16", "uint8"],
+                    help="HiFi-GAN arithmetic; the headline metric is quoted at f32 (uint8 = the "
+                         "export_onnx.py --quant dynamic-quantisation variant)")
     ap.add_argument("--flow-dtype", default=None, choices=["f32", "bf16", "f16"],
                     help="arithmetic of the flow's WaveNet layers (wetts_set_flow_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

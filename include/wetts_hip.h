@@ -227,8 +227,24 @@ int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_st
  * first use.  At 16 bit every ResBlock1 (c1, c2) pair with <= 128 channels runs as ONE fused
  * kernel (intermediate kept in LDS); OR-ing WETTS_DECODER_UNFUSED into `precision` forces the
  * two-launch form, which is bit-identical (diagnostics / tests). */
+/* 3 = uint8 dynamic quantisation: the decoder graph `export_onnx.py --quant` leaves behind
+ * (wetts/vits/export_onnx.py:149-157, onnxruntime quantize_dynamic with QUInt8 weights): every Conv1d
+ * becomes DynamicQuantizeLinear (per launch, per tensor) -> ConvInteger (int32 accumulate, here on
+ * v_mfma_i32_32x32x32_i8) -> scale + bias; ConvTranspose1d and the element-wise ops stay float32.
+ * onnxruntime is absent from the reference tree, so this variant's parity is unpinned (the oracle
+ * restates the published operator definitions). */
+#define WETTS_DECODER_UINT8_DYNAMIC 3
 #define WETTS_DECODER_UNFUSED 0x10
 int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision);
+
+/* One Conv1d ("same" padding) as a dynamically quantised ONNX graph computes it -- the building block
+ * of WETTS_DECODER_UINT8_DYNAMIC, exposed for validation: DynamicQuantizeLinear over the whole x,
+ * per-tensor uint8 weights, ConvInteger on the int8 matrix cores, dequantise + bias.  x [B,Cin,T],
+ * w [Cout,Cin,k] (natural PyTorch layout), bias [Cout] or NULL, out [B,Cout,T]; all device pointers.
+ * Unlike the stage calls it allocates (packed weights, scratch) and synchronises the stream. */
+int32_t wetts_dynamic_quant_conv1d(const float* x, const float* w, const float* bias, int32_t B,
+                                   int32_t Cin, int32_t Cout, int32_t k, int32_t dilation,
+                                   int32_t padding, int32_t T, float* out, void* stream);
 
 /* Arithmetic of the flow's WaveNet layers (modules.py:60-87: in_layers k = 5, the gate, res_skip 1x1,
  * the residual / skip update): 0 = float32 (default, the parity-gated path), 1 = bfloat16,

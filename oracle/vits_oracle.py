@@ -500,6 +500,77 @@ def hifigan_bf16sim(W, cfg, z, g):
 
 
 # ------------------------------------------------------------------------------------------------
+# uint8 dynamic quantisation of the decoder's Conv1d nodes (wetts/vits/export_onnx.py:149-157:
+# onnxruntime.quantization.quantize_dynamic(..., weight_type=QuantType.QUInt8)).  onnxruntime 1.13.1 is
+# fetched by the reference's CMake and is NOT in the reference tree, so this is a restatement of the
+# published operator definitions -- PARITY UNPINNED:
+#   weights      quant_utils.compute_scale_zp / quantize_nparray: per tensor, asymmetric uint8,
+#                range widened to include 0, scale = (max - min) / 255, zp = round(0 - min / scale),
+#                w_q = clip(round(w / scale + zp), 0, 255)
+#   activations  ONNX DynamicQuantizeLinear: the same formulas over the WHOLE input tensor, per call,
+#                rounding half to even, saturating
+#   contraction  ONNX ConvInteger: int32 sum (x_q - z_x)(w_q - z_w), zero padding = z_x
+#   output       Cast(float) * (s_x * s_w) + bias            (the graph quantize_dynamic emits)
+# ConvTranspose nodes are left in float32 by dynamic quantisation.
+# ------------------------------------------------------------------------------------------------
+def _dq_params(t):
+    mn = torch.clamp(t.min(), max=0.0).to(torch.float32)
+    mx = torch.clamp(t.max(), min=0.0).to(torch.float32)
+    scale = (mx - mn) / torch.tensor(255.0, dtype=torch.float32)
+    if not (scale > 0):
+        scale = torch.tensor(1.0, dtype=torch.float32)
+    zp = torch.clamp(torch.round((0.0 - mn) / scale), 0, 255)  # torch.round: half to even
+    return scale, zp
+
+
+def dynamic_quant_conv1d(x, w, b, dilation=1, padding=0):
+    """One quantised Conv node.  Exact integer arithmetic (float64 holds the int32 sums exactly)."""
+    sx, zx = _dq_params(x)
+    xq = torch.clamp(torch.round(x / sx) + zx, 0, 255)
+    sw, zw = _dq_params(w)
+    wq = torch.clamp(torch.round(w / sw) + zw, 0, 255)
+    acc = F.conv1d((xq - zx).double(), (wq - zw).double(), None, dilation=dilation, padding=padding)
+    y = acc.to(torch.float32) * (sx * sw)
+    if b is not None:
+        y = y + b.view(1, -1, 1)
+    return y
+
+
+def hifigan_uint8_dynamic(W, cfg, z, g):
+    """Generator.forward as the dynamically quantised ONNX graph computes it."""
+    def qc(name, x, dilation=1, padding=0):
+        return dynamic_quant_conv1d(x, W[name + ".weight"], W.get(name + ".bias"), dilation, padding)
+    x = qc("dec.conv_pre", z, padding=3)
+    if g is not None:
+        x = x + qc("dec.cond", g)
+    nk = len(cfg["resblock_kernel_sizes"])
+    for i, (u, uk) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
+        x = F.leaky_relu(x, LRELU_SLOPE)
+        x = F.conv_transpose1d(x, W[f"dec.ups.{i}.weight"], W[f"dec.ups.{i}.bias"], stride=u,
+                               padding=(uk - u) // 2)
+        xs = None
+        for j, (k, dils) in enumerate(zip(cfg["resblock_kernel_sizes"],
+                                          cfg["resblock_dilation_sizes"])):
+            n = i * nk + j
+            r = x
+            nd = 3 if cfg["resblock"] == 1 else 2
+            for d, dil in enumerate(dils[:nd]):
+                if cfg["resblock"] == 1:
+                    t = qc(f"dec.resblocks.{n}.convs1.{d}", F.leaky_relu(r, LRELU_SLOPE), dil,
+                           (k * dil - dil) // 2)
+                    t = qc(f"dec.resblocks.{n}.convs2.{d}", F.leaky_relu(t, LRELU_SLOPE), 1, (k - 1) // 2)
+                else:
+                    t = qc(f"dec.resblocks.{n}.convs.{d}", F.leaky_relu(r, LRELU_SLOPE), dil,
+                           (k * dil - dil) // 2)
+                r = t + r
+            xs = r if xs is None else xs + r
+        x = xs / nk
+    x = F.leaky_relu(x)
+    x = dynamic_quant_conv1d(x, W["dec.conv_post.weight"], None, 1, 3)
+    return torch.tanh(x)
+
+
+# ------------------------------------------------------------------------------------------------
 # infer  (model/models.py:228-280)
 # ------------------------------------------------------------------------------------------------
 def infer(W, cfg, x_ids, x_lengths, sid=None, noise_scale=1.0, length_scale=1.0,

@@ -271,3 +271,58 @@ def test_flow_16bit_mode_matches_its_numerics_spec(name, dtype):
     tol_spec, tol_f32 = (1e-2, 3e-2) if dtype == torch.bfloat16 else (2e-3, 5e-3)
     assert np.isfinite(z16.cpu().numpy()).all()
     assert r_spec < tol_spec and r_f32 < tol_f32
+
+
+@pytest.mark.parametrize("B,Cin,Cout,k,dil,T", [(2, 32, 32, 3, 1, 300), (3, 192, 64, 7, 1, 77),
+                                                (1, 64, 64, 11, 5, 1000), (2, 256, 1, 1, 1, 1),
+                                                (2, 40, 96, 5, 3, 129), (1, 32, 1, 7, 1, 513)])
+def test_dynamic_quant_conv1d_is_bit_exact_to_its_restatement(B, Cin, Cout, k, dil, T):
+    """The uint8 dynamic-quantisation conv (qconv_u8.hip, v_mfma_i32_32x32x32_i8) against the exact-integer
+    restatement of DynamicQuantizeLinear -> ConvInteger -> scale + bias (oracle.dynamic_quant_conv1d):
+    integer work => array_equal.  Covers channel counts that need padding to 32, a single output channel
+    (conv_post), T = 1 (the speaker conditioning conv), tiles straddling the sequence end, dilation."""
+    from oracle import vits_oracle as vo
+    from wetts_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 1000 + Cin + k)
+    x = torch.randn(B, Cin, T, generator=g) * 0.7 + 0.1
+    w = torch.randn(Cout, Cin, k, generator=g) / (Cin * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    pad = (k - 1) * dil // 2
+    with torch.no_grad():
+        ref = vo.dynamic_quant_conv1d(x, w, b, dilation=dil, padding=pad)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    out = torch.empty(B, Cout, T, device="cuda")
+    _lib.check(lib.wetts_dynamic_quant_conv1d(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), B, Cin, Cout, k, dil,
+                                              pad, T, _lib.ptr(out), None), "dynamic_quant_conv1d")
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize("name", ["tiny_sdp_b3", "v1_b2", "v3_b2"])
+def test_hifigan_uint8_dynamic_variant(name):
+    """Decoder precision 3 = the `export_onnx.py --quant` graph (export_onnx.py:149-157): every Conv1d
+    dynamically quantised to uint8, ConvTranspose1d in f32.  Against the oracle's restatement of that
+    graph (parity with onnxruntime itself is unpinned: ORT is not in the reference tree).  The integer
+    convs are exact; the f32 ConvTranspose1d in between differs from ATen's by round-off, which can move
+    a value across a quantisation step now and then => a small tolerance, and a loose one vs f32."""
+    from oracle import vits_oracle as vo
+    case = util.load_case(name)
+    net, cfg, W = _model(case)
+    cd = util.cfg_dict(cfg)
+    z = util.t(case["z"]) * util.t(case["y_mask"])
+    sid = util.t(case["sid"])
+    g = torch.nn.functional.embedding(sid, W["emb_g.weight"]).unsqueeze(-1)
+    with torch.no_grad():
+        spec = vo.hifigan_uint8_dynamic(W, cd, z, g).numpy()
+        f32 = vo.hifigan(W, cd, z, g).numpy()
+    net.set_decoder_dtype(torch.uint8)
+    got = net.hifigan(z.cuda(), g[:, :, 0].cuda()).cpu().numpy()
+    net.set_decoder_dtype(torch.float32)
+    back = net.hifigan(z.cuda(), g[:, :, 0].cuda()).cpu().numpy()
+    r_spec, r_f32 = util.rel_rms(got, spec), util.rel_rms(got, f32)
+    print(name, "uint8 vs restatement", r_spec, "uint8 vs f32", r_f32, "restatement vs f32", util.rel_rms(spec, f32))
+    assert got.shape == f32.shape and np.isfinite(got).all()
+    assert r_spec < 5e-3 and r_f32 < 0.15
+    assert util.rms(back - f32) < ABS_RMS_OURS

@@ -99,6 +99,7 @@ SIGNATURES = {
     "wetts_hifigan": (_I32, [_P, _P, _I64, _I64, _P, _I64, _P, _I32, _I32, _P, _P, _I64, _P]),
     "wetts_set_decoder_precision": (_I32, [_P, _I32]),
     "wetts_set_flow_precision": (_I32, [_P, _I32]),
+    "wetts_dynamic_quant_conv1d": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "wetts_mas": (_I32, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _I64, _P]),
     "wetts_audio_to_int16": (_I32, [_P, _P, _I32, _I64, _P, _P]),
     "wetts_infer_workspace_bytes": (_I64, [_P, _I32, _I32, _I32]),

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "conv_bf16.h"
 #include "resblock32.h"
+#include "qconv_u8.h"
 #include "kernels.h"
 
 namespace wetts {
@@ -419,6 +420,10 @@ struct wetts_model {
   // 16-bit WaveNet layers of the flow (opt-in, wetts_set_flow_precision): weights packed on first use
   mutable int flow_precision = 0;  // 0 = f32, 1 = bf16, 2 = f16
   mutable std::vector<std::vector<PackedConvB>> b_wn_in, b_wn_rs;  // [flow][layer]
+  // uint8 dynamic-quantisation decoder (precision 3): Conv1d weights quantised on first use
+  mutable PackedQConv q_pre, q_cond, q_post;
+  mutable std::vector<std::vector<PackedQConv>> q_c1, q_c2;  // per resblock
+  mutable bool q_packed = false;
   mutable std::vector<PackedConvB> b_ups;
   mutable std::vector<std::vector<PackedConvB>> b_c1, b_c2;  // per resblock
   // device status word the stage calls OR their WETTS_STATUS_* bits into (wetts_set_status_word)
@@ -775,8 +780,15 @@ static int64_t ws_vocos(const wetts_config_t* c, int B, int L) {
 
 static int64_t ws_decoder(const wetts_config_t* c, int B, int L) {
   if (c->vocoder_type == 1) return ws_vocos(c, B, L);
-  return (3 + 3 * (int64_t)c->n_resblock_kernels) * A256(dec_max_elems(c, B, L)) +
-         A256((int64_t)B * c->upsample_initial_channel);
+  const int64_t f32need = (3 + 3 * (int64_t)c->n_resblock_kernels) * A256(dec_max_elems(c, B, L)) +
+                          A256((int64_t)B * c->upsample_initial_channel);
+  // uint8 variant: six stage-sized f32 buffers + the int8 image / channel sums of the widest input
+  int64_t lenmax = L;
+  for (int i = 0; i < c->n_upsamples; ++i) lenmax *= c->upsample_rates[i];
+  const int64_t u8need = 6 * A256(dec_max_elems(c, B, L)) + A256((int64_t)B * c->upsample_initial_channel) +
+                         align_up(dec_max_elems(c, B, L) + 32 * (int64_t)B * lenmax, 256) +
+                         align_up(4 * (int64_t)B * lenmax, 256) + 1024;
+  return f32need > u8need ? f32need : u8need;
 }
 
 }  // namespace wetts
@@ -911,6 +923,11 @@ void wetts_destroy(wetts_model_t* m) {
   for (auto& v : m->b_c2) for (auto& pc : v) free_packed_bf16(&pc);
   for (auto& v : m->b_wn_in) for (auto& pc : v) free_packed_bf16(&pc);
   for (auto& v : m->b_wn_rs) for (auto& pc : v) free_packed_bf16(&pc);
+  free_packed_qconv(&m->q_pre);
+  free_packed_qconv(&m->q_cond);
+  free_packed_qconv(&m->q_post);
+  for (auto& v : m->q_c1) for (auto& pc : v) free_packed_qconv(&pc);
+  for (auto& v : m->q_c2) for (auto& pc : v) free_packed_qconv(&pc);
   for (int j = 0; j < WETTS_MAX_RB_KERNELS; ++j) {
     if (m->aux_stream[j]) (void)hipStreamDestroy(m->aux_stream[j]);
     if (m->ev_chain[j]) (void)hipEventDestroy(m->ev_chain[j]);
@@ -1924,15 +1941,191 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
 }
 }  // namespace wetts
 
+namespace wetts {
+static int32_t pack_decoder_u8(const wetts_model* m, hipStream_t s) {
+  if (m->q_packed) return WETTS_OK;
+  const wetts_config_t* c = &m->cfg;
+  const int I = c->inter_channels, C0 = c->upsample_initial_channel;
+  const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
+  WETTS_TRY(pack_qconv_weight(m->T("dec.conv_pre.weight"), m->T("dec.conv_pre.bias"), C0, I, 7, 1, 3, s,
+                              &m->q_pre));
+  if (has_g(c))
+    WETTS_TRY(pack_qconv_weight(m->T("dec.cond.weight"), m->T("dec.cond.bias"), C0, c->gin_channels, 1,
+                                1, 0, s, &m->q_cond));
+  m->q_c1.assign(c->n_upsamples * nk, std::vector<PackedQConv>(nd));
+  m->q_c2.assign(c->n_upsamples * nk, std::vector<PackedQConv>(c->resblock == 1 ? nd : 0));
+  int ch = C0;
+  for (int i = 0; i < c->n_upsamples; ++i) {
+    ch /= 2;
+    for (int j = 0; j < nk; ++j) {
+      const int n = i * nk + j, k = c->resblock_kernel_sizes[j];
+      for (int d = 0; d < nd; ++d) {
+        const int dil = c->resblock_dilation_sizes[j][d];
+        if (c->resblock == 1) {
+          WETTS_TRY(pack_qconv_weight(m->T(S("dec.resblocks.%d.convs1.%d.weight", n, d)),
+                                      m->T(S("dec.resblocks.%d.convs1.%d.bias", n, d)), ch, ch, k, dil,
+                                      (k * dil - dil) / 2, s, &m->q_c1[n][d]));
+          WETTS_TRY(pack_qconv_weight(m->T(S("dec.resblocks.%d.convs2.%d.weight", n, d)),
+                                      m->T(S("dec.resblocks.%d.convs2.%d.bias", n, d)), ch, ch, k, 1,
+                                      (k - 1) / 2, s, &m->q_c2[n][d]));
+        } else {
+          WETTS_TRY(pack_qconv_weight(m->T(S("dec.resblocks.%d.convs.%d.weight", n, d)),
+                                      m->T(S("dec.resblocks.%d.convs.%d.bias", n, d)), ch, ch, k, dil,
+                                      (k * dil - dil) / 2, s, &m->q_c1[n][d]));
+        }
+      }
+    }
+  }
+  WETTS_TRY(pack_qconv_weight(m->T("dec.conv_post.weight"), nullptr, 1, ch, 7, 1, 3, s, &m->q_post));
+  m->q_packed = true;
+  return WETTS_OK;
+}
+
+static QConvIO qio(const float* x, int Cin, int T, float* out, int Cout, int B) {
+  QConvIO io;
+  memset(&io, 0, sizeof(io));
+  io.x = x; io.x_bs = (int64_t)Cin * T; io.x_cs = T;
+  io.out = out; io.o_bs = (int64_t)Cout * T; io.o_cs = T;
+  io.out_div = 1.f; io.B = B; io.T = T;
+  return io;
+}
+
+// Generator.forward as the graph `export_onnx.py --quant` leaves behind (export_onnx.py:149-157):
+// every Conv1d dynamically quantised to uint8 (qconv_u8.hip), ConvTranspose1d and the element-wise
+// ops in float32.
+static int32_t run_hifigan_u8(const wetts_model* m, const float* z, int64_t z_bs, int64_t z_cs,
+                              const float* y_mask, int64_t mask_stride, const float* g, int B, int L,
+                              float* audio, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+  const wetts_config_t* c = &m->cfg;
+  const int I = c->inter_channels, C0 = c->upsample_initial_channel;
+  WETTS_TRY(pack_decoder_u8(m, s));
+  const int64_t mx = dec_max_elems(c, B, L);
+  int64_t lenmax = L;
+  for (int i = 0; i < c->n_upsamples; ++i) lenmax *= c->upsample_rates[i];
+  Bump ws(workspace, workspace_bytes);
+  float* bx = ws.take<float>(mx);
+  float* bt = ws.take<float>(mx);
+  float* bs = ws.take<float>(mx);
+  float* fa = ws.take<float>(mx);
+  float* fb = ws.take<float>(mx);
+  float* ft = ws.take<float>(mx);
+  float* cond = ws.take<float>((int64_t)B * C0);
+  const int64_t qbytes = align_up(mx + 32 * (int64_t)B * lenmax, 256) + align_up(4 * (int64_t)B * lenmax, 256) + 512;
+  char* qs = ws.take<char>(qbytes);
+  if (!ws.ok) {
+    set_error("hifigan(uint8): workspace too small");
+    return WETTS_E_WORKSPACE;
+  }
+  const bool use_g = has_g(c) && g;
+  if (use_g) {  // cond(g): a Conv node like the others
+    QConvIO io = qio(g, c->gin_channels, 1, cond, C0, B);
+    WETTS_TRY(launch_qconv(m->q_cond, io, qs, qbytes, s));
+  }
+  {
+    QConvIO io = qio(z, I, L, bx, C0, B);
+    io.x_bs = z_bs;
+    io.x_cs = z_cs;
+    io.mask = y_mask;
+    io.mask_stride = mask_stride;
+    if (use_g) {
+      io.bias_b = cond;
+      io.bias_b_stride = C0;
+    }
+    WETTS_TRY(launch_qconv(m->q_pre, io, qs, qbytes, s));
+  }
+  int ch = C0, len = L;
+  float* x = bx;
+  const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
+  for (int i = 0; i < c->n_upsamples; ++i) {
+    const int u = c->upsample_rates[i];
+    {  // ConvTranspose1d stays float32 (dynamic quantisation does not touch it)
+      ConvParams p = conv_io(x, ch, len, bt, ch / 2, B);
+      p.in_act = IN_LRELU;
+      p.in_slope = 0.1f;
+      p.Tout = len * u;
+      p.o_bs = (int64_t)(ch / 2) * len * u;
+      p.o_cs = (int64_t)len * u;
+      WETTS_TRY(launch_conv(m->ups[i], p, s));
+    }
+    ch /= 2;
+    len *= u;
+    float* xsum = (x == bx) ? bs : bx;
+    for (int j = 0; j < nk; ++j) {
+      const int n = i * nk + j;
+      const float* rx = bt;
+      for (int d = 0; d < nd; ++d) {
+        const bool last_d = (d == nd - 1);
+        float* outp = last_d ? xsum : ((rx == fa) ? fb : fa);
+        const float* cin = rx;
+        if (c->resblock == 1) {
+          QConvIO i1 = qio(rx, ch, len, ft, ch, B);
+          i1.in_act = 1;
+          i1.in_slope = 0.1f;
+          WETTS_TRY(launch_qconv(m->q_c1[n][d], i1, qs, qbytes, s));
+          cin = ft;
+        }
+        QConvIO i2 = qio(cin, ch, len, outp, ch, B);
+        i2.in_act = 1;
+        i2.in_slope = 0.1f;
+        i2.res = rx;
+        i2.r_bs = (int64_t)ch * len;
+        i2.r_cs = len;
+        i2.accum = (last_d && j > 0) ? 1 : 0;
+        i2.out_div = (last_d && j == nk - 1) ? (float)nk : 1.f;
+        WETTS_TRY(launch_qconv(c->resblock == 1 ? m->q_c2[n][d] : m->q_c1[n][d], i2, qs, qbytes, s));
+        rx = outp;
+      }
+    }
+    x = xsum;
+  }
+  {  // leaky_relu (default slope 0.01) -> conv_post (no bias) -> tanh
+    QConvIO io = qio(x, ch, len, audio, 1, B);
+    io.in_act = 1;
+    io.in_slope = 0.01f;
+    WETTS_TRY(launch_qconv(m->q_post, io, qs, qbytes, s));
+    WETTS_TRY(k_tanh_inplace(audio, (int64_t)B * len, s));
+  }
+  return WETTS_OK;
+}
+}  // namespace wetts
+
+int32_t wetts_dynamic_quant_conv1d(const float* x, const float* w, const float* bias, int32_t B,
+                                   int32_t Cin, int32_t Cout, int32_t k, int32_t dilation, int32_t padding,
+                                   int32_t T, float* out, void* stream) {
+  WETTS_REQUIRE(x && w && out && B > 0 && Cin > 0 && Cout > 0 && k > 0 && T > 0, "bad argument");
+  WETTS_REQUIRE(2 * padding == (k - 1) * dilation, "only 'same' padding (output length T)");
+  hipStream_t s = (hipStream_t)stream;
+  PackedQConv pc;
+  int32_t rc = pack_qconv_weight(w, bias, Cout, Cin, k, dilation, padding, s, &pc);
+  void* scratch = nullptr;
+  const int64_t nb = qconv_scratch_bytes(B, Cin, T);
+  if (rc == WETTS_OK && hipMalloc(&scratch, (size_t)nb) != hipSuccess) {
+    set_error("dynamic_quant_conv1d: hipMalloc(%lld) failed", (long long)nb);
+    rc = WETTS_E_HIP;
+  }
+  if (rc == WETTS_OK) {
+    QConvIO io = qio(x, Cin, T, out, Cout, B);
+    rc = launch_qconv(pc, io, scratch, nb, s);
+  }
+  if (rc == WETTS_OK && hipStreamSynchronize(s) != hipSuccess) {
+    set_error("dynamic_quant_conv1d: kernel failed");
+    rc = WETTS_E_HIP;
+  }
+  if (scratch) (void)hipFree(scratch);
+  free_packed_qconv(&pc);
+  return rc;
+}
+
 int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision) {
   WETTS_REQUIRE(m != nullptr, "null model");
   const int unfused = (precision & WETTS_DECODER_UNFUSED) ? 1 : 0;
   precision &= ~WETTS_DECODER_UNFUSED;
-  WETTS_REQUIRE(precision >= 0 && precision <= 2, "precision must be 0 (f32), 1 (bf16) or 2 (f16)");
+  WETTS_REQUIRE(precision >= 0 && precision <= 3,
+                "precision must be 0 (f32), 1 (bf16), 2 (f16) or 3 (uint8 dynamic quantisation)");
   m->dec_unfused = unfused;
   WETTS_REQUIRE(precision == 0 || m->cfg.vocoder_type == 0,
                 "the 16-bit decoder mode covers the HiFi-GAN generator only");
-  if (precision >= 1) {
+  if (precision == 1 || precision == 2) {
     const wetts_config_t* c = &m->cfg;
     WETTS_REQUIRE((c->upsample_initial_channel >> c->n_upsamples) % 32 == 0,
                   "bf16 decoder needs every stage width to be a multiple of 32 channels");
@@ -1950,6 +2143,9 @@ int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_st
   if (m->cfg.vocoder_type == 1)
     return run_vocos(m, z, z_batch_stride, z_channel_stride, y_mask, mask_stride, g, B, L, audio,
                      workspace, workspace_bytes, (hipStream_t)stream);
+  if (m->dec_precision == 3)
+    return run_hifigan_u8(m, z, z_batch_stride, z_channel_stride, y_mask, mask_stride, g, B, L, audio,
+                          workspace, workspace_bytes, (hipStream_t)stream);
   if (m->dec_precision >= 1)
     return run_hifigan_bf16(m, z, z_batch_stride, z_channel_stride, y_mask, mask_stride, g, B, L,
                             audio, workspace, workspace_bytes, (hipStream_t)stream);

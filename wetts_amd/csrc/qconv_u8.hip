@@ -1,0 +1,380 @@
+// uint8 dynamic-quantisation variant of the decoder's Conv1d layers -- what
+// `export_onnx.py --quant` produces (wetts/vits/export_onnx.py:149-157: onnxruntime
+// quantize_dynamic(..., weight_type=QuantType.QUInt8)) and the reference's runtimes then execute:
+//   every Conv node  y = conv(x, w) + b   becomes
+//     x_q, s_x, z_x = DynamicQuantizeLinear(x)        per launch, over the WHOLE activation tensor
+//     acc           = ConvInteger(x_q, w_q, z_x, z_w) int32:  sum (x_q - z_x)(w_q - z_w)
+//     y             = float(acc) * (s_x * s_w) + b
+//   with w_q / s_w / z_w a per-tensor asymmetric uint8 quantisation of the (weight-norm folded)
+//   weight.  ConvTranspose nodes are not touched by dynamic quantisation and stay float32.
+// onnxruntime 1.13.1 is fetched by the reference's CMake and absent here, so parity for this variant is
+// UNPINNED: oracle/vits_oracle.py restates the published operator definitions (ONNX
+// DynamicQuantizeLinear / ConvInteger, onnxruntime/python/tools/quantization/quant_utils.py
+// compute_scale_zp / quantize_nparray) and the tests hold this file bit-exact to that restatement.
+//
+// On gfx950 the integer contraction runs on v_mfma_i32_32x32x32_i8.  Its operands are SIGNED bytes, so
+// both sides are shifted by 128 (xs = x_q - 128, ws = w_q - 128) and the zero points come back as
+// rank-one corrections in the epilogue:
+//   sum (xs + 128 - z_x)(ws + 128 - z_w)
+//     = sum xs ws + (128 - z_w) sum_K xs + (128 - z_x) sum_K ws + K (128 - z_x)(128 - z_w)
+// sum_K ws is a per-row constant computed at pack time; sum_K xs is a k-tap window over the per-frame
+// channel sums the quantise kernel emits.  Padded positions hold xs = z_x - 128 (a real zero).
+// Four launches per conv (reset, min/max, quantise, contract): a fidelity variant, HBM-bound passes
+// over f32 tensors plus an integer contraction -- not a speed path on this machine.
+#include "common.h"
+#include "qconv_u8.h"
+
+namespace wetts {
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// order-preserving float <-> uint encoding for atomicMin / atomicMax
+__device__ __forceinline__ unsigned f2ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+__device__ __forceinline__ float q_act(float v, int act, float slope) {
+  return act ? (v > 0.f ? v : v * slope) : v;
+}
+
+// DynamicQuantizeLinear parameters from the tensor's (min, max), ONNX operator spec:
+//   range adjusted to include 0; scale = (max - min) / 255; zp = saturate(round_half_even(-min / scale))
+__device__ __forceinline__ void dq_params(const QuantStats* st, float* scale, int* zp) {
+  float mn = fminf(ord2f(st->min_ord), 0.f), mx = fmaxf(ord2f(st->max_ord), 0.f);
+  float s = (mx - mn) / 255.f;
+  if (!(s > 0.f)) s = 1.f;  // an all-zero tensor
+  float z = rintf((0.f - mn) / s);
+  z = fminf(fmaxf(z, 0.f), 255.f);
+  *scale = s;
+  *zp = (int)z;
+}
+
+__global__ void qstats_reset_kernel(QuantStats* st, int* colsum, int64_t n_colsum) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    st->min_ord = 0xffffffffu;
+    st->max_ord = 0u;
+  }
+  if (i < n_colsum) colsum[i] = 0;
+}
+
+// min / max of act(x) over a [B][C][T] tensor (arbitrary batch / channel strides, optional [B][T] mask)
+__global__ __launch_bounds__(256) void qminmax_kernel(const float* __restrict__ x, int64_t x_bs,
+                                                      int64_t x_cs, const float* __restrict__ mask,
+                                                      int64_t mask_stride, int B, int C, int T, int act,
+                                                      float slope, QuantStats* st) {
+  const int64_t total = (int64_t)B * C * T;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const int c = (int)((i / T) % C);
+    const int b = (int)(i / ((int64_t)T * C));
+    float v = x[b * x_bs + c * x_cs + t];
+    if (mask) v *= mask[b * mask_stride + t];
+    v = q_act(v, act, slope);
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, off, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0 && mn <= mx) {
+    atomicMin(&st->min_ord, f2ord(mn));
+    atomicMax(&st->max_ord, f2ord(mx));
+  }
+}
+
+// x [B][C][T] f32 -> xs [B][T][Cp] int8 (x_q - 128, channel-last, channels padded to Cp with a real
+// zero) and colsum[b][t] = sum_c xs (over the Cp channels)
+__global__ __launch_bounds__(256) void qquantize_kernel(const float* __restrict__ x, int64_t x_bs,
+                                                        int64_t x_cs, const float* __restrict__ mask,
+                                                        int64_t mask_stride, int B, int C, int Cp, int T,
+                                                        int act, float slope, const QuantStats* st,
+                                                        signed char* __restrict__ xs, int* __restrict__ colsum) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, c8, t), t fastest
+  const int C8 = Cp / 8;
+  if (idx >= (int64_t)B * C8 * T) return;
+  const int t = (int)(idx % T);
+  const int c8 = (int)((idx / T) % C8);
+  const int b = (int)(idx / ((int64_t)T * C8));
+  float scale;
+  int zp;
+  dq_params(st, &scale, &zp);
+  const float mk = mask ? mask[b * mask_stride + t] : 1.f;
+  unsigned w[2] = {0u, 0u};
+  int sum = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e;
+    int q = zp;  // channel padding: (q - zp) = 0
+    if (c < C) {
+      float v = x[b * x_bs + c * x_cs + t] * mk;
+      v = q_act(v, act, slope);
+      float r = rintf(v / scale) + (float)zp;  // round half to even, then saturate
+      r = fminf(fmaxf(r, 0.f), 255.f);
+      q = (int)r;
+    }
+    const int sv = q - 128;
+    sum += sv;
+    w[e >> 2] |= (unsigned)(sv & 0xff) << (8 * (e & 3));
+  }
+  *reinterpret_cast<uint2*>(xs + ((int64_t)b * T + t) * Cp + c8 * 8) = make_uint2(w[0], w[1]);
+  atomicAdd(&colsum[(int64_t)b * T + t], sum);
+}
+
+// weight statistics -> (scale, zero point) per ORT's compute_scale_zp (range includes 0)
+__global__ void qweight_params_kernel(const QuantStats* st, QuantWeightParams* wp) {
+  if (threadIdx.x || blockIdx.x) return;
+  float mn = fminf(ord2f(st->min_ord), 0.f), mx = fmaxf(ord2f(st->max_ord), 0.f);
+  float s = (mx - mn) / 255.f;
+  if (!(s > 0.f)) s = 1.f;
+  float z = rintf(0.f - mn / s);
+  z = fminf(fmaxf(z, 0.f), 255.f);
+  wp->scale = s;
+  wp->zp = (int)z;
+}
+
+// w [Cout][Cin][k] f32 -> packed ws = w_q - 128 in MFMA A-fragment order
+//   [mt32][tap][cg (16-channel pairs: 32 channels)][lane][16 bytes]: lane -> row = mt32*32 + (lane&31),
+//   channels cg*32 + 16*(lane>>5) + e;  and rowsum[row] = sum_K ws (padded channels hold a real zero)
+__global__ void qpack_weight_kernel(const float* __restrict__ w, const QuantWeightParams* wp, int Cout,
+                                    int Cin, int Cp, int k, signed char* __restrict__ out,
+                                    int* __restrict__ rowsum, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte lane record
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  int64_t rest = idx >> 6;
+  const int CG = Cp / 32;
+  const int cg = (int)(rest % CG);
+  rest /= CG;
+  const int tap = (int)(rest % k);
+  const int mt32 = (int)(rest / k);
+  const int row = mt32 * 32 + (lane & 31);
+  const float scale = wp->scale;
+  const int zp = wp->zp;
+  unsigned o[4] = {0u, 0u, 0u, 0u};
+  int sum = 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int ci = cg * 32 + 16 * (lane >> 5) + e;
+    int q = zp;
+    if (row < Cout && ci < Cin) {
+      float r = rintf(w[((int64_t)row * Cin + ci) * k + tap] / scale) + (float)zp;
+      r = fminf(fmaxf(r, 0.f), 255.f);
+      q = (int)r;
+    }
+    const int sv = q - 128;
+    sum += sv;
+    o[e >> 2] |= (unsigned)(sv & 0xff) << (8 * (e & 3));
+  }
+  *reinterpret_cast<uint4*>(out + idx * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+  if (row < Cout) atomicAdd(&rowsum[row], sum);
+}
+
+// The integer contraction + dequantising epilogue.  Block = 4 waves; wave w owns m-block
+// (mtile*WM + w / WN) and NB 32-column blocks; B operands come straight from the channel-last int8
+// image (16 consecutive channels of one frame = one aligned 16-byte piece per lane), A operands from
+// the packed weights: no LDS, L1 / L2 carry the tap and tile overlap.
+template <int NB>
+__global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NT = 32 * NB;  // columns per wave (= per block: the 4 waves take 4 m-blocks)
+  const int ntiles = (p.T + NT - 1) / NT;
+  const int mtiles = (p.M + 127) / 128;
+  int bid = blockIdx.x;
+  const int ntile = bid % ntiles;
+  bid /= ntiles;
+  const int mtile = bid % mtiles;
+  const int b = bid / mtiles;
+  const int mt32 = mtile * 4 + wave;
+  const int row0 = mt32 * 32;
+  if (row0 >= p.M) return;
+  const int n0 = ntile * NT;
+  const int khalf = lane >> 5, l31 = lane & 31;
+  float sx;
+  int zx;
+  dq_params(p.stats, &sx, &zx);
+  const int padv = (zx - 128) & 0xff;
+  const unsigned padw = (unsigned)padv * 0x01010101u;
+  const int CG = p.Cp / 32;
+  const signed char* xb = p.xs + (int64_t)b * p.T * p.Cp;
+  const uint4* ab = reinterpret_cast<const uint4*>(p.wpk) + ((int64_t)mt32 * p.ktaps * CG) * 64 + lane;
+
+  i32x16 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0;
+
+  for (int tap = 0; tap < p.ktaps; ++tap) {
+    int tj[NB];
+    bool ok[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      tj[j] = n0 + 32 * j + l31 + tap * p.dil - p.pad;
+      ok[j] = tj[j] >= 0 && tj[j] < p.T;
+    }
+    for (int cg = 0; cg < CG; ++cg) {
+      const uint4 av = ab[((int64_t)tap * CG + cg) * 64];
+      const i32x4 a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        uint4 bv = make_uint4(padw, padw, padw, padw);
+        if (ok[j])
+          bv = *reinterpret_cast<const uint4*>(xb + (int64_t)tj[j] * p.Cp + cg * 32 + 16 * khalf);
+        const i32x4 bq = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq, acc[j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: zero-point corrections, dequantise, bias / residual / running sum, f32 store ------
+  const float sw = p.wparams->scale;
+  const int zw = p.wparams->zp;
+  const int cx = 128 - zx, cw = 128 - zw;
+  const int K = p.Cp * p.ktaps;
+  const float sprod = sx * sw;  // Mul(x_scale, w_scale) of the quantised graph, in f32
+  const int* csb = p.colsum + (int64_t)b * p.T;
+  float* ob = p.out + (int64_t)b * p.o_bs;
+  const float* rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
+  const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
+  const bool dodiv = p.out_div != 1.f;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int t = n0 + 32 * j + l31;
+    if (t >= p.T) continue;
+    int cs = 0;  // sum over the receptive field of the per-frame channel sums (padding = Cp * (zx-128))
+    for (int tap = 0; tap < p.ktaps; ++tap) {
+      const int tt = t + tap * p.dil - p.pad;
+      cs += (tt >= 0 && tt < p.T) ? csb[tt] : p.Cp * (zx - 128);
+    }
+    const int base = cw * cs + K * cx * cw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      if (row >= p.M) continue;
+      const int a = acc[j][r] + base + cx * p.rowsum[row];
+      float v = (float)a * sprod;
+      if (p.bias) v += p.bias[row];
+      if (bb) v += bb[row];
+      if (rb) v += rb[(int64_t)row * p.r_cs + t];
+      float* dst = ob + (int64_t)row * p.o_cs + t;
+      if (p.accum) v += *dst;
+      if (dodiv) v = v / p.out_div;
+      *dst = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+int32_t pack_qconv_weight(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k, int dil,
+                          int pad, hipStream_t s, PackedQConv* pc) {
+  pc->Cout = Cout;
+  pc->Cin = Cin;
+  pc->Cp = (Cin + 31) / 32 * 32;
+  pc->ktaps = k;
+  pc->dil = dil;
+  pc->pad = pad;
+  pc->bias = bias_dev;
+  const int mt32 = cdiv(Cout, 128) * 4, CG = pc->Cp / 32;
+  const int64_t recs = (int64_t)mt32 * k * CG * 64;
+  WETTS_HIP_CHECK(hipMalloc((void**)&pc->wpk, (size_t)recs * 16));
+  WETTS_HIP_CHECK(hipMalloc((void**)&pc->rowsum, (size_t)mt32 * 32 * sizeof(int)));
+  WETTS_HIP_CHECK(hipMalloc((void**)&pc->wparams, sizeof(QuantWeightParams)));
+  WETTS_HIP_CHECK(hipMalloc((void**)&pc->wstats, sizeof(QuantStats)));
+  hipLaunchKernelGGL(qstats_reset_kernel, dim3(cdiv(mt32 * 32, 256)), dim3(256), 0, s, pc->wstats,
+                     pc->rowsum, (int64_t)mt32 * 32);
+  WETTS_LAUNCH_CHECK();
+  const int64_t nw = (int64_t)Cout * Cin * k;
+  const int gridm = (int)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048);
+  hipLaunchKernelGGL(qminmax_kernel, dim3(gridm), dim3(256), 0, s, w_dev, (int64_t)0, (int64_t)0,
+                     (const float*)nullptr, (int64_t)0, 1, 1, (int)nw, 0, 0.f, pc->wstats);
+  WETTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(qweight_params_kernel, dim3(1), dim3(64), 0, s, pc->wstats, pc->wparams);
+  WETTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(qpack_weight_kernel, dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, s, w_dev,
+                     pc->wparams, Cout, Cin, pc->Cp, k, pc->wpk, pc->rowsum, recs);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+void free_packed_qconv(PackedQConv* pc) {
+  if (pc->wpk) (void)hipFree(pc->wpk);
+  if (pc->rowsum) (void)hipFree(pc->rowsum);
+  if (pc->wparams) (void)hipFree(pc->wparams);
+  if (pc->wstats) (void)hipFree(pc->wstats);
+  pc->wpk = nullptr;
+  pc->rowsum = nullptr;
+  pc->wparams = nullptr;
+  pc->wstats = nullptr;
+}
+
+int64_t qconv_scratch_bytes(int B, int Cin, int T) {
+  const int64_t Cp = (Cin + 31) / 32 * 32;
+  return align_up((int64_t)B * T * Cp, 256) + align_up((int64_t)B * T * 4, 256) + 256;
+}
+
+int32_t launch_qconv(const PackedQConv& pc, QConvIO io, void* scratch, int64_t scratch_bytes,
+                     hipStream_t s) {
+  WETTS_REQUIRE(pc.wpk != nullptr, "quantised conv weight not packed");
+  const int B = io.B, T = io.T;
+  if ((int64_t)B * T == 0) return WETTS_OK;
+  WETTS_REQUIRE(scratch_bytes >= qconv_scratch_bytes(B, pc.Cin, T), "qconv: scratch too small");
+  char* sp = static_cast<char*>(scratch);
+  signed char* xs = reinterpret_cast<signed char*>(sp);
+  sp += align_up((int64_t)B * T * pc.Cp, 256);
+  int* colsum = reinterpret_cast<int*>(sp);
+  sp += align_up((int64_t)B * T * 4, 256);
+  QuantStats* st = reinterpret_cast<QuantStats*>(sp);
+  const int64_t ncs = (int64_t)B * T;
+  hipLaunchKernelGGL(qstats_reset_kernel, dim3((unsigned)((ncs + 255) / 256)), dim3(256), 0, s, st, colsum, ncs);
+  WETTS_LAUNCH_CHECK();
+  const int64_t nx = (int64_t)B * pc.Cin * T;
+  const int gridm = (int)((nx + 255) / 256 < 4096 ? (nx + 255) / 256 : 4096);
+  hipLaunchKernelGGL(qminmax_kernel, dim3(gridm), dim3(256), 0, s, io.x, io.x_bs, io.x_cs, io.mask,
+                     io.mask_stride, B, pc.Cin, T, io.in_act, io.in_slope, st);
+  WETTS_LAUNCH_CHECK();
+  const int64_t nq = (int64_t)B * (pc.Cp / 8) * T;
+  hipLaunchKernelGGL(qquantize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, io.x, io.x_bs,
+                     io.x_cs, io.mask, io.mask_stride, B, pc.Cin, pc.Cp, T, io.in_act, io.in_slope, st, xs,
+                     colsum);
+  WETTS_LAUNCH_CHECK();
+  QConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.xs = xs; p.colsum = colsum; p.stats = st;
+  p.wpk = pc.wpk; p.rowsum = pc.rowsum; p.wparams = pc.wparams; p.bias = pc.bias;
+  p.bias_b = io.bias_b; p.bias_b_stride = io.bias_b_stride;
+  p.M = pc.Cout; p.Cp = pc.Cp; p.ktaps = pc.ktaps; p.dil = pc.dil; p.pad = pc.pad; p.T = T; p.B = B;
+  p.out = io.out; p.o_bs = io.o_bs; p.o_cs = io.o_cs;
+  p.res = io.res; p.r_bs = io.r_bs; p.r_cs = io.r_cs;
+  p.accum = io.accum; p.out_div = io.out_div;
+  constexpr int NB = 4;
+  const int64_t blocks = (int64_t)cdiv(T, 32 * NB) * cdiv(pc.Cout, 128) * B;
+  WETTS_REQUIRE(blocks < (1ll << 31), "qconv grid too large");
+  hipLaunchKernelGGL((qconv_i8_kernel<NB>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+__global__ void tanh_inplace_kernel(float* x, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = tanhf(x[i]);
+}
+
+int32_t k_tanh_inplace(float* x, int64_t n, hipStream_t s) {
+  if (n <= 0) return WETTS_OK;
+  hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+}  // namespace wetts

@@ -107,7 +107,9 @@ class SynthesizerTrn:
         `fused=False` runs every ResBlock1 (c1, c2) pair as two conv launches instead of the fused
         LDS-resident kernel -- bit-identical, for diagnostics."""
         prec = {torch.float32: 0, "f32": 0, "fp32": 0, torch.bfloat16: 1, "bf16": 1,
-                torch.float16: 2, "f16": 2, "fp16": 2}[dtype]
+                torch.float16: 2, "f16": 2, "fp16": 2,
+                # the `export_onnx.py --quant` variant (export_onnx.py:149-157): uint8 dynamic quantisation
+                torch.uint8: 3, torch.quint8: 3, "uint8": 3, "u8": 3}[dtype]
         if not fused:
             prec |= 0x10  # WETTS_DECODER_UNFUSED
         self._decoder_precision = prec
