@@ -23,6 +23,17 @@
 namespace wetts {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int kBufRsrcDword3 = 0x00020000;  // gfx9 family raw buffer: 32-bit data format, no swizzle
+
+// max(x, slope*x) == (x > 0 ? x : slope*x) for 0 <= slope <= 1: two VALU ops instead of three
+// (v_max_f32 through asm: no canonicalising v_max x, x in front of it)
+__device__ __forceinline__ float lrelu2(float x, float slope) {
+  const float m = x * slope;
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m));
+  return r;
+}
 
 // ------------------------------------------------------------------------------------------
 // weight packing
@@ -120,7 +131,15 @@ void free_packed(PackedConv* pc) {
 // the extra resident wave hides the staging / A-fragment waits of the chunked loop.
 // (The ablation / experiment switches this kernel carried in round 1 are gone from the product; their
 // measurements are kept under profiles/r01_conv_ablation*.txt.)
-template <int MB, int NB, int WM, int WN, int EPI = 0, bool MRF = false>
+// FAST = 16-byte staging for plain convs (no mask, no channel flip, whole 16-channel chunks, rows that
+// start on 16-byte boundaries and hold a multiple of 4 samples): the f32 matrix pipe and the vector ALU
+// are ONE resource on gfx950 -- every VALU instruction of any wave on the SIMD costs the MFMA stream
+// ~4 cycles (profiles/r02_mfma_valu_coissue.txt) -- and the general staging path spends ~10 VALU per
+// element on addresses, bounds and selects.  FAST: buffer addressing (uniform descriptor + uniform row
+// offset + one lane offset + immediates: no vector address arithmetic), aligned 16-byte loads with one
+// in-range predicate per piece, leaky-relu as mul + max, ds_write_b128.  The staged window starts at
+// the 16-byte boundary at or below its first column; `sh` shifts the B-operand columns to match.
+template <int MB, int NB, int WM, int WN, int EPI = 0, bool MRF = false, bool FAST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB * NB >= 4 && WN < 4) ? 3 : 1)))
 void conv_mfma_kernel(const ConvParams p) {
   static_assert(WM * WN == 4, "4 waves per block");
@@ -147,27 +166,79 @@ void conv_mfma_kernel(const ConvParams p) {
   const int b = bid / mtiles;
 
   const int n0 = ntile * NT;
-  const int W = NT + p.span;
+  const int W = FAST ? ((NT + p.span + 3 + 3) & ~3) : NT + p.span;  // LDS row stride
   float* buf0 = smem;
   float* buf1 = smem + CK * W;
 
-  const float* xb = p.x + (int64_t)b * p.x_bs;
+  const float* xb = p.x + (int64_t)(FAST ? __builtin_amdgcn_readfirstlane(b) : b) * p.x_bs;
   const float* mrow = p.in_mask ? p.in_mask + (int64_t)b * p.in_mask_stride : nullptr;
 
-  // per-column staging info is chunk independent
+  // ---- FAST staging state -----------------------------------------------------------------------
+  constexpr int Q4 = FAST ? (NT + 125 + 3 + 255) / 256 : 1;  // 16-byte pieces per lane per row
+  const int tstart = (n0 + p.off_lo) & ~3;                   // first staged time (may be < 0)
+  const int sh = FAST ? ((n0 + p.off_lo) & 3) : 0;
+  const int W4 = (NT + p.span + sh + 3) >> 2;                 // pieces needed per row (<= W / 4)
+  const int t0c = tstart < 0 ? 0 : tstart;                    // the row offset stays non-negative
+  const int vbase = lane * 16 + (tstart - t0c) * 4;           // lane byte offset from (row, t0c)
+  bool okq[Q4];
+#pragma unroll
+  for (int q = 0; q < Q4; ++q) {
+    const int piece = lane + 64 * q, tp = tstart + 4 * piece;
+    okq[q] = piece < W4 && tp >= 0 && tp + 4 <= p.Tin;  // rows hold a multiple of 4 samples
+  }
+  const bool wrq_last = lane + 64 * (Q4 - 1) < W4;  // LDS: only the last piece column can be partial
+  __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0,
+      FAST ? __builtin_amdgcn_readfirstlane(((p.Cin - 1) * (int)p.x_cs + p.Tin) * 4) : 0, kBufRsrcDword3);
+  f32x4v stage4[RPW][Q4];
+  auto load_chunk4 = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int soff = __builtin_amdgcn_readfirstlane(((c * CK + wave + 4 * r) * (int)p.x_cs + t0c) * 4);
+#pragma unroll
+      for (int q = 0; q < Q4; ++q) {
+        stage4[r][q] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (okq[q]) stage4[r][q] = __builtin_amdgcn_raw_buffer_load_b128(rsx, vbase + q * 1024, soff, 0);
+      }
+    }
+  };
+  auto store_chunk4 = [&](float* buf) {
+    const bool lr = p.in_act == IN_LRELU;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      float* row = buf + (wave + 4 * r) * W + 4 * lane;
+#pragma unroll
+      for (int q = 0; q < Q4; ++q)
+        if (q < Q4 - 1 || wrq_last) {
+          f32x4v v = stage4[r][q];
+          if (lr) {
+            v.x = lrelu2(v.x, p.in_slope);
+            v.y = lrelu2(v.y, p.in_slope);
+            v.z = lrelu2(v.z, p.in_slope);
+            v.w = lrelu2(v.w, p.in_slope);
+          }
+          *reinterpret_cast<f32x4v*>(row + 256 * q) = v;
+        }
+    }
+  };
+
+  // ---- general staging: per-column info is chunk independent ----------------------------------------
   int tcol[MAXCI];
   float mcol[MAXCI];
+  if (!FAST) {
 #pragma unroll
-  for (int i = 0; i < MAXCI; ++i) {
-    int col = lane + 64 * i;
-    int t = n0 + p.off_lo + col;
-    bool ok = (col < W) && (t >= 0) && (t < p.Tin);
-    tcol[i] = ok ? t : -1;
-    mcol[i] = (ok && mrow) ? mrow[t] : 1.f;
+    for (int i = 0; i < MAXCI; ++i) {
+      int col = lane + 64 * i;
+      int t = n0 + p.off_lo + col;
+      bool ok = (col < W) && (t >= 0) && (t < p.Tin);
+      tcol[i] = ok ? t : -1;
+      mcol[i] = (ok && mrow) ? mrow[t] : 1.f;
+    }
   }
 
   float stage[RPW][MAXCI];
   auto load_chunk = [&](int c) {
+    if (FAST) return load_chunk4(c);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       int ci = c * CK + wave + 4 * r;
@@ -185,6 +256,7 @@ void conv_mfma_kernel(const ConvParams p) {
   // activation + mask are applied on the way into LDS, i.e. AFTER the chunk's MFMA work, so the
   // HBM latency of the staging loads is hidden behind the matrix cores instead of stalling here
   auto store_chunk = [&](float* buf) {
+    if (FAST) return store_chunk4(buf);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       float* row = buf + (wave + 4 * r) * W;
@@ -288,7 +360,7 @@ void conv_mfma_kernel(const ConvParams p) {
   __syncthreads();
 
   const int half = lane >> 5;
-  const int bcol0 = wn * (32 * NB) + (lane & 31) - p.pad - p.off_lo;
+  const int bcol0 = wn * (32 * NB) + (lane & 31) - p.pad - p.off_lo + sh;
   int g = 0;
   for (int c = 0; c < p.nchunks; ++c) {
     const float* cur = (c & 1) ? buf1 : buf0;
@@ -466,15 +538,28 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
   int64_t blocks = (int64_t)ntiles * mtiles * p.B;
   if (blocks <= 0) return WETTS_OK;
   WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
-  const size_t lds = (size_t)2 * kConvCK * (NT + p.span) * sizeof(float);
+  // FAST staging (see the kernel): plain input, 16-byte aligned rows holding a multiple of 4 samples
+  const bool fast = p.in_mask == nullptr && p.in_rev_base < 0 && (p.Cin % kConvCK) == 0 &&
+                    (p.x_cs & 3) == 0 && (p.x_bs & 3) == 0 && (p.Tin & 3) == 0 && p.span <= 125 &&
+                    (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 &&
+                    ((int64_t)p.Cin * p.x_cs) < (1ll << 29);
+  const size_t lds = (size_t)2 * kConvCK * (fast ? ((NT + p.span + 3 + 3) & ~3) : NT + p.span) * sizeof(float);
   const dim3 grid((unsigned)blocks), blk(256);
   // epilogue specialisation: residual / running sum are folded into the accumulator init
   // whenever there is no output activation or mask, which leaves "acc + bias [/ div]"
   const bool plain = p.up == 0 && p.out_act == OUT_NONE && p.out_mask == nullptr;
   if (p.up > 0 && p.up_shift >= 0 && p.out_act == OUT_NONE && !p.out_mask && !p.res && !p.accum &&
       !p.bias_b && p.out_div == 1.f) {
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 3, false>), grid, blk, lds, stream, p);
-  } else if (plain && p.tag) {  // MRF ResBlock launches: own kernel symbol
+    if (fast)
+      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 3, false, true>), grid, blk, lds, stream, p);
+    else
+      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 3, false>), grid, blk, lds, stream, p);
+  } else if (plain && p.tag && fast) {  // MRF ResBlock launches: own kernel symbol, FAST staging
+    if (p.out_div == 1.f)
+      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 1, true, true>), grid, blk, lds, stream, p);
+    else
+      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 2, true, true>), grid, blk, lds, stream, p);
+  } else if (plain && p.tag) {
     if (p.out_div == 1.f)
       hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 1, true>), grid, blk, lds, stream, p);
     else
