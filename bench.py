@@ -440,8 +440,9 @@ def main():
         roofline = {
             "kernel": ("conv_mfma_kernel (Vocos ConvNeXt pointwise GEMMs 512<->1536)"
                        if "vocos" in mname else
-                       "the MRF ResBlock conv class: conv_mfma_kernel (tag 1) + resblock_pair32_kernel "
-                       "+ resblock_chain32_kernel"),
+                       "the MRF ResBlock conv class: conv_mfma_kernel<.., MRF=true, FAST=true> (single "
+                       "convs) + resblock_chain32_kernel (whole ResBlock1 at C=32 k<=7 / C=64 k=3, single "
+                       "pairs at C=32 k=11 / C=128 k=3)"),
             "bound": "mfma", "achieved": mrf_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": mrf_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
             "traffic_unit": "HBM bytes per MRF launch (2*FETCH_SIZE+WRITE_SIZE)*1024, PMC",
@@ -456,7 +457,9 @@ def main():
         }
     backend = dist.get_backend() if world > 1 else "none"
     observed_world = dist.get_world_size() if world > 1 else 1
-    prec = ("fp32" if ddtype == "f32" else ddtype + " decoder") + \
+    prec = ("fp32" if ddtype == "f32" else
+            "uint8 dynamic-quantised decoder convs (int32 accumulate)" if ddtype == "uint8" else
+            ddtype + " decoder") + \
         ("" if fdtype == "f32" else f" + {fdtype} flow WaveNet layers")
     out = {
         "metric": "audio samples/sec + RTF @22.05 kHz, VITS-Baker, 1/2/4/8 MI355X",
@@ -464,7 +467,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if ddtype == "f32" and fdtype == "f32" else
-                 f"{prec} (f32 accumulate)",
+                 (prec if ddtype == "uint8" else f"{prec} (f32 accumulate)"),
         "data": "synthetic (seeded phoneme ids, seeded random-init weights, ~6.5 frames/phoneme, "
                 "Philox noise drawn on the device)",
         "rtf": elapsed / (samples / sr), "x_realtime": (samples / sr) / elapsed,

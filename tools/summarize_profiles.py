@@ -10,20 +10,22 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = "gpurun_out"
 shutil.copy(f"{src}/prof_stats/r_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
 shutil.copy(f"{src}/bench.json", f"profiles/{tag}_bench.json")
 import os
 for a, b in [("bench_bf16.json", "bench_bf16.json"), ("bench_f16.json", "bench_f16.json"),
-             ("prof_stats_bf16/r_kernel_stats.csv", "bf16_kernel_stats.csv"),
-             ("conv32_fused_pair.txt", "conv32_fused_pair.txt"),
+             ("bench_uint8.json", "bench_uint8.json"),
+             ("prof_stats_cfg2/r_kernel_stats.csv", "kernel_stats_cfg2_multilingual_bf16.csv"),
              ("conv16_fused_pair.txt", "conv16_fused_pair.txt"),
-             ("conv_microbench.txt", "conv_microbench.txt"),
+             ("conv_microbench.txt", "conv_microbench.txt"), ("resblock_chain.txt", "resblock_chain.txt"),
              ("stream_v1.json", "stream_v1.json"), ("stream_vits2_vocos.json", "stream_vits2_vocos.json"),
              ("bench_vocos.json", "bench_vocos.json"), ("bench_vits2_vocos.json", "bench_vits2_vocos.json"),
-             ("bench_cfg3_v3_b64_bf16.json",) * 2, ("bench_cfg3_v3_b64_f32.json",) * 2,
-             ("bench_cfg5_stress48k_f16.json",) * 2]:
+             ("bench_cfg2_multilingual_bf16.json",) * 2, ("bench_cfg2_multilingual_f32.json",) * 2,
+             ("bench_cfg3_aishell3.json",) * 2, ("bench_cfg4_stress48k_f16.json",) * 2,
+             ("bench_gpus2_refused.err",) * 2, ("bench_2rank_dryrun.json",) * 2,
+             ("pytest_gpu.log",) * 2]:
     if os.path.exists(f"{src}/{a}"):
         shutil.copy(f"{src}/{a}", f"profiles/{tag}_{b}")
 
@@ -56,10 +58,11 @@ for k in sorted(f, key=lambda k: -sum(f[k])):
         ent["avg_duration_ns"] = float(stats[k]["AverageNs"])
         ent["calls_in_stats_run"] = int(stats[k]["Calls"])
     out["kernels"][k] = ent
-    # dominant kernel class = the MRF ResBlock launches: the fused f32 pair kernel and the tagged
-    # conv_mfma instantiations (OPT bit 64, set only by run_hifigan's ResBlock launches)
-    mm = re.search(r"conv_mfma_kernel<\d+, \d+, \d+, \d+, \w+, \w+, \d+, (\d+)>", k)
-    is_dom = (mm and (int(mm.group(1)) & 64)) or "resblock_pair32_kernel" in k
+    # dominant kernel class = the MRF ResBlock launches: the chain / pair kernels and the conv_mfma
+    # instantiations whose MRF template flag is set (only run_hifigan's ResBlock launches set it)
+    mm = re.search(r"conv_mfma_kernel<\d+, \d+, \d+, \d+, \d+, (true|false)", k)
+    is_dom = (mm and mm.group(1) == "true") or "resblock_pair32_kernel" in k or \
+        "resblock_chain32_kernel" in k
     if is_dom:
         dom["launches"] += n
         dom["fetch_kb"] += sum(f[k])
