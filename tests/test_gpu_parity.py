@@ -220,7 +220,8 @@ def test_fused_resblock_pair_bit_identical(dtype, L, cname):
     case = util.load_case(cname)  # v1: ResBlock1 pairs; v3: ResBlock2 chains (RB2 instantiations)
     # also fuse launches too small to fill the chip, ResBlock2 shapes with a wide second halo, and whole
     # ResBlock1 chains whatever their halo costs (every fused kernel must be exercised here)
-    os.environ["WETTS_TUNE"] = "fuse_min_blocks=0,fuse2_waste_pct=100,chain_whole_pct=100,chain_whole_maxc=128"
+    os.environ["WETTS_TUNE"] = ("fuse_min_blocks=0,fuse2_waste_pct=100,chain_whole_pct=100,chain_whole_maxc=128,"
+                                "small_max_tiles=0")  # (conv_small_kernel sums K in another order)
     try:
         net, cfg, W = _model(case)
     finally:

@@ -142,6 +142,9 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream);
 
 int conv_variant();
 void set_conv_variant(int v);
+// conv_small.hip: the schedule for launches of at most ~one 64x64 tile per CU (B = 1 latency)
+int32_t launch_conv_small(const ConvParams& p, hipStream_t stream, bool* taken);
+void set_conv_small_max_tiles(int v);  // launches up to this many 64x64 tiles use it (0: never)
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }

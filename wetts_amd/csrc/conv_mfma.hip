@@ -598,6 +598,12 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
   } else {
     p.N = p.Tout;
   }
+  // launches of at most ~one small tile per CU are latency-, not throughput-bound: own schedule
+  if (conv_variant() == 0) {
+    bool taken = false;
+    WETTS_TRY(launch_conv_small(p, stream, &taken));
+    if (taken) return WETTS_OK;
+  }
   // tile selection: fill the chip first, then maximise per-wave register reuse
   const int64_t cols = (int64_t)p.N * p.B;
   // 1x4 wave tiles (one A fragment feeds four B fragments) measured 2-3 % faster than 2x2 at

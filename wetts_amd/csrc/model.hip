@@ -411,6 +411,7 @@ struct wetts_model {
   // ResBlock1 chain kernel (resblock_chain32.hip; profiles/r02_resblock_chain.txt): a whole ResBlock1
   // in one launch where the chain's halo discards at most this share of the tile (C = 32: k = 3, 7;
   // C = 64: k = 3), single pairs at C = 32 (every k) and for k <= chain_pair_kmax at any width
+  int small_max_tiles = 256;      // conv launches of at most this many 64x64 tiles use conv_small_kernel (0: off)
   int chain_whole_waste_pct = 15; // WETTS_CHAIN_WHOLE_PCT (0 disables whole-ResBlock launches)
   int chain_whole_maxc = 64;      // WETTS_CHAIN_WHOLE_MAXC
   int chain_pair_maxc = 32;       // WETTS_CHAIN_PAIR_MAXC: widest stage whose pairs all run on the chain kernel
@@ -867,7 +868,7 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
         {"fuse2_maxc", &m->fuse2_maxc},           {"fuse2_waste_pct", &m->fuse2_waste_pct},
         {"fuse_min_blocks", &m->fuse_min_blocks}, {"chain_whole_pct", &m->chain_whole_waste_pct},
         {"chain_whole_maxc", &m->chain_whole_maxc}, {"chain_pair_maxc", &m->chain_pair_maxc},
-        {"chain_pair_kmax", &m->chain_pair_kmax},
+        {"chain_pair_kmax", &m->chain_pair_kmax}, {"small_max_tiles", &m->small_max_tiles},
     };
     if (const char* env = getenv("WETTS_TUNE")) {
       std::string all(env);
@@ -891,6 +892,7 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
         pos = end + 1;
       }
     }
+    set_conv_small_max_tiles(m->small_max_tiles);  // process-wide (a diagnostics switch)
     if (m->mrf_streams < 1) m->mrf_streams = 1;
     if (m->mrf_streams > cfg->n_resblock_kernels) m->mrf_streams = cfg->n_resblock_kernels;
     (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
