@@ -61,6 +61,8 @@ def summarize(d):
         print(f"--- call with {len(g)} launches")
         for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
             print(f"{t/1e3:9.1f} us {c:4d} x {t/c/1e3:7.1f} us  {n}")
+        if os.environ.get("B1_SEQ"):
+            print("    sequence (us):", " ".join(f"{n.split('(')[0].split('::')[-1][:14]}:{(e-s)/1e3:.0f}" for s, e, n in g))
 
 
 if __name__ == "__main__":

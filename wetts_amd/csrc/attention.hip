@@ -120,7 +120,15 @@ __global__ void attn_relk_kernel(const float* __restrict__ q, const float* __res
   const float* qb = q + (int64_t)(bh / n_heads) * qbs + (int64_t)(bh % n_heads) * dk * T;
   const float* er = emb_rel_k + (int64_t)r * dk;
   float acc = 0.f;
-  for (int d = 0; d < dk; ++d) acc += (qb[(int64_t)d * T + i] / qdiv) * er[d];
+  int d0 = 0;
+  for (; d0 + 16 <= dk; d0 += 16) {  // 16 loads in flight, then their FMAs (same sum order as a plain loop)
+    float qv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) qv[u] = qb[(int64_t)(d0 + u) * T + i];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += (qv[u] / qdiv) * er[d0 + u];
+  }
+  for (int d = d0; d < dk; ++d) acc += (qb[(int64_t)d * T + i] / qdiv) * er[d];
   rel[((int64_t)bh * nrel + r) * T + i] = acc;
 }
 

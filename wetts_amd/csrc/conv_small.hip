@@ -27,10 +27,9 @@ namespace wetts {
 
 typedef float f32x16s __attribute__((ext_vector_type(16)));
 
-template <int KT, int SCH>
-__global__ __launch_bounds__(256) void conv_small_kernel(const ConvParams p) {
-  constexpr int CK = kConvCK;
-  constexpr int KG = 4;                 // K-groups = waves
+template <int KT, int SCH, int KG>
+__global__ __launch_bounds__(64 * KG) void conv_small_kernel(const ConvParams p) {
+  constexpr int CK = kConvCK;           // KG: K-groups = waves per block (4, 8 or 16)
   constexpr int NT = 32, MT = 32;
   constexpr int ROWS = CK * SCH;        // staged rows per stage
   constexpr int RP = ROWS / 2;          // row pairs: lanes 0-31 stage row 2i, lanes 32-63 row 2i+1
@@ -154,7 +153,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvParams p) {
     __builtin_amdgcn_wave_barrier();  // the wave's own LDS traffic is processed in order
   }
 
-  // the four partial tiles meet in LDS ([wave][r][lane]); wave w finishes accumulator rows 4w .. 4w+3
+  // the KG partial tiles meet in LDS ([wave][r][lane]); wave w finishes accumulator registers
+  // w*16/KG .. (w+1)*16/KG - 1, adding the partials in wave order
+  constexpr int FPW = 16 / KG;
   __syncthreads();  // every wave is done with its staging buffers
   {
     float* mine = smem + kg * 1024 + lane;
@@ -162,11 +163,14 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvParams p) {
     for (int r = 0; r < 16; ++r) mine[r * 64] = acc[r];
   }
   __syncthreads();
-  float fin[4];
+  float fin[FPW];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float* src = smem + (4 * kg + q) * 64 + lane;
-    fin[q] = ((src[0] + src[1024]) + src[2048]) + src[3072];
+  for (int q = 0; q < FPW; ++q) {
+    const float* src = smem + (FPW * kg + q) * 64 + lane;
+    float v = src[0];
+#pragma unroll
+    for (int w2 = 1; w2 < KG; ++w2) v += src[w2 * 1024];
+    fin[q] = v;
   }
 
   // ---- epilogue (generic: bias, per-utterance bias, activation, mask, residual, running sum, mean,
@@ -178,9 +182,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvParams p) {
   const int col = n0 + l32;
   if (col >= p.N) return;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    // accumulator register r = 4 kg + q holds row (r & 3) + 8 (r >> 2) + 4 half = q + 8 kg + 4 half
-    const int row = mtile * MT + q + 8 * kg + 4 * half;
+  for (int q = 0; q < FPW; ++q) {
+    const int r = FPW * kg + q;  // accumulator register r holds row (r & 3) + 8 (r >> 2) + 4 half
+    const int row = mtile * MT + (r & 3) + 8 * (r >> 2) + 4 * half;
     if (row >= p.M) continue;
     int co = row, t = col;
     if (p.up > 0) {
@@ -206,27 +210,47 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvParams p) {
 static int g_small_max_tiles = 256;
 void set_conv_small_max_tiles(int v) { g_small_max_tiles = v; }
 
-static size_t small_lds_bytes(int sch, int span) {
-  const size_t stage = (size_t)4 * 2 * kConvCK * sch * (32 + span) * sizeof(float);
-  const size_t red = (size_t)4 * 1024 * sizeof(float);
+static size_t small_lds_bytes(int sch, int span, int kg) {
+  const size_t stage = (size_t)kg * 2 * kConvCK * sch * (32 + span) * sizeof(float);
+  const size_t red = (size_t)kg * 1024 * sizeof(float);
   return stage > red ? stage : red;
 }
 
-template <int KT, int SCH>
-static int32_t launch_small_cfg(const ConvParams& p, hipStream_t stream) {
+template <int KT, int SCH, int KG>
+static int32_t launch_small_kg(const ConvParams& p, hipStream_t stream) {
   const int64_t blocks = (int64_t)cdiv(p.M, 32) * cdiv(p.N, 32) * p.B;
-  const size_t lds = small_lds_bytes(SCH, p.span);
+  const size_t lds = small_lds_bytes(SCH, p.span, KG);
   static bool attr_done[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (lds > 64 * 1024 && dev >= 0 && dev < 64 && !attr_done[dev]) {
-    WETTS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_kernel<KT, SCH>),
+    WETTS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_kernel<KT, SCH, KG>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
-  hipLaunchKernelGGL((conv_small_kernel<KT, SCH>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_small_kernel<KT, SCH, KG>), dim3((unsigned)blocks), dim3(64 * KG), lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
+}
+
+// Waves per block: a stage of a short-tap conv is well under a microsecond of matrix work, less than the
+// round trip of its staging loads, so a wave's time is (stages per wave) x (load latency): long
+// reductions get 8 or 16 waves (2 / 4 per SIMD) as long as the blocks do not fill the chip anyway and
+// LDS / registers allow (MAXKG: 8 for k >= 7).
+template <int KT, int SCH, int MAXKG>
+static int32_t launch_small_cfg(const ConvParams& p, hipStream_t stream) {
+  const int64_t blocks = (int64_t)cdiv(p.M, 32) * cdiv(p.N, 32) * p.B;
+  const int NS = p.nchunks / SCH;
+  int kg = 4;
+  if (NS >= 16 && blocks * 2 <= 512) kg = 8;
+  if (NS >= 32 && blocks * 4 <= 512) kg = 16;
+  if (kg > MAXKG) kg = MAXKG;
+  while (kg > 4 && small_lds_bytes(SCH, p.span, kg) > 128 * 1024) kg >>= 1;
+  if constexpr (MAXKG >= 16)
+    if (kg == 16) return launch_small_kg<KT, SCH, 16>(p, stream);
+  if constexpr (MAXKG >= 8)
+    if (kg == 8) return launch_small_kg<KT, SCH, 8>(p, stream);
+  return launch_small_kg<KT, SCH, 4>(p, stream);
 }
 
 // p: geometry filled by launch_conv.  *taken = false when the shape is not one this kernel handles
@@ -237,15 +261,15 @@ int32_t launch_conv_small(const ConvParams& p, hipStream_t stream, bool* taken) 
   if (g_small_max_tiles <= 0 || tiles64 <= 0 || tiles64 > g_small_max_tiles) return WETTS_OK;
   if (p.span > 128 || p.nchunks < 2) return WETTS_OK;
   const bool sch4 = p.ktaps == 1 && (p.nchunks % 4) == 0;
-  if (small_lds_bytes(sch4 ? 4 : 1, p.span) > 160 * 1024) return WETTS_OK;
+  if (small_lds_bytes(sch4 ? 4 : 1, p.span, 4) > 160 * 1024) return WETTS_OK;
   *taken = true;
   switch (p.ktaps) {
-    case 1: return sch4 ? launch_small_cfg<1, 4>(p, stream) : launch_small_cfg<1, 1>(p, stream);
-    case 2: return launch_small_cfg<2, 1>(p, stream);
-    case 3: return launch_small_cfg<3, 1>(p, stream);
-    case 5: return launch_small_cfg<5, 1>(p, stream);
-    case 7: return launch_small_cfg<7, 1>(p, stream);
-    case 11: return launch_small_cfg<11, 1>(p, stream);
+    case 1: return sch4 ? launch_small_cfg<1, 4, 8>(p, stream) : launch_small_cfg<1, 1, 16>(p, stream);
+    case 2: return launch_small_cfg<2, 1, 16>(p, stream);
+    case 3: return launch_small_cfg<3, 1, 16>(p, stream);
+    case 5: return launch_small_cfg<5, 1, 16>(p, stream);
+    case 7: return launch_small_cfg<7, 1, 8>(p, stream);
+    case 11: return launch_small_cfg<11, 1, 8>(p, stream);
     default: break;
   }
   *taken = false;

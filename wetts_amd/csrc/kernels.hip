@@ -115,11 +115,88 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   }
 }
 
+// The same block shape with the column held in registers (channel c = cg + 16 j, j < PER): one pass over
+// memory with all loads in flight at once instead of three passes of dependent-latency loops -- at B = 1
+// this kernel is launched 36 times per utterance and each pass is a round trip to L2
+// (profiles/r02_b1_anatomy.txt: 11.5 us per launch before).
+template <int PER>
+__global__ __launch_bounds__(256) void layernorm_reg_kernel(
+    const float* __restrict__ a, const float* __restrict__ add, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ res, const float* __restrict__ mask,
+    int gelu, int B, int C, int T, float eps, float* __restrict__ out) {
+  constexpr int TL = 16, CG = 16;
+  __shared__ float red[CG][TL + 1];
+  const int tl = threadIdx.x % TL, cg = threadIdx.x / TL;
+  const int tblocks = (T + TL - 1) / TL;
+  const int b = blockIdx.x / tblocks;
+  const int t = (blockIdx.x % tblocks) * TL + tl;
+  const bool ok = t < T;
+  const int64_t base = (int64_t)b * C * T + (ok ? t : 0);
+  float v[PER], rv[PER], gm[PER], bt[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int c = cg + CG * j;
+    const int cc = c < C ? c : 0;  // clamped: every load is issued, the value is dropped below
+    v[j] = a[base + (int64_t)cc * T];
+    if (add) v[j] += add[base + (int64_t)cc * T];
+    rv[j] = res ? res[base + (int64_t)cc * T] : 0.f;
+    gm[j] = gamma[cc];
+    bt[j] = beta[cc];
+  }
+  const float mk = (mask && ok) ? mask[(int64_t)b * T + t] : 1.f;
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) sum += (cg + CG * j < C) ? v[j] : 0.f;
+  red[cg][tl] = sum;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int q = 0; q < CG; ++q) tot += red[q][tl];
+  const float mean = tot / (float)C;
+  __syncthreads();
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const float d = v[j] - mean;
+    sq += (cg + CG * j < C) ? d * d : 0.f;
+  }
+  red[cg][tl] = sq;
+  __syncthreads();
+  tot = 0.f;
+#pragma unroll
+  for (int q = 0; q < CG; ++q) tot += red[q][tl];
+  const float rstd = 1.f / sqrtf(tot / (float)C + eps);
+  if (!ok) return;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int c = cg + CG * j;
+    if (c < C) {
+      float y = (v[j] - mean) * rstd * gm[j] + bt[j];
+      if (gelu) y = gelu_erf(y);
+      out[base + (int64_t)c * T] = (y + rv[j]) * mk;
+    }
+  }
+}
+
 int32_t k_layernorm(const float* a, const float* add, const float* gamma, const float* beta,
                     const float* res, const float* mask, int gelu, int B, int C, int T, float* out,
                     hipStream_t s) {
   if (B * T == 0) return WETTS_OK;
   int blocks = B * cdiv(T, 16);
+  if (C <= 512) {
+    const dim3 g(blocks), blk(256);
+    if (C <= 192)
+      hipLaunchKernelGGL(layernorm_reg_kernel<12>, g, blk, 0, s, a, add, gamma, beta, res, mask, gelu, B, C, T,
+                         1e-5f, out);
+    else if (C <= 256)
+      hipLaunchKernelGGL(layernorm_reg_kernel<16>, g, blk, 0, s, a, add, gamma, beta, res, mask, gelu, B, C, T,
+                         1e-5f, out);
+    else
+      hipLaunchKernelGGL(layernorm_reg_kernel<32>, g, blk, 0, s, a, add, gamma, beta, res, mask, gelu, B, C, T,
+                         1e-5f, out);
+    WETTS_LAUNCH_CHECK();
+    return WETTS_OK;
+  }
   hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, s, a, add, gamma, beta, res,
                      mask, gelu, B, C, T, 1e-5f, out);
   WETTS_LAUNCH_CHECK();
@@ -512,11 +589,64 @@ __global__ __launch_bounds__(256) void conv_post_tanh_kernel(const float* __rest
     if (t0 + o < T) out[(int64_t)b * T + t0 + o] = tanhf(acc[o]);
 }
 
+// conv_post for launches too small to fill the chip (a streaming window is 15 k samples = 15 blocks of
+// the kernel above, each thread walking all C channels: 63 us, profiles/r02_b1_anatomy.txt): 8 channel
+// groups x 32 samples per block, the k-tap windows of a thread's C/8 channels loaded up front, partial
+// sums combined through LDS in a fixed order.
+template <int K>
+__global__ __launch_bounds__(256) void conv_post_tanh_small_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ w, int B,
+                                                                   int C, int T, float* __restrict__ out) {
+  constexpr int TL = 32, CG = 8, MAXC = 8;  // C <= 64
+  __shared__ float red[CG][TL + 1];
+  const int tl = threadIdx.x % TL, cg = threadIdx.x / TL;
+  const int tblocks = (T + TL - 1) / TL;
+  const int b = blockIdx.x / tblocks;
+  const int t = (blockIdx.x % tblocks) * TL + tl;
+  constexpr int pad = (K - 1) / 2;
+  const float* xb = x + (int64_t)b * C * T;
+  float win[MAXC][K], wv[MAXC][K];
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const int c = cg + CG * j;
+    const int cc = c < C ? c : 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int tt = t - pad + i;
+      const bool ok = c < C && tt >= 0 && tt < T;
+      win[j][i] = xb[(int64_t)cc * T + (ok ? tt : 0)];
+      wv[j][i] = ok ? w[cc * K + i] : 0.f;
+    }
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j)
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const float v = win[j][i];
+      acc += wv[j][i] * (v > 0.f ? v : v * 0.01f);  // F.leaky_relu default slope, decoders.py:78
+    }
+  red[cg][tl] = acc;
+  __syncthreads();
+  if (cg == 0 && t < T) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < CG; ++q) tot += red[q][tl];
+    out[(int64_t)b * T + t] = tanhf(tot);
+  }
+}
+
 int32_t k_conv_post_tanh(const float* x, const float* w, int k, int B, int C, int T, float* out,
                          hipStream_t s) {
   WETTS_REQUIRE(k <= 15, "conv_post kernel size %d unsupported", k);
   int64_t n = (int64_t)B * ((T + 3) / 4);
   if (n == 0) return WETTS_OK;
+  if (k == 7 && C <= 64 && n <= 64 * 256) {  // fewer than 64 blocks of the kernel above
+    hipLaunchKernelGGL(conv_post_tanh_small_kernel<7>, dim3((unsigned)(B * cdiv(T, 32))), dim3(256), 0, s, x, w,
+                       B, C, T, out);
+    WETTS_LAUNCH_CHECK();
+    return WETTS_OK;
+  }
   hipLaunchKernelGGL(conv_post_tanh_kernel, grid1d(n, 256), dim3(256), (size_t)C * k * 4, s, x, w,
                      k, B, C, T, out);
   WETTS_LAUNCH_CHECK();
