@@ -494,8 +494,10 @@ def hifigan_bf16sim(W, cfg, z, g):
                 else:
                     r = _q(y)
         x = xs
-    x = F.leaky_relu(x)
-    x = F.conv1d(x, W["dec.conv_post.weight"], None, padding=3)
+    # conv_post like every other conv of this mode: 16-bit input (after the leaky-relu) and weights,
+    # f32 accumulation; tanh in f32
+    x = _q(F.leaky_relu(x))
+    x = F.conv1d(x, _q(W["dec.conv_post.weight"]), None, padding=3)
     return torch.tanh(x)
 
 

@@ -132,9 +132,10 @@ struct PackedConv {
 // Packs a natural-layout weight into MFMA fragment order on the device.
 //  transposed == 0: w is Conv1d [Cout][Cin][k]
 //  transposed == 1: w is ConvTranspose1d [Cin][Cout][k] with stride `up`
+// rev_in: input channels in reverse order (the flow's Flip folded into the weights of `pre`)
 int32_t pack_conv_weight(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
                          int dil, int pad, int transposed, int up, hipStream_t stream,
-                         PackedConv* out);
+                         PackedConv* out, int rev_in = 0);
 void free_packed(PackedConv* pc);
 
 // Launches the conv.  Fills geometry fields of `p` from `pc`; caller fills the I/O fields.

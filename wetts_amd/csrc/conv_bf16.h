@@ -10,6 +10,7 @@ struct PackedConvB {
   int M = 0, Cin = 0, Cout = 0, ktaps = 0, dil = 1, pad = 0, up = 0, up_pad = 0;
   int off_lo = 0, span = 0, nchunks = 0, CKB = 64;
   int f16 = 0;  // 0: bfloat16 storage, 1: IEEE half
+  int gate_h = 0;  // > 0: WN in_layer packed for the fused gate epilogue (rows paired tanh / sigmoid)
 };
 
 struct ConvBParams {
@@ -32,6 +33,18 @@ struct ConvBParams {
   int accum;
   float out_div;
   int B;
+  // fused WaveNet epilogues of the 16-bit flow (set by the caller; conv_bf16.hip):
+  //  epi_mode 1, in_layer packed with gate_h = H: out [B][T][H] = tanh(a) * sigmoid(b) of the rounded
+  //    conv outputs a = channel c, b = channel H + c (commons.py:98-105)
+  //  epi_mode 2, res_skip: h = (h + rs[:H]) * mask (16 bit, in place), skip (+)= rs[H:] in f32
+  //    (modules.py:79-86); `out` is not written
+  //  epi_mode 3, conv_post (k_conv_post_mfma16): out_f32 [B][T] = tanh(row 0)
+  int epi_mode;
+  float* out_f32;
+  unsigned short* wn_h;   // [B][T][H]
+  float* wn_skip;         // [B][T][H] f32
+  const float* wn_mask;   // [B][T]
+  int wn_H, wn_last, wn_first;
 };
 
 // fused ResBlock1 pair (resblock16.hip): out = (x + c2(lrelu(c1(lrelu(x)))) [+ out]) / div
@@ -59,7 +72,7 @@ int32_t launch_resblock2_chain16(const PackedConvB& c1, const PackedConvB& c2, R
 
 int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
                               int dil, int pad, int transposed, int up, int f16, hipStream_t stream,
-                              PackedConvB* out);
+                              PackedConvB* out, int gate_h = 0);
 void free_packed_bf16(PackedConvB* pc);
 int32_t launch_conv_bf16(const PackedConvB& pc, ConvBParams p, hipStream_t stream);
 int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, int f16,
@@ -77,5 +90,7 @@ int32_t k_cl32_to_cf32(const float* x, float* out, int B, int C, int T, hipStrea
 
 int32_t k_conv_post_bf16(const unsigned short* x, const float* w, int k, int B, int C, int T,
                          float* out, int f16, hipStream_t s);
+int32_t k_conv_post_mfma16(const PackedConvB& pc, const unsigned short* x, int B, int C, int T,
+                           float* out, hipStream_t s);
 
 }  // namespace wetts

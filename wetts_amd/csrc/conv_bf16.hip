@@ -28,7 +28,7 @@ namespace wetts {
 // ------------------------------------------------------------------------------------------
 __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
                                  int M, int Cin, int Cout, int k, int ktaps, int up, int transposed,
-                                 int CKB, int f16, int64_t total) {
+                                 int CKB, int f16, int gate_h, int64_t total) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int KS = CKB / 16;
@@ -47,6 +47,12 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __
   // one lane's 16 accumulator rows are two runs of 8 consecutive channels (16-byte stores)
   const int rho = lane & 31, q = rho >> 3, h = (rho >> 2) & 1;
   int row = mt32 * 32 + 16 * (q >> 1) + 8 * h + 4 * (q & 1) + (rho & 3);
+  if (gate_h > 0) {
+    // fused WN gate: m-block mt32 holds tanh channels 16 mt32 .. +15 (first run of a lane) and their
+    // sigmoid partners gate_h + the same (second run)
+    const int local = row - mt32 * 32, c = mt32 * 16 + (local & 15);
+    row = c < gate_h ? (local >> 4) * gate_h + c : M;
+  }
   float v = 0.f;
   if (row < M && ci < Cin) {
     if (!transposed) {
@@ -62,8 +68,9 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __
 
 int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
                               int dil, int pad, int transposed, int up, int f16, hipStream_t stream,
-                              PackedConvB* pc) {
+                              PackedConvB* pc, int gate_h) {
   pc->f16 = f16;
+  pc->gate_h = gate_h;
   pc->Cin = Cin;
   pc->Cout = Cout;
   pc->bias = bias_dev;
@@ -84,7 +91,7 @@ int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cou
   WETTS_HIP_CHECK(hipMalloc((void**)&pc->wpk, total * sizeof(unsigned short)));
   hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                      w_dev, pc->wpk, pc->M, Cin, Cout, k, pc->ktaps, up > 0 ? up : 1, transposed,
-                     pc->CKB, f16, total);
+                     pc->CKB, f16, gate_h, total);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -97,7 +104,18 @@ void free_packed_bf16(PackedConvB* pc) {
 // ------------------------------------------------------------------------------------------
 // the conv kernel: 4 waves (WM x WN), each wave one 32-row m-block x NB 32-column n-blocks
 // ------------------------------------------------------------------------------------------
-template <int NB, int WM, int WN, int CKB, bool F16>
+// tanh(a) * sigmoid(b) on the hardware exp / rcp (v_exp_f32, v_rcp_f32; ~1e-6 relative, far inside the
+// 16-bit rounding that follows): in a conv epilogue the vector ALU work is paid in matrix-pipe time, and
+// libm's tanhf / expf made the fused in_layer conv twice as long as the plain one.
+//   tanh(a) = 2 / (1 + e^-2a) - 1,  sigmoid(b) = 1 / (1 + e^-b); both saturate correctly at +-inf.
+__device__ __forceinline__ float gate_fast(float a, float b) {
+  const float ea = __expf(-2.f * a), eb = __expf(-b);
+  const float th = 2.f * __builtin_amdgcn_rcpf(1.f + ea) - 1.f;
+  return th * __builtin_amdgcn_rcpf(1.f + eb);
+}
+
+// EPIM: 0 = plain epilogue, 1 / 2 = the fused WaveNet epilogues of the 16-bit flow (ConvBParams::epi_mode)
+template <int NB, int WM, int WN, int CKB, bool F16, int EPIM = 0>
 // three waves per SIMD where the register allocation reaches it without heavy spilling (the compiler
 // otherwise spreads over VGPRs + AGPRs and settles at two)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CKB == 32 || WM == 4) ? 3 : 1)))
@@ -275,6 +293,101 @@ void conv_bf16_kernel(const ConvBParams p) {
 
   // ---- epilogue: + bias, / div, round to 16 bit, channel-last stores ---------------------------
   if (!rows_ok) return;  // M is a multiple of 32 in every decoder conv; guard only
+  if (EPIM == 1) {
+    // WN gate: a lane's first run of 8 rows are tanh channels, the second their sigmoid partners
+    // (pack_bf16_kernel, gate_h).  Both conv outputs are rounded to 16 bit first, as the unfused path
+    // stores them; the gate itself uses the hardware exp / rcp (gate_fast), k_gate_cl16 libm.
+    const int H = p.wn_H, mtb = mrow_blk >> 5, c0 = mtb * 16 + 8 * half;
+    if (c0 >= H) return;
+    float bt[8], bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bt[e] = p.bias ? p.bias[c0 + e] : 0.f;
+      bs[e] = p.bias ? p.bias[H + c0 + e] : 0.f;
+    }
+    if (p.bias_b) {
+      const float* bb = p.bias_b + (int64_t)b * p.bias_b_stride;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bt[e] += bb[c0 + e];
+        bs[e] += bb[H + c0 + e];
+      }
+    }
+    unsigned short* ob = p.out + (int64_t)b * p.o_bs;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = wcol0 + 32 * j + (lane & 31);
+      if (t >= p.N) continue;
+      unsigned o[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const unsigned ta = pk2<F16>(acc[j][2 * e2] + bt[2 * e2], acc[j][2 * e2 + 1] + bt[2 * e2 + 1]);
+        const unsigned sa = pk2<F16>(acc[j][8 + 2 * e2] + bs[2 * e2], acc[j][9 + 2 * e2] + bs[2 * e2 + 1]);
+        o[e2] = pk2<F16>(gate_fast(lo16<F16>(ta), lo16<F16>(sa)), gate_fast(hi16<F16>(ta), hi16<F16>(sa)));
+      }
+      *reinterpret_cast<uint4*>(ob + (int64_t)t * H + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    return;
+  }
+  if (EPIM == 3) {
+    // conv_post as a 32-row conv whose only non-zero weight row is row 0 (k_conv_post_mfma16): tanh -> f32
+    if (half == 0) {
+      float* of = p.out_f32 + (int64_t)b * p.Tout;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int t = wcol0 + 32 * j + (lane & 31);
+        if (t < p.N) of[t] = tanhf(acc[j][0]);
+      }
+    }
+    return;
+  }
+  if (EPIM == 2) {
+    // WN residual / skip update on the rounded conv output (equals k_wn_update_cl16 on the stored tensor)
+    const int H = p.wn_H;
+    float bia[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      bia[r] = p.bias ? p.bias[co_blk + 16 * (r >> 3) + 8 * half + (r & 7)] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = wcol0 + 32 * j + (lane & 31);
+      if (t >= p.N) continue;
+      const int64_t rowi = (int64_t)b * p.Tout + t;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = co_blk + 16 * i + 8 * half;
+        unsigned w[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2)
+          w[e2] = pk2<F16>(acc[j][8 * i + 2 * e2] + bia[8 * i + 2 * e2],
+                           acc[j][8 * i + 2 * e2 + 1] + bia[8 * i + 2 * e2 + 1]);
+        if (!p.wn_last && c < H) {
+          unsigned short* hp = p.wn_h + rowi * H + c;
+          const uint4 hv = *reinterpret_cast<const uint4*>(hp);
+          const unsigned hw[4] = {hv.x, hv.y, hv.z, hv.w};
+          const float mk = p.wn_mask[rowi];
+          unsigned o[4];
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2)
+            o[e2] = pk2<F16>((lo16<F16>(hw[e2]) + lo16<F16>(w[e2])) * mk,
+                             (hi16<F16>(hw[e2]) + hi16<F16>(w[e2])) * mk);
+          *reinterpret_cast<uint4*>(hp) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+          float4* sp = reinterpret_cast<float4*>(p.wn_skip + rowi * H + (p.wn_last ? c : c - H));
+          float4 a = make_float4(lo16<F16>(w[0]), hi16<F16>(w[0]), lo16<F16>(w[1]), hi16<F16>(w[1]));
+          float4 bq = make_float4(lo16<F16>(w[2]), hi16<F16>(w[2]), lo16<F16>(w[3]), hi16<F16>(w[3]));
+          if (!p.wn_first) {
+            const float4 pa = sp[0], pb = sp[1];
+            a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
+            bq.x += pb.x; bq.y += pb.y; bq.z += pb.z; bq.w += pb.w;
+          }
+          sp[0] = a;
+          sp[1] = bq;
+        }
+      }
+    }
+    return;
+  }
   const bool dodiv = p.out_div != 1.f;
   unsigned short* ob = p.out + (int64_t)b * p.o_bs;
   // lane rows = two runs of 8 consecutive channels (see pack_bf16_kernel) -> 16-byte stores
@@ -322,6 +435,29 @@ static int32_t launch_b(const ConvBParams& p, hipStream_t stream, bool f16) {
   const int nbuf = p.nchunks > 1 ? 2 : 1;
   size_t lds = (size_t)nbuf * (NT + p.span) * RS;
   const dim3 grid((unsigned)blocks), blk(256);
+  if constexpr (NB == 4 && WM == 4 && WN == 1 && CKB == 64) {  // the shape of the flow's WN convs
+    if (p.epi_mode == 1) {
+      if (f16) hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, 1>), grid, blk, lds, stream, p);
+      else hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, 1>), grid, blk, lds, stream, p);
+      WETTS_LAUNCH_CHECK();
+      return WETTS_OK;
+    }
+    if (p.epi_mode == 2) {
+      if (f16) hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, 2>), grid, blk, lds, stream, p);
+      else hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, 2>), grid, blk, lds, stream, p);
+      WETTS_LAUNCH_CHECK();
+      return WETTS_OK;
+    }
+  }
+  if constexpr (NB == 4 && WM == 1 && WN == 4 && CKB == 32) {  // conv_post (k_conv_post_mfma16)
+    if (p.epi_mode == 3) {
+      if (f16) hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, 3>), grid, blk, lds, stream, p);
+      else hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, 3>), grid, blk, lds, stream, p);
+      WETTS_LAUNCH_CHECK();
+      return WETTS_OK;
+    }
+  }
+  WETTS_REQUIRE(p.epi_mode == 0, "fused epilogue requested for a tile shape it is not instantiated for");
   if (f16)
     hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true>), grid, blk, lds, stream, p);
   else
@@ -345,6 +481,7 @@ int32_t launch_conv_bf16(const PackedConvB& pc, ConvBParams p, hipStream_t strea
   p.up = pc.up;
   p.up_pad = pc.up_pad;
   WETTS_REQUIRE(pc.wpk != nullptr, "bf16 conv weight not packed");
+  WETTS_REQUIRE((pc.gate_h > 0) == (p.epi_mode == 1), "gate-packed weights and the gate epilogue go together");
   WETTS_REQUIRE(p.span <= 128, "conv receptive field too wide");
   WETTS_REQUIRE(pc.Cout % 32 == 0 && pc.Cin % 8 == 0, "bf16 path needs Cout %% 32 == 0, Cin %% 8 == 0");
   p.N = p.up > 0 ? p.Tin + p.ktaps - 1 : p.Tout;
@@ -429,6 +566,24 @@ __global__ __launch_bounds__(256) void conv_post_bf16_kernel(const unsigned shor
     }
   }
   out[idx] = tanhf(acc);
+}
+
+// conv_post on the matrix cores: lrelu(0.01) (rounded to 16 bit, as every conv input of this mode) ->
+// Conv1d(32, 1, 7) with 16-bit weights, f32 accumulation -> tanh -> f32.  `pc` packs a 32-row weight
+// whose rows 1..31 are zero; the vector-ALU kernel below spends ~1100 lane operations per sample on
+// conversions, leaky-relu and broadcast weight reads (0.6 ms per step at B = 64, v3), this one is
+// bound by reading the activations once.
+int32_t k_conv_post_mfma16(const PackedConvB& pc, const unsigned short* x, int B, int C, int T,
+                           float* out, hipStream_t s) {
+  WETTS_REQUIRE(pc.wpk && pc.Cin == C && pc.Cout == 32 && pc.CKB == 32, "conv_post: weights not packed for this shape");
+  ConvBParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.x_bs = (int64_t)C * T; p.Cin = C; p.Tin = T;
+  p.in_act = IN_LRELU; p.in_slope = 0.01f;  // F.leaky_relu default slope, decoders.py:78
+  p.Tout = T; p.out_div = 1.f; p.B = B;
+  p.epi_mode = 3;
+  p.out_f32 = out;
+  return launch_conv_bf16(pc, p, s);
 }
 
 int32_t k_conv_post_bf16(const unsigned short* x, const float* w, int k, int B, int C, int T,

@@ -43,7 +43,7 @@ __device__ __forceinline__ float lrelu2(float x, float slope) {
 // ------------------------------------------------------------------------------------------
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ out,
                                         int M, int Cin, int Cout, int k, int ktaps, int up,
-                                        int transposed, int G, int64_t total) {
+                                        int transposed, int rev_in, int G, int64_t total) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   int s = (int)(idx & 3);
@@ -62,7 +62,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
   float v = 0.f;
   if (row < M && ci < Cin) {
     if (!transposed) {
-      v = w[((int64_t)row * Cin + ci) * k + tap];
+      v = w[((int64_t)row * Cin + (rev_in ? Cin - 1 - ci : ci)) * k + tap];
     } else {
       int co = row / up, ph = row % up;
       int kk = ph + tap * up;
@@ -74,7 +74,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
 
 int32_t pack_conv_weight(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
                          int dil, int pad, int transposed, int up, hipStream_t stream,
-                         PackedConv* pc) {
+                         PackedConv* pc, int rev_in) {
   pc->Cin = Cin;
   pc->Cout = Cout;
   pc->k_orig = k;
@@ -108,7 +108,7 @@ int32_t pack_conv_weight(const float* w_dev, const float* bias_dev, int Cout, in
   int64_t blocks = (total + threads - 1) / threads;
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream,
                      w_dev, pc->wpk, pc->M, Cin, Cout, k, pc->ktaps, up > 0 ? up : 1, transposed,
-                     G, total);
+                     rev_in, G, total);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -123,7 +123,7 @@ void free_packed(PackedConv* pc) {
 // ------------------------------------------------------------------------------------------
 // EPI: 0 = generic epilogue (runtime activation / masks / late residual), 1 = plain
 // (acc + bias [+ per-utterance bias]), 2 = plain followed by the MRF mean division, 3 = polyphase
-// ConvTranspose1d store.  MRF = name tag of the ResBlock launches (no code difference): rocprofv3
+// ConvTranspose1d store, 4 = plain times the output mask (the flow's pre / post convs).  MRF = name tag of the ResBlock launches (no code difference): rocprofv3
 // --stats then separates bench.py's dominant-kernel class from the flow / encoder convs that share
 // the tile shape.
 // Four 32x32 accumulators per wave (64 AGPRs) plus ~105 VGPRs sat one allocation granule above the
@@ -436,6 +436,9 @@ void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) bia[i][r] += bp[i * 32 + (r & 3) + 8 * (r >> 2)];
     }
+    float om[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) om[j] = EPI == 4 ? omask[wcol0 + 32 * j + (lane & 31)] : 1.f;
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
 #pragma unroll
@@ -446,6 +449,7 @@ void conv_mfma_kernel(const ConvParams p) {
         for (int j = 0; j < NB; ++j) {
           float v = acc[i][j][r] + bia[i][r];
           if (EPI == 2) v = v / p.out_div;
+          if (EPI == 4) v *= om[j];
           *reinterpret_cast<float*>(obase + (roff + 128u * j)) = v;
         }
       }
@@ -554,6 +558,11 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
       hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 3, false, true>), grid, blk, lds, stream, p);
     else
       hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 3, false>), grid, blk, lds, stream, p);
+  } else if (p.up == 0 && p.out_act == OUT_NONE && p.out_mask && !p.res && !p.accum && p.out_div == 1.f) {
+    if (fast)
+      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 4, false, true>), grid, blk, lds, stream, p);
+    else
+      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 4, false>), grid, blk, lds, stream, p);
   } else if (plain && p.tag && fast) {  // MRF ResBlock launches: own kernel symbol, FAST staging
     if (p.out_div == 1.f)
       hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 1, true, true>), grid, blk, lds, stream, p);
@@ -592,6 +601,11 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
   for (int q = 0; q < 16; ++q)
     if (pc.up == (1 << q)) p.up_shift = q;
   WETTS_REQUIRE(pc.wpk != nullptr, "conv weight not packed");
+  // a 1x1 conv whose output is multiplied by the SAME 0/1 mask does not need it on the input: columns with
+  // mask 0 come out 0 either way, the others are untouched (and the plain input can use FAST staging)
+  if (pc.ktaps == 1 && pc.up == 0 && p.in_mask && p.in_mask == p.out_mask &&
+      p.in_mask_stride == p.out_mask_stride && p.out_act == OUT_NONE)
+    p.in_mask = nullptr;
   WETTS_REQUIRE(p.span <= 128, "conv receptive field too wide (span %d > 128)", p.span);
   if (p.up > 0) {
     p.N = p.Tin + p.ktaps - 1;

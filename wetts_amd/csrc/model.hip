@@ -421,6 +421,8 @@ struct wetts_model {
   // 16-bit WaveNet layers of the flow (opt-in, wetts_set_flow_precision): weights packed on first use
   mutable int flow_precision = 0;  // 0 = f32, 1 = bf16, 2 = f16
   mutable std::vector<std::vector<PackedConvB>> b_wn_in, b_wn_rs;  // [flow][layer]
+  mutable PackedConvB b_post;          // conv_post as a 32-row conv (row 0 = the weights), 32-channel models
+  mutable float* b_post_wpad = nullptr;
   // uint8 dynamic-quantisation decoder (precision 3): Conv1d weights quantised on first use
   mutable PackedQConv q_pre, q_cond, q_post;
   mutable std::vector<std::vector<PackedQConv>> q_c1, q_c2;  // per resblock
@@ -464,11 +466,11 @@ struct Bump {
 
 static int32_t pack(wetts_model* m, const std::string& wname, const std::string& bname, int Cout,
                     int Cin, int k, int dil, int pad, int transposed, int up, hipStream_t s,
-                    PackedConv* pc) {
+                    PackedConv* pc, int rev_in = 0) {
   const float* w = m->T(wname);
   WETTS_REQUIRE(w != nullptr, "tensor %s missing from layout", wname.c_str());
   const float* b = bname.empty() ? nullptr : m->T(bname);
-  WETTS_TRY(pack_conv_weight(w, b, Cout, Cin, k, dil, pad, transposed, up, s, pc));
+  WETTS_TRY(pack_conv_weight(w, b, Cout, Cin, k, dil, pad, transposed, up, s, pc, rev_in));
   m->all_packed.push_back(pc);
   return WETTS_OK;
 }
@@ -620,7 +622,11 @@ static int32_t build_model(wetts_model* m, hipStream_t s) {
   for (int f = 0; f < c->flow_n_flows; ++f) {
     FlowW& fw = m->flows[f];
     std::string p = S("flow.flows.%d", 2 * f);
-    WETTS_TRY(pack(m, p + ".pre.weight", p + ".pre.bias", H, I / 2, 1, 1, 0, 0, 0, s, &fw.pre));
+    // plain coupling layers read x0 = Flip(x)[:I/2] = x[I-1 .. I/2]: the Flip is folded into `pre` by packing
+    // its input channels in reverse, so the conv reads channels I/2 .. I-1 in place (no index arithmetic
+    // while staging); the pre_conv transformer flow materialises x0 and keeps the natural order
+    WETTS_TRY(pack(m, p + ".pre.weight", p + ".pre.bias", H, I / 2, 1, 1, 0, 0, 0, s, &fw.pre,
+                   c->transformer_flows == 1 ? 0 : 1));
     WETTS_TRY(pack(m, p + ".post.weight", p + ".post.bias", I / 2, H, 1, 1, 0, 0, 0, s, &fw.post));
     fw.in_layers.resize(c->flow_wn_layers);
     fw.res_skip.resize(c->flow_wn_layers);
@@ -925,6 +931,8 @@ void wetts_destroy(wetts_model_t* m) {
   for (auto& v : m->b_c2) for (auto& pc : v) free_packed_bf16(&pc);
   for (auto& v : m->b_wn_in) for (auto& pc : v) free_packed_bf16(&pc);
   for (auto& v : m->b_wn_rs) for (auto& pc : v) free_packed_bf16(&pc);
+  free_packed_bf16(&m->b_post);
+  if (m->b_post_wpad) (void)hipFree(m->b_post_wpad);
   free_packed_qconv(&m->q_pre);
   free_packed_qconv(&m->q_cond);
   free_packed_qconv(&m->q_post);
@@ -1255,6 +1263,10 @@ int32_t wetts_length_regulate(const wetts_model_t* m, const float* stats, const 
 // ---------------------------------------------------------------------------------------------
 namespace wetts {
 // 16-bit copies of the WN conv weights (in_layers k = 5, res_skip 1x1) of every coupling layer
+// gate and residual / skip update run in the epilogues of the two convs of a layer when the convs take the
+// 128-row, 64-channel-chunk tile those epilogues are instantiated for (conv_bf16.hip)
+static bool wn16_fused(int H) { return H % 16 == 0 && H >= 128; }
+
 static int32_t pack_flow_bf16(const wetts_model* m, hipStream_t s) {
   const int f16 = m->flow_precision == 2 ? 1 : 0;
   if (!m->b_wn_in.empty() && m->b_wn_in[0][0].f16 == f16) return WETTS_OK;
@@ -1269,7 +1281,8 @@ static int32_t pack_flow_bf16(const wetts_model* m, hipStream_t s) {
     for (int i = 0; i < NL; ++i) {
       WETTS_TRY(pack_conv_weight_bf16(m->T(p + S(".enc.in_layers.%d.weight", i)),
                                       m->T(p + S(".enc.in_layers.%d.bias", i)), 2 * H, H, fk, 1,
-                                      (fk - 1) / 2, 0, 0, f16, s, &m->b_wn_in[f][i]));
+                                      (fk - 1) / 2, 0, 0, f16, s, &m->b_wn_in[f][i],
+                                      wn16_fused(H) ? H : 0));
       const int rs = (i < NL - 1) ? 2 * H : H;
       WETTS_TRY(pack_conv_weight_bf16(m->T(p + S(".enc.res_skip_layers.%d.weight", i)),
                                       m->T(p + S(".enc.res_skip_layers.%d.bias", i)), rs, H, 1, 1, 0,
@@ -1349,8 +1362,8 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
       p.out_mask_stride = Ty;
       WETTS_TRY(launch_conv(fw.pre, p, s));
     } else {
-      ConvParams p = conv_io(cur, I, Ty, h, H, B);  // h = pre(x0) * mask
-      p.in_rev_base = I - 1;
+      ConvParams p = conv_io(cur + (int64_t)(I / 2) * Ty, I / 2, Ty, h, H, B);  // h = pre(x0) * mask
+      p.x_bs = (int64_t)I * Ty;  // (x0 = the upper half of the channels, reversed inside the weights)
       p.out_mask = y_mask;
       p.out_mask_stride = Ty;
       WETTS_TRY(launch_conv(fw.pre, p, s));
@@ -1382,16 +1395,33 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
           p1.bias_b = gl + (int64_t)i * 2 * H;
           p1.bias_b_stride = (int64_t)2 * H * NL;
         }
+        const bool fusedwn = wn16_fused(H);
+        if (fusedwn) {  // gate in the epilogue: acts16 written directly
+          p1.epi_mode = 1;
+          p1.wn_H = H;
+          p1.out = acts16;
+          p1.o_bs = (int64_t)H * Ty;
+        }
         WETTS_TRY(launch_conv_bf16(m->b_wn_in[f][i], p1, s));
-        WETTS_TRY(k_gate_cl16(xin16, acts16, rows, H, f16, s));
+        if (!fusedwn) WETTS_TRY(k_gate_cl16(xin16, acts16, rows, H, f16, s));
         const int RC = last ? H : 2 * H;
         ConvBParams p2;
         memset(&p2, 0, sizeof(p2));
         p2.x = acts16; p2.x_bs = (int64_t)H * Ty; p2.Cin = H; p2.Tin = Ty; p2.in_act = IN_NONE;
         p2.out = rs16; p2.o_bs = (int64_t)RC * Ty; p2.cout = RC; p2.Tout = Ty;
         p2.out_div = 1.f; p2.B = B;
+        if (fusedwn) {  // h / skip update in the epilogue: rs16 is never written
+          p2.epi_mode = 2;
+          p2.wn_H = H;
+          p2.wn_h = h16;
+          p2.wn_skip = skip_cl;
+          p2.wn_mask = y_mask;
+          p2.wn_last = last ? 1 : 0;
+          p2.wn_first = i == 0 ? 1 : 0;
+        }
         WETTS_TRY(launch_conv_bf16(m->b_wn_rs[f][i], p2, s));
-        WETTS_TRY(k_wn_update_cl16(rs16, h16, skip_cl, y_mask, last ? 1 : 0, i == 0 ? 1 : 0, rows, H, f16, s));
+        if (!fusedwn)
+          WETTS_TRY(k_wn_update_cl16(rs16, h16, skip_cl, y_mask, last ? 1 : 0, i == 0 ? 1 : 0, rows, H, f16, s));
       }
       WETTS_TRY(k_cl32_to_cf32(skip_cl, skip, B, H, Ty, s));
     } else
@@ -1760,6 +1790,7 @@ static int32_t pack_decoder_bf16(const wetts_model* m, hipStream_t s) {
   for (auto& pc : m->b_ups) free_packed_bf16(&pc);
   for (auto& v : m->b_c1) for (auto& pc : v) free_packed_bf16(&pc);
   for (auto& v : m->b_c2) for (auto& pc : v) free_packed_bf16(&pc);
+  free_packed_bf16(&m->b_post);
   const wetts_config_t* c = &m->cfg;
   const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
   m->b_ups.resize(c->n_upsamples);
@@ -1789,6 +1820,14 @@ static int32_t pack_decoder_bf16(const wetts_model* m, hipStream_t s) {
         }
       }
     }
+  }
+  if (ch == 32) {  // conv_post on the matrix cores (k_conv_post_mfma16): rows 1..31 of the weight are zero
+    const size_t n = (size_t)32 * ch * 7;
+    if (!m->b_post_wpad) WETTS_HIP_CHECK(hipMalloc((void**)&m->b_post_wpad, n * sizeof(float)));
+    WETTS_HIP_CHECK(hipMemsetAsync(m->b_post_wpad, 0, n * sizeof(float), s));
+    WETTS_HIP_CHECK(hipMemcpyAsync(m->b_post_wpad, m->conv_post_w, (size_t)ch * 7 * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s));
+    WETTS_TRY(pack_conv_weight_bf16(m->b_post_wpad, nullptr, 32, ch, 7, 1, 3, 0, 0, f16, s, &m->b_post));
   }
   return WETTS_OK;
 }
@@ -1939,6 +1978,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
     x = xsum;
   }
   if (m->mrf_timing) m->mrf_calls += 1;
+  if (m->b_post.wpk && ch == 32) return k_conv_post_mfma16(m->b_post, x, B, ch, len, audio, s);
   return k_conv_post_bf16(x, m->conv_post_w, 7, B, ch, len, audio, m->dec_precision == 2 ? 1 : 0, s);
 }
 }  // namespace wetts
