@@ -238,6 +238,31 @@ def test_fused_resblock_pair_bit_identical(dtype, L, cname):
     assert np.array_equal(a, b), f"max |diff| {np.abs(a - b).max()}"
 
 
+@pytest.mark.parametrize("L", [3, 50, 200])
+def test_small_launch_conv_schedule_matches_the_big_tile_kernel(L):
+    """conv_small_kernel (32x32 tiles, K split over the block's waves; B = 1 streaming windows and short
+    texts) against conv_mfma_kernel on the same decoder input: same arithmetic, another summation
+    order.  L = 200 at B = 2 mixes both kernels inside one decode (the C = 256 stage is below the
+    256-tile threshold, the later stages above it)."""
+    case = util.load_case("v1_b2")
+    os.environ["WETTS_TUNE"] = "small_max_tiles=0"
+    try:
+        net, cfg, W = _model(case)  # (the switch is process-wide: use this model before creating the next)
+    finally:
+        del os.environ["WETTS_TUNE"]
+    torch.manual_seed(11)
+    z = torch.randn(2, cfg.inter_channels, L).cuda()
+    g = torch.nn.functional.embedding(util.t(case["sid"]), W["emb_g.weight"]).cuda()
+    big = net.hifigan(z, g).cpu().numpy()
+    net2, _, _ = _model(case)
+    small = net2.hifigan(z, g).cpu().numpy()
+    assert big.shape == small.shape and np.isfinite(small).all()
+    r = util.rel_rms(small, big)
+    print("small-launch schedule vs big tiles, L =", L, "rel rms", r)
+    # ~60 convs deep, each summing K = 100..2800 terms in another order: 1e-6-level differences
+    assert r < 1e-5 and not np.array_equal(small, big)  # (equal would mean the switch did nothing)
+
+
 @pytest.mark.parametrize("name,dtype", [("v3_b3x128", torch.bfloat16), ("v3_b3x128", torch.float16),
                                         ("v1_b4x128", torch.bfloat16)])
 def test_flow_16bit_mode_matches_its_numerics_spec(name, dtype):

@@ -26,7 +26,9 @@ python bench.py --config stress48k --steps 10 --warmup 3 --no-cpu-baseline > gpu
 python bench.py --model vocos --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_vocos.json 2>/dev/null
 python bench.py --model vits2_vocos_v1 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_vits2_vocos.json 2>/dev/null
 python bench.py --stream --model v1 > gpurun_out/stream_v1.json 2>/dev/null
+WETTS_TUNE=small_max_tiles=0 python bench.py --stream --model v1 > gpurun_out/stream_v1_old_path.json 2>/dev/null
 python bench.py --stream --model vits2_vocos_v1 --stream-cpu > gpurun_out/stream_vits2_vocos.json 2>/dev/null
+(cd /tmp && rocprofv3 --kernel-trace -d /tmp/b1 -o b1 --output-format csv -- python $R/tools/trace_b1.py --reps 5 > $R/gpurun_out/b1_run.txt 2>&1; python $R/tools/trace_b1.py --summarize /tmp/b1 > $R/gpurun_out/b1_summary.txt 2>&1)
 python tools/bench_conv.py 0 > gpurun_out/conv_microbench.txt 2>&1
 WETTS_FLAGS=4 python tools/bench_resblock.py > gpurun_out/resblock_chain.txt 2>&1
 WETTS_PAIR=1 WETTS_CONV_FLAGS=16 WETTS_SHAPES=128:3,128:11,64:3,32:3,32:11 python tools/bench_conv.py 32,16 > gpurun_out/conv16_fused_pair.txt 2>&1

@@ -21,6 +21,7 @@ for a, b in [("bench_bf16.json", "bench_bf16.json"), ("bench_f16.json", "bench_f
              ("conv16_fused_pair.txt", "conv16_fused_pair.txt"),
              ("conv_microbench.txt", "conv_microbench.txt"), ("resblock_chain.txt", "resblock_chain.txt"),
              ("stream_v1.json", "stream_v1.json"), ("stream_vits2_vocos.json", "stream_vits2_vocos.json"),
+             ("stream_v1_old_path.json",) * 2, ("b1_summary.txt", "b1_trace_summary.txt"),
              ("bench_vocos.json", "bench_vocos.json"), ("bench_vits2_vocos.json", "bench_vits2_vocos.json"),
              ("bench_cfg2_multilingual_bf16.json",) * 2, ("bench_cfg2_multilingual_f32.json",) * 2,
              ("bench_cfg3_aishell3.json",) * 2, ("bench_cfg4_stress48k_f16.json",) * 2,

@@ -133,18 +133,48 @@ __global__ void attn_relk_kernel(const float* __restrict__ q, const float* __res
 }
 
 // out[bh][d][i] += sum_{|r|<=w} P[i+r][i] * E_v[r+w][d]   (attentions.py:273-279)
-__global__ void attn_relv_add_kernel(const float* __restrict__ P, const float* __restrict__ emb_rel_v,
-                                     int window, int dk, int T, float* __restrict__ out) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  const int d = blockIdx.y, bh = blockIdx.z;
+// block = 64 query lanes x 4 channel groups: a thread keeps its 2w+1 probabilities in registers and walks
+// its quarter of the channels (E_v in LDS, broadcast reads), instead of one thread per (i, d) re-reading
+// the probabilities dk times
+constexpr int kRelvMaxW = 8;
+__global__ __launch_bounds__(256) void attn_relv_add_kernel(const float* __restrict__ P,
+                                                            const float* __restrict__ emb_rel_v, int window,
+                                                            int dk, int T, float* __restrict__ out) {
+  extern __shared__ float esh[];  // [2w+1][dk]
+  const int nrel = 2 * window + 1;
+  for (int q = threadIdx.x; q < nrel * dk; q += blockDim.x) esh[q] = emb_rel_v[q];
+  __syncthreads();
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), dg = threadIdx.x >> 6, bh = blockIdx.y;
   if (i >= T) return;
   const float* Pc = P + (int64_t)bh * T * T + i;
-  float rel = 0.f;
-  for (int r = -window; r <= window; ++r) {
-    const int j = i + r;
-    if (j >= 0 && j < T) rel += Pc[(int64_t)j * T] * emb_rel_v[(int64_t)(r + window) * dk + d];
+  float pv[2 * kRelvMaxW + 1];
+#pragma unroll
+  for (int q = 0; q < 2 * kRelvMaxW + 1; ++q) {
+    const int j = i + q - window;
+    pv[q] = (q < nrel && j >= 0 && j < T) ? Pc[(int64_t)j * T] : 0.f;
   }
-  out[((int64_t)bh * dk + d) * T + i] += rel;
+  const int d0 = (dk * dg) / 4, d1 = (dk * (dg + 1)) / 4;
+  float* ob = out + (int64_t)bh * dk * T + i;
+  for (int db = d0; db < d1; db += 8) {  // eight read-modify-writes in flight at a time
+    float o[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) o[u] = ob[(int64_t)(db + u < d1 ? db + u : d0) * T];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int d = db + u < d1 ? db + u : d0;
+      float rel = 0.f;
+#pragma unroll
+      for (int q = 0; q < 2 * kRelvMaxW + 1; ++q)
+        if (q < nrel) {
+          const int j = i + q - window;
+          if (j >= 0 && j < T) rel += pv[q] * esh[q * dk + d];  // same terms, same order as the (i, d) form
+        }
+      o[u] += rel;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (db + u < d1) ob[(int64_t)(db + u) * T] = o[u];
+  }
 }
 
 __global__ __launch_bounds__(256) void attn_scores_mfma_kernel(
@@ -466,8 +496,9 @@ int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t 
                        dim3(256), 0, s, scores, vT, dk, T, out);
     WETTS_LAUNCH_CHECK();
     if (window >= 0) {
-      hipLaunchKernelGGL(attn_relv_add_kernel, dim3(cdiv(T, 64), dk, B * n_heads), dim3(64), 0, s,
-                         scores, emb_rel_v, window, dk, T, out);
+      WETTS_REQUIRE(window <= kRelvMaxW, "relative attention window %d > %d", window, kRelvMaxW);
+      hipLaunchKernelGGL(attn_relv_add_kernel, dim3(cdiv(T, 64), B * n_heads), dim3(256),
+                         (size_t)(2 * window + 1) * dk * sizeof(float), s, scores, emb_rel_v, window, dk, T, out);
       WETTS_LAUNCH_CHECK();
     }
     return WETTS_OK;
