@@ -253,7 +253,7 @@ def main():
         sys.exit(spawn_ranks(args))
     from wetts_amd import SynthesizerTrn, _lib, checkpoint, config, sharding, synth
 
-    rank, local_rank, world = sharding.init_process_group()
+    rank, local_rank, world = sharding.env_world()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
@@ -263,8 +263,9 @@ def main():
     elif torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no HIP device "
                          f"({torch.cuda.device_count()} visible)")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)  # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local_rank)
+    sharding.init_process_group()
     lib = _lib.load()
 
     pre = PRESETS[args.config]
