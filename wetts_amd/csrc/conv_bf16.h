@@ -49,6 +49,7 @@ struct ConvBParams {
 
 // fused ResBlock1 pair (resblock16.hip): out = (x + c2(lrelu(c1(lrelu(x)))) [+ out]) / div
 constexpr int RESPAIR_MAX_SPAN = 64;  // (k-1)*dilation of c1 the fused kernel is sized for
+constexpr int RESPAIR2_MAX_SPAN32 = 80;  // ... of the C = 32 ResBlock2 chain
 struct ResPairParams {
   const unsigned short* x;  // [B][T][C] residual stream, channel-last
   unsigned short* out;      // [B][T][C] (never aliases x)

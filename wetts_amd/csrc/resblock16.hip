@@ -41,7 +41,10 @@ void resblock_pair16_kernel(const ResPairParams p) {
   constexpr int NCH = C / CKB, KS = CKB / 16;
   constexpr int SEG = C / 8;                   // 16-byte pieces per row
   constexpr int RS = C * 2 + 16;               // padded LDS row stride (bytes)
-  constexpr int MAXU = ((NTC + RESPAIR_MAX_SPAN) * SEG + 255) / 256;
+  // widest halo the staging loop is sized for; the C = 32 ResBlock2 chain also takes v3's k = 7 block
+  // (dilations 3 / 12: 72 columns, 14 % of the 512-column tile)
+  constexpr int MAXSPAN = (RB2 && C == 32) ? RESPAIR2_MAX_SPAN32 : RESPAIR_MAX_SPAN;
+  constexpr int MAXU = ((NTC + MAXSPAN) * SEG + 255) / 256;
   static_assert(256 % SEG == 0, "piece index must not depend on the unit");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
@@ -355,7 +358,8 @@ bool resblock2_chain16_supported(const PackedConvB& c1, const PackedConvB& c2, i
   if (c1.Cout != C || c2.Cin != C || c2.Cout != C || c1.up || c2.up) return false;
   if (c1.ktaps != c2.ktaps || (c1.ktaps & 1) == 0 || c1.f16 != c2.f16) return false;
   if (c1.pad != (c1.ktaps - 1) / 2 * c1.dil || c2.pad != (c2.ktaps - 1) / 2 * c2.dil) return false;
-  if ((c1.ktaps - 1) * (c1.dil > c2.dil ? c1.dil : c2.dil) > RESPAIR_MAX_SPAN) return false;
+  if ((c1.ktaps - 1) * (c1.dil > c2.dil ? c1.dil : c2.dil) > (C == 32 ? RESPAIR2_MAX_SPAN32 : RESPAIR_MAX_SPAN))
+    return false;
   const int NTC = 128 * (4 / (C / 32));
   return (c2.ktaps - 1) * c2.dil * 100 <= max_waste_pct * NTC;
 }
