@@ -25,14 +25,19 @@ from . import _lib, checkpoint, config as _config
 
 
 class _Workspace:
-    """Grow-only device scratch (one per model; the kernels themselves never allocate)."""
+    """Grow-only device scratch (one per model; the kernels themselves never allocate).
+
+    Grows with 25 % headroom: the frame count of a batch is data dependent (durations are sampled), so a
+    buffer sized to the request would be re-allocated every time a batch sets a new maximum -- a multi-GB
+    hipMalloc in the middle of serving (seen as 75-88 ms bench steps instead of 73 on a fresh process)."""
 
     def __init__(self):
         self.buf = None
 
     def get(self, nbytes, device):
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self.buf = None  # release the old block to the caching allocator first
+            self.buf = torch.empty(int(nbytes) + int(nbytes) // 4, dtype=torch.uint8, device=device)
         return self.buf
 
 
