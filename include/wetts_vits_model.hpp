@@ -27,12 +27,15 @@ class DeviceBuffer {
   ~DeviceBuffer() { if (p_) (void)hipFree(p_); }
   DeviceBuffer(const DeviceBuffer&) = delete;
   DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  // grow-only, with 25 % headroom: sizes follow the (sampled) frame count, and a request that sets a new
+  // maximum should not cost a hipFree + hipMalloc every time
   void* Reserve(size_t bytes) {
     if (bytes > cap_) {
       if (p_) (void)hipFree(p_);
       p_ = nullptr;
-      if (hipMalloc(&p_, bytes) != hipSuccess) throw std::runtime_error("hipMalloc failed");
-      cap_ = bytes;
+      const size_t cap = bytes + bytes / 4;
+      if (hipMalloc(&p_, cap) != hipSuccess) throw std::runtime_error("hipMalloc failed");
+      cap_ = cap;
     }
     return p_;
   }
