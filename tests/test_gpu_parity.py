@@ -247,7 +247,7 @@ def test_small_launch_conv_schedule_matches_the_big_tile_kernel(L):
     case = util.load_case("v1_b2")
     os.environ["WETTS_TUNE"] = "small_max_tiles=0"
     try:
-        net, cfg, W = _model(case)  # (the switch is process-wide: use this model before creating the next)
+        net, cfg, W = _model(case)  # (a per-model setting, read at create)
     finally:
         del os.environ["WETTS_TUNE"]
     torch.manual_seed(11)

@@ -145,7 +145,11 @@ int conv_variant();
 void set_conv_variant(int v);
 // conv_small.hip: the schedule for launches of at most ~one 64x64 tile per CU (B = 1 latency)
 int32_t launch_conv_small(const ConvParams& p, hipStream_t stream, bool* taken);
-void set_conv_small_max_tiles(int v);  // launches up to this many 64x64 tiles use it (0: never)
+struct SmallConvScope {  // RAII: launches of up to `max_tiles` 64x64 tiles use it on this thread (0: never)
+  explicit SmallConvScope(int max_tiles);
+  ~SmallConvScope();
+  int prev;
+};
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }

@@ -207,8 +207,10 @@ __global__ __launch_bounds__(64 * KG) void conv_small_kernel(const ConvParams p)
 }
 
 // launches of at most this many 64x64 tiles (four times as many 32x32 blocks) take this kernel (0: never)
-static int g_small_max_tiles = 256;
-void set_conv_small_max_tiles(int v) { g_small_max_tiles = v; }
+// (per calling thread, set for the duration of a C-ABI call from the model's setting: no process-wide state)
+static thread_local int tls_small_max_tiles = 256;
+SmallConvScope::SmallConvScope(int max_tiles) : prev(tls_small_max_tiles) { tls_small_max_tiles = max_tiles; }
+SmallConvScope::~SmallConvScope() { tls_small_max_tiles = prev; }
 
 static size_t small_lds_bytes(int sch, int span, int kg) {
   const size_t stage = (size_t)kg * 2 * kConvCK * sch * (32 + span) * sizeof(float);
@@ -258,7 +260,7 @@ static int32_t launch_small_cfg(const ConvParams& p, hipStream_t stream) {
 int32_t launch_conv_small(const ConvParams& p, hipStream_t stream, bool* taken) {
   *taken = false;
   const int64_t tiles64 = (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * p.B;
-  if (g_small_max_tiles <= 0 || tiles64 <= 0 || tiles64 > g_small_max_tiles) return WETTS_OK;
+  if (tls_small_max_tiles <= 0 || tiles64 <= 0 || tiles64 > tls_small_max_tiles) return WETTS_OK;
   if (p.span > 128 || p.nchunks < 2) return WETTS_OK;
   const bool sch4 = p.ktaps == 1 && (p.nchunks % 4) == 0;
   if (small_lds_bytes(sch4 ? 4 : 1, p.span, 4) > 160 * 1024) return WETTS_OK;

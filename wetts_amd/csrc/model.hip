@@ -898,7 +898,6 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
         pos = end + 1;
       }
     }
-    set_conv_small_max_tiles(m->small_max_tiles);  // process-wide (a diagnostics switch)
     if (m->mrf_streams < 1) m->mrf_streams = 1;
     if (m->mrf_streams > cfg->n_resblock_kernels) m->mrf_streams = cfg->n_resblock_kernels;
     (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
@@ -1029,6 +1028,7 @@ int32_t wetts_text_encoder(const wetts_model_t* m, const int64_t* x, const int64
                            const float* g, int32_t B, int32_t Tx, float* x_enc, float* stats,
                            float* x_mask, void* workspace, int64_t workspace_bytes, void* stream) {
   WETTS_REQUIRE(m && x && x_lengths && x_enc && stats && x_mask, "null argument");
+  SmallConvScope small_scope(m->small_max_tiles);
   if (B == 0 || Tx == 0) return WETTS_OK;
   hipStream_t s = (hipStream_t)stream;
   const wetts_config_t* c = &m->cfg;
@@ -1094,6 +1094,7 @@ int32_t wetts_duration_sdp(const wetts_model_t* m, const float* x_enc, const flo
                            int32_t Tx, float* logw, int32_t* status_dev, void* workspace,
                            int64_t workspace_bytes, void* stream) {
   WETTS_REQUIRE(m && x_enc && x_mask && eps_w && logw, "null argument");
+  SmallConvScope small_scope(m->small_max_tiles);
   WETTS_REQUIRE(m->cfg.use_sdp, "model was built with use_sdp=false");
   if (B == 0 || Tx == 0) return WETTS_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -1160,6 +1161,7 @@ int32_t wetts_duration_dp(const wetts_model_t* m, const float* x_enc, const floa
                           const float* g, int32_t B, int32_t Tx, float* logw, void* workspace,
                           int64_t workspace_bytes, void* stream) {
   WETTS_REQUIRE(m && x_enc && x_mask && logw, "null argument");
+  SmallConvScope small_scope(m->small_max_tiles);
   WETTS_REQUIRE(!m->cfg.use_sdp, "model was built with use_sdp=true");
   if (B == 0 || Tx == 0) return WETTS_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -1306,6 +1308,7 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
                            const float* g, int32_t B, int32_t Ty, float* z_out, void* workspace,
                            int64_t workspace_bytes, void* stream) {
   WETTS_REQUIRE(m && z_p && y_mask && z_out, "null argument");
+  SmallConvScope small_scope(m->small_max_tiles);
   if (B == 0 || Ty == 0) return WETTS_OK;
   hipStream_t s = (hipStream_t)stream;
   const wetts_config_t* c = &m->cfg;
@@ -2181,6 +2184,7 @@ int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_st
                       const float* g, int32_t B, int32_t L, float* audio, void* workspace,
                       int64_t workspace_bytes, void* stream) {
   WETTS_REQUIRE(m && z && audio, "null argument");
+  SmallConvScope small_scope(m->small_max_tiles);
   if (B == 0 || L == 0) return WETTS_OK;
   if (m->cfg.vocoder_type == 1)
     return run_vocos(m, z, z_batch_stride, z_channel_stride, y_mask, mask_stride, g, B, L, audio,
@@ -2200,6 +2204,7 @@ int32_t wetts_profile_hifigan(const wetts_model_t* m, const float* z, int64_t z_
                               float* audio, void* workspace, int64_t workspace_bytes, void* stream,
                               double* mrf_ms, double* total_ms, int32_t* mrf_launches) {
   WETTS_REQUIRE(m && z && audio && mrf_ms && total_ms && mrf_launches, "null argument");
+  SmallConvScope small_scope(m->small_max_tiles);
   WETTS_REQUIRE(m->cfg.vocoder_type == 0, "wetts_profile_hifigan: HiFi-GAN models only");
   hipStream_t s = (hipStream_t)stream;
   DecTiming tm;
