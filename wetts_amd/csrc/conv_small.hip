@@ -9,13 +9,15 @@
 // CUs idle.  K-splitting inside a 64x64 block does not help (the four SIMDs of the CU are the limit;
 // measured) and splitting K across blocks costs two device-scope fences per launch (L2 write-back /
 // invalidate between XCDs; measured slower than not splitting).  So: the smallest tile the matrix core
-// offers and the K range split over the block's four SIMDs --
-//  * tile 32 x 32, one block = four waves = four K-groups: wave w runs stages w, w + 4, ... of the
-//    reduction (a stage = one 16-channel chunk with all its taps; four chunks for 1x1 convs) on its own
-//    SIMD with its own LDS double buffer, staged by the wave itself -- no block barrier in the K loop.
-//    4x as many blocks as 64x64 tiles, and each block's chain is K/8 MFMAs instead of K/2;
-//  * the four partial tiles meet in LDS; wave w sums accumulator rows 4w..4w+3 of all four waves in a
-//    fixed order (deterministic) and runs the epilogue for them;
+// offers and the K range split over the block's waves --
+//  * tile 32 x 32, one block = KG waves (4, 8 or 16) = K-groups: wave w runs stages w, w + KG, ... of the
+//    reduction (a stage = one 16-channel chunk with all its taps; four chunks for 1x1 convs) with its own
+//    LDS double buffer, staged by the wave itself -- no block barrier in the K loop.  4x as many blocks
+//    as 64x64 tiles, each wave's chain K / (2 KG) MFMAs instead of K / 2.  8 / 16 waves serve long
+//    reductions with short taps: a k = 3 stage is 0.6 us of matrix work, less than the round trip of its
+//    staging loads, so a wave's time is (stages per wave) x (load latency);
+//  * the KG partial tiles meet in LDS; wave w sums accumulator registers w 16/KG .. of all waves in wave
+//    order (deterministic) and runs the epilogue for them;
 //  * a register ring of R weight fragments per wave (R = all groups of a stage for k <= 5, half of them
 //    for k = 7 / 11): the prefetch runs a stage ahead.  The tap count is a template parameter so that
 //    ring slots, loop structure and therefore the s_waitcnt counts are static; every load is
