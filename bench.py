@@ -52,15 +52,24 @@ def parse_args():
     ap.add_argument("--speakers", type=int, default=None, help="rows of the speaker table")
     ap.add_argument("--ragged", action="store_true", help="Tx ~ U{32..phonemes} (configs[3] style)")
     ap.add_argument("--buckets", type=int, default=0,
-                    help="padded sub-batches per step (0 = auto: 1 for equal lengths, 4 for ragged batches; "
-                         "SURVEY 8e: each rank buckets its length-sorted shard)")
+                    help="0 = sub-batches chosen by wetts_amd.batching.plan (SURVEY 8e: each rank buckets its "
+                         "length-sorted shard); N > 0 = N equal-count buckets (round-2 behaviour, for A/B)")
+    ap.add_argument("--max-pad-frac", type=float, default=0.08, help="padding share batching.plan may spend")
+    ap.add_argument("--max-batch", type=int, default=0, help="largest padded sub-batch (0 = no cap)")
+    ap.add_argument("--length-scale", type=float, default=0.92,
+                    help="calibrated so the synthetic duration heads give 6.0 +- 0.5 frames/phoneme (SURVEY 8d)")
+    ap.add_argument("--presteps-s", type=float, default=2.5, help="untimed set-up before the warm-up steps")
+    ap.add_argument("--cpu-baseline-multi", action="store_true",
+                    help="also time the CPU baseline on rank 0 when N > 1 (the contract asks for it at N = 1 only)")
+    ap.add_argument("--mas", action="store_true", help="print the monotonic-alignment-search JSON instead")
     ap.add_argument("--decoder-dtype", default=None, choices=["f32", "bf16", "f16", "uint8"],
                     help="HiFi-GAN arithmetic; the headline metric is quoted at f32 (uint8 = the "
                          "export_onnx.py --quant dynamic-quantisation variant)")
     ap.add_argument("--flow-dtype", default=None, choices=["f32", "bf16", "f16"],
                     help="arithmetic of the flow's WaveNet layers (wetts_set_flow_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2, help="utterances in the CPU sample")
+    ap.add_argument("--cpu-sample", type=int, default=1,
+                    help="utterances in the CPU sample (1 = the reference CLI's own call shape, inference.py:83-110)")
     # secondary mode: streaming (chunked decoder) latency at B = 1 instead of the throughput step
     ap.add_argument("--stream", action="store_true", help="print the streaming-latency JSON instead")
     ap.add_argument("--stream-phonemes", type=int, default=64)
@@ -191,11 +200,13 @@ PRESETS = {
 }
 
 
-def cpu_baseline(cfg, sd, x, lens, sid, n_utts, sr, hop):
+def cpu_baseline(cfg, sd, x, lens, sid, n_utts, sr, hop, length_scale=1.0):
     """Times the oracle (CPU port of the reference path; /root/reference does not exist on the GPU
-    box, so `kind` is "port": same ATen CPU kernels, same module order) on `n_utts` utterances of
-    the same workload, at 1 / 8 / 16 / 32 threads; `value` is the best, with its thread count.
-    The single-thread figure is the reference's own setting (inference.py:49-50)."""
+    box, so `kind` is "port": same ATen CPU kernels, same module order) on ONE bounded sample of the
+    workload -- the first `n_utts` utterances, the same sample at every thread count -- at 1 / 8 / 16 / 32
+    threads: one warm-up run, then the median of three (SURVEY 8(d)).  `value` is the best thread count;
+    `threads_1` is the reference's own setting (inference.py:49-50: torch.set_num_threads(1))."""
+    import statistics
     from oracle import vits_oracle as vo  # checker / baseline only -- never on the product path
     from tests import util
     from wetts_amd import checkpoint
@@ -205,23 +216,25 @@ def cpu_baseline(cfg, sd, x, lens, sid, n_utts, sr, hop):
     saved = torch.get_num_threads()
     host = os.cpu_count() or 1
     sweep = []
+    t_all = time.perf_counter()
     try:
-        torch.set_num_threads(min(8, host))
-        vo.infer(W, cd, xs[:1, :16], torch.tensor([16]), ss[:1], 0.667, 1.0, 0.8)  # warm-up (tiny)
         for thr in [t for t in (1, 8, 16, 32) if t <= host]:
             torch.set_num_threads(thr)
-            torch.manual_seed(1)
-            # the single-thread point is the slowest: bound it to one utterance
-            n = 1 if thr == 1 else n_utts
-            tm = {}
-            t0 = time.perf_counter()
-            o, _, y_mask, _ = vo.infer(W, cd, xs[:n], ls[:n], ss[:n], noise_scale=0.667,
-                                       length_scale=1.0, noise_scale_w=0.8, timers=tm)
-            dt = time.perf_counter() - t0
+            runs, tm = [], {}
+            for rep in range(4):  # rep 0 = warm-up
+                torch.manual_seed(1)
+                tm = {}
+                t0 = time.perf_counter()
+                o, _, y_mask, _ = vo.infer(W, cd, xs, ls, ss, noise_scale=0.667, length_scale=length_scale,
+                                           noise_scale_w=0.8, timers=tm)
+                dt = time.perf_counter() - t0
+                if rep:
+                    runs.append(dt)
+            dt = statistics.median(runs)
             samples = float(y_mask.sum().item()) * hop
-            sweep.append({"threads": thr, "samples_per_s": samples / dt, "seconds": dt,
-                          "utterances": n, "rtf": dt / (samples / sr),
-                          "stage_s": {k: round(v, 4) for k, v in tm.items()}})
+            sweep.append({"threads": thr, "samples_per_s": samples / dt, "seconds_median_of_3": dt,
+                          "seconds_runs": [round(r, 4) for r in runs], "utterances": n_utts,
+                          "rtf": dt / (samples / sr), "stage_s_last_run": {k: round(v, 4) for k, v in tm.items()}})
     finally:
         torch.set_num_threads(saved)
     best = max(sweep, key=lambda r: r["samples_per_s"])
@@ -229,10 +242,84 @@ def cpu_baseline(cfg, sd, x, lens, sid, n_utts, sr, hop):
             "kind": "port",
             "kind_reason": "the GPU box has no /root/reference; oracle/vits_oracle.py restates it on "
                            "the same ATen CPU kernels and is pinned to it by tests/golden",
-            "host_cores": host, "rtf": best["rtf"], "stage_s": best["stage_s"],
+            "host_cores": host, "rtf": best["rtf"], "stage_s": best["stage_s_last_run"],
+            "threads_1": {"samples_per_s": sweep[0]["samples_per_s"], "rtf": sweep[0]["rtf"],
+                          "note": "the reference's own setting (inference.py:49-50)"},
+            "best": {"threads": best["threads"], "samples_per_s": best["samples_per_s"]},
+            "method": "same sample at every thread count; 1 warm-up + median of 3 (SURVEY 8d)",
             "thread_sweep": sweep,
-            "sample": f"{best['utterances']} of the batch's utterances x {int(ls[0])} phonemes, oracle "
-                      f"infer() once per thread count ({sum(r['seconds'] for r in sweep):.0f} s total)"}
+            "sample": f"{n_utts} utterance(s) of the batch x {int(ls[0])} phonemes, oracle infer() 4x per "
+                      f"thread count ({time.perf_counter() - t_all:.0f} s total)"}
+
+
+def mas_bench(args):
+    """`bench.py --mas`: the monotonic-alignment search kernel (monotonic_align.py:22-57) on
+    training-shaped score tensors, device time from HIP events on the launch stream (median), against
+    oracle/mas_oracle.c (the reference's numba loop restated in C, single thread like the reference's
+    serial loop over the batch) on the host.  One JSON line."""
+    import ctypes as C
+    import statistics
+    import subprocess
+    import numpy as np
+    from wetts_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["make", "-s", "-C", odir])
+    olib = C.CDLL(os.path.join(odir, "_build", "libmas_oracle.so"))  # cpu_baseline leg only
+    olib.mas_oracle.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
+    olib.mas_oracle.restype = None
+    rows = []
+    for (b, ty, tx) in ((16, 800, 128), (64, 1000, 200)):
+        g = torch.Generator().manual_seed(7)
+        neg = torch.randn(b, ty, tx, generator=g)
+        t_y = torch.randint(ty // 2, ty + 1, (b,), generator=g).int()
+        t_x = torch.minimum(torch.randint(tx // 3, tx + 1, (b,), generator=g).int(), t_y)
+        nd, tyd, txd = neg.to(dev), t_y.to(dev), t_x.to(dev)
+        path = torch.empty(b, ty, tx, dtype=torch.int32, device=dev)
+        ws = torch.empty(b * ty * tx, dtype=torch.float32, device=dev)
+
+        def run():
+            _lib.check(lib.wetts_mas(_lib.ptr(nd), _lib.ptr(tyd), _lib.ptr(txd), b, ty, tx, _lib.ptr(path),
+                                     _lib.ptr(ws), ws.numel() * 4, _lib.current_stream_ptr()), "wetts_mas")
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(args.stream_reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ms = statistics.median(ts)
+        # host: the C restatement of the numba kernel, 1 warm-up + median of 3
+        cpu = []
+        negn = neg.numpy()
+        for rep in range(4):
+            vals = np.array(negn, dtype=np.float32, copy=True)
+            pth = np.zeros(vals.shape, dtype=np.int32)
+            t0 = time.perf_counter()
+            olib.mas_oracle(pth.ctypes.data, vals.ctypes.data, t_y.numpy().ctypes.data, t_x.numpy().ctypes.data,
+                            b, ty, tx)
+            if rep:
+                cpu.append((time.perf_counter() - t0) * 1e3)
+        same = bool(np.array_equal(path.cpu().numpy(), pth))
+        cells = float((t_y.double() * t_x.double()).sum())
+        byt = 2.0 * b * ty * tx * 4  # scores read once, path written once
+        rows.append({"shape": [b, ty, tx], "device_ms": ms, "device_ms_min": min(ts),
+                     "cpu_ms_1thread": statistics.median(cpu), "speedup": statistics.median(cpu) / ms,
+                     "bit_exact_vs_c_oracle": same, "valid_cells_per_s": cells / (ms * 1e-3),
+                     "hbm_gbs": byt / (ms * 1e-3) / 1e9, "hbm_frac": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "rows_per_us_per_utterance": float(t_y.max()) / (ms * 1e3)})
+    print(json.dumps({"metric": "monotonic alignment search (maximum_path), device ms per batch",
+                      "kernel": "mas_wave_kernel (one wave per utterance, DPP row step, decision bits in LDS)",
+                      "bound": "latency of the serial row recurrence (t_y dependent steps per utterance)",
+                      "cases": rows,
+                      "cpu_baseline": {"kind": "port", "cores": 1,
+                                       "what": "oracle/mas_oracle.c = maximum_path_jit restated in C, serial over "
+                                               "the batch like the reference (monotonic_align.py:11-19)"}}), flush=True)
 
 
 def spawn_ranks(args):
@@ -240,145 +327,59 @@ def spawn_ranks(args):
     per GPU, RCCL rendezvous on 127.0.0.1).  Refuses -- exit code 3, nothing on stdout -- when the
     node has fewer than N GPUs (WETTS_BENCH_SINGLE_DEVICE=1: dry run, all ranks share GPU 0)."""
     from wetts_amd import sharding
+    stub = bool(os.environ.get("WETTS_BENCH_TEST_BACKEND"))
     return sharding.launch_ranks(args.gpus, __file__, sys.argv[1:],
-                                 require_gpus=not os.environ.get("WETTS_BENCH_SINGLE_DEVICE"))
+                                 require_gpus=not (os.environ.get("WETTS_BENCH_SINGLE_DEVICE") or stub))
 
 
-def main():
-    args = parse_args()
-    if args.stream:
+class HipBackend:
+    """Everything of the bench that touches the device.  The control flow in main() -- plan, warm-up, timed
+    loop, reductions over ranks, the JSON line -- talks to the device only through this object, so that
+    tests/test_bench_control_flow.py can run that whole flow at world size 2 on the CPU (gloo) against a stub
+    with the same methods (selected by WETTS_BENCH_TEST_BACKEND; its JSON line is labelled, see `label`)."""
+    label = None  # a stub puts a marker here; it is copied into the JSON line
+
+    def __init__(self, rank, local_rank):
+        from wetts_amd import _lib
         assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-        return stream_bench(args)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args))
-    from wetts_amd import SynthesizerTrn, _lib, checkpoint, config, sharding, synth
+        self.single_dev = bool(os.environ.get("WETTS_BENCH_SINGLE_DEVICE"))  # dry run: all ranks on GPU 0
+        if self.single_dev:
+            local_rank = 0
+        elif torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: local rank {local_rank} has no HIP device "
+                             f"({torch.cuda.device_count()} visible)")
+        torch.cuda.set_device(local_rank)  # before the process group: RCCL binds to the current device
+        self.device = torch.device("cuda", local_rank)
+        self._lib_mod = _lib
+        self.lib = _lib.load()
 
-    rank, local_rank, world = sharding.env_world()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    single_dev = bool(os.environ.get("WETTS_BENCH_SINGLE_DEVICE"))  # dry run: all ranks on GPU 0
-    if single_dev:
-        local_rank = 0
-    elif torch.cuda.device_count() <= local_rank:
-        raise SystemExit(f"rank {rank}: local rank {local_rank} has no HIP device "
-                         f"({torch.cuda.device_count()} visible)")
-    torch.cuda.set_device(local_rank)  # before the process group: RCCL binds to the current device
-    dev = torch.device("cuda", local_rank)
-    sharding.init_process_group()
-    lib = _lib.load()
-
-    pre = PRESETS[args.config]
-    mname = args.model or pre["model"]
-    batch = args.batch or pre["batch"]
-    phonemes = args.phonemes or pre["phonemes"]
-    ragged = args.ragged or pre["ragged"]
-    ddtype = args.decoder_dtype or pre["decoder_dtype"]
-    fdtype = args.flow_dtype or (pre["flow_dtype"] if not args.decoder_dtype else "f32")
-    n_speakers = args.speakers or pre["n_speakers"]
-    sr = pre["sr"] if not args.model else config.SAMPLING_RATES[mname]
-    n_vocab = 256  # SURVEY 8(d): synthetic phone table
-    net = SynthesizerTrn(n_vocab, 513, 32, n_speakers=n_speakers, **config.MODEL_CONFIGS[mname])
-    cfg = net.cfg
-    hop = net.hop_length
-
-    # ---- weights: rank 0 builds the blob, one broadcast over RCCL, every rank repacks locally
-    numel = checkpoint.blob_numel(cfg)
-    sd = None
-    if rank == 0:
-        sd = synth.make_state_dict(cfg, seed=0)
-        blob = checkpoint.pack_blob(cfg, sd).to(dev)
-    else:
-        blob = torch.empty(numel, dtype=torch.float32, device=dev)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t_b0 = time.perf_counter()
-    sharding.broadcast_blob(blob, src=0)
-    torch.cuda.synchronize()
-    bcast_ms = (time.perf_counter() - t_b0) * 1e3
-    net.load_blob(blob)
-    if ddtype != "f32":
-        net.set_decoder_dtype(ddtype)
-    if fdtype != "f32":
-        net.set_flow_dtype(fdtype)
-
-    # ---- inputs: global utterance list, LPT-dealt to ranks, resident on the device
-    total = batch * world
-    x, lens, sid = make_inputs(mname, n_vocab, n_speakers, total, phonemes, ragged)
-    shards = sharding.shard_utterances(lens.tolist(), world)
-    mine = torch.tensor(shards[rank], dtype=torch.long)
-    xh, lh, sh = x[mine].contiguous(), lens[mine].contiguous(), sid[mine].contiguous()
-    # the shard is length-sorted (sharding.shard_utterances), so consecutive slices pad little: a ragged
-    # shard is decoded as `nb` padded sub-batches, each cut to its own longest utterance
-    nb = args.buckets or (4 if ragged else 1)
-    nb = max(1, min(nb, len(mine)))
-    per = -(-len(mine) // nb)
-    host_buckets = []
-    for i in range(0, len(mine), per):
-        tx = int(lh[i:i + per].max())
-        host_buckets.append((xh[i:i + per, :tx].contiguous(), lh[i:i + per].contiguous(),
-                             sh[i:i + per].contiguous()))
-    dev_buckets = [tuple(t.to(dev) for t in hb) for hb in host_buckets]
-    torch.manual_seed(1 + rank)  # the library's Philox stream follows torch.initial_seed()
-
-    def step(buckets=dev_buckets):
-        # eps_w / eps_z = None: both standard-normal draws come from the library's Philox kernel
-        outs, masks_ = [], []
-        for (xb_, lb_, sb_) in buckets:
-            o, attn, y_mask, _ = net.infer(xb_, lb_, sid=sb_, noise_scale=0.667, length_scale=1.0,
-                                           noise_scale_w=0.8)
-            outs.append(o)
-            masks_.append(y_mask)
-        return outs, masks_
-
-    # untimed set-up, before the W warm-up steps of the contract: a fresh box starts with the GPU
-    # in a low power state and with lazy one-time initialisation pending (code objects, the MRF
-    # event pool); run the step for ~2.5 s so that neither lands inside the timed region
-    _lib.check(lib.wetts_set_mrf_timing(net._handle, 1), "set_mrf_timing")
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 2.5:
-        step()
+    def sync(self):
         torch.cuda.synchronize()
-    ms0, nl0, nc0 = C.c_double(), C.c_int64(), C.c_int32()
-    _lib.check(lib.wetts_read_mrf_timing(net._handle, C.byref(ms0), C.byref(nl0), C.byref(nc0)),
-               "read_mrf_timing")  # drains the set-up events
-    _lib.check(lib.wetts_set_mrf_timing(net._handle, 0), "set_mrf_timing")
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    _lib.check(lib.wetts_set_mrf_timing(net._handle, 1), "set_mrf_timing")
-    frames = 0.0
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    masks = []
-    for _ in range(args.steps):
-        o, y_masks = step()
-        masks.extend(y_masks)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    for ym in masks:
-        frames += float(ym.sum().item())
-    ms, nl, nc = C.c_double(), C.c_int64(), C.c_int32()
-    _lib.check(lib.wetts_read_mrf_timing(net._handle, C.byref(ms), C.byref(nl), C.byref(nc)),
-               "read_mrf_timing")
-    _lib.check(lib.wetts_set_mrf_timing(net._handle, 0), "set_mrf_timing")
-    padded_frames = float(sum(ym.numel() for ym in masks))  # B*Ty: what the decoder computes
 
-    # PCIe-inclusive variant (SURVEY 8d's wall: H2D of the ids, D2H of the audio; the driver contract
-    # says inputs are resident when the timed region starts, so this is reported beside `value`,
-    # never as it): a few extra steps with pinned host buffers on both sides
-    pinned = [tuple(t.pin_memory() for t in hb) for hb in host_buckets]
-    n_pcie = max(1, min(3, args.steps))
+    def make_model(self, mname, n_vocab, n_speakers):
+        from wetts_amd import SynthesizerTrn, config
+        return SynthesizerTrn(n_vocab, 513, 32, n_speakers=n_speakers, **config.MODEL_CONFIGS[mname])
 
-    def pcie_pass(n, pipelined):
+    def set_mrf_timing(self, net, on):
+        self._lib_mod.check(self.lib.wetts_set_mrf_timing(net._handle, 1 if on else 0), "set_mrf_timing")
+
+    def read_mrf_timing(self, net):
+        ms, nl, nc = C.c_double(), C.c_int64(), C.c_int32()
+        self._lib_mod.check(self.lib.wetts_read_mrf_timing(net._handle, C.byref(ms), C.byref(nl), C.byref(nc)),
+                            "read_mrf_timing")
+        return ms.value, nl.value
+
+    def hifigan_cost(self, cfg):
+        fl, by, mfl, mby = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        self.lib.wetts_hifigan_cost(C.byref(cfg), C.byref(fl), C.byref(by), C.byref(mfl), C.byref(mby))
+        return mfl.value, mby.value
+
+    def pcie_pass(self, net, pinned, n, pipelined, infer_kw):
         """ids H2D -> infer() -> audio D2H for n steps.  Serial: every step waits for its own copy-out
         (a blocking .cpu()).  Pipelined: the audio goes to a pinned double buffer on a copy stream while the
         next step computes -- what a server that streams results does."""
+        dev = self.device
+        hop = net.hop_length
         copy_stream = torch.cuda.Stream(device=dev)
         bufs, done = [None, None], [None, None]
         frames_, k = 0.0, 0
@@ -387,8 +388,7 @@ def main():
         for _ in range(n):
             for hb in pinned:
                 xd2, ld2, sd2 = (t.to(dev, non_blocking=True) for t in hb)
-                o, _, y_mask, _ = net.infer(xd2, ld2, sid=sd2, noise_scale=0.667, length_scale=1.0,
-                                            noise_scale_w=0.8)
+                o, _, y_mask, _ = net.infer(xd2, ld2, sid=sd2, **infer_kw)
                 if not pipelined:
                     _ = o.cpu()
                 else:
@@ -410,20 +410,179 @@ def main():
         torch.cuda.synchronize()
         return frames_ * hop / (time.perf_counter() - t_)
 
-    pcie_rate = pcie_pass(n_pcie, False)
-    n_pipe = max(n_pcie, min(8, args.steps))
-    pcie_pass(1, True)  # allocates the pinned buffers outside the timed pass
-    pcie_pipe_rate = pcie_pass(n_pipe, True)
+    def pin(self, t):
+        return t.pin_memory()
 
-    # ---- reduce over ranks: time = max, work = sum
-    stat = torch.tensor([elapsed, frames, padded_frames, ms.value, float(nl.value), pcie_rate, pcie_pipe_rate],
+
+def load_backend(rank, local_rank):
+    spec = os.environ.get("WETTS_BENCH_TEST_BACKEND")  # "module:Class" -- CPU control-flow tests only
+    if spec:
+        import importlib
+        mod, cls = spec.split(":")
+        return getattr(importlib.import_module(mod), cls)(rank, local_rank)
+    return HipBackend(rank, local_rank)
+
+
+def blob_fingerprint(blob):
+    """Order-sensitive checksum of the weight blob, computed where the blob lives: two float64 sums (plain and
+    index-weighted) -- any rank whose broadcast copy differs from rank 0's shows up in the min / max over
+    ranks."""
+    b = blob.detach().to(torch.float64)
+    w = torch.arange(1, b.numel() + 1, dtype=torch.float64, device=b.device) % 8191
+    return torch.stack([b.sum(), (b * w).sum()])
+
+
+def main():
+    args = parse_args()
+    if args.stream or args.mas:
+        assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+        return stream_bench(args) if args.stream else mas_bench(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    from wetts_amd import batching, checkpoint, config, sharding, synth
+
+    rank, local_rank, world = sharding.env_world()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    be = load_backend(rank, local_rank)
+    dev = be.device
+    single_dev = getattr(be, "single_dev", False)
+    sharding.init_process_group()
+
+    pre = PRESETS[args.config]
+    mname = args.model or pre["model"]
+    batch = args.batch or pre["batch"]
+    phonemes = args.phonemes or pre["phonemes"]
+    ragged = args.ragged or pre["ragged"]
+    ddtype = args.decoder_dtype or pre["decoder_dtype"]
+    fdtype = args.flow_dtype or (pre["flow_dtype"] if not args.decoder_dtype else "f32")
+    n_speakers = args.speakers or pre["n_speakers"]
+    sr = pre["sr"] if not args.model else config.SAMPLING_RATES[mname]
+    n_vocab = 256  # SURVEY 8(d): synthetic phone table
+    net = be.make_model(mname, n_vocab, n_speakers)
+    cfg = net.cfg
+    hop = net.hop_length
+    # SURVEY 8(d) duration pinning: 6.0 +- 0.5 frames per phoneme.  The synthetic duration heads give
+    # ceil(6 e^{0.1 z}) = 6.57 on average at length_scale 1; 0.92 calibrates the mean to 6.0-6.1
+    infer_kw = dict(noise_scale=0.667, length_scale=args.length_scale, noise_scale_w=0.8)
+
+    # ---- weights: rank 0 builds the blob, one broadcast over RCCL, every rank repacks locally
+    numel = checkpoint.blob_numel(cfg)
+    sd = None
+    if rank == 0:
+        sd = synth.make_state_dict(cfg, seed=0)
+        blob = checkpoint.pack_blob(cfg, sd).to(dev)
+    else:
+        blob = torch.empty(numel, dtype=torch.float32, device=dev)
+    be.sync()
+    if world > 1:
+        dist.barrier()
+    t_b0 = time.perf_counter()
+    sharding.broadcast_blob(blob, src=0)
+    be.sync()
+    bcast_ms = (time.perf_counter() - t_b0) * 1e3
+    # every rank verifies what it received: min == max over ranks of the blob fingerprint
+    fp = blob_fingerprint(blob)
+    blob_ok, ranks_seen = True, 1
+    if world > 1:
+        lo, hi = fp.clone(), fp.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        blob_ok = bool(torch.equal(lo, hi)) and bool(torch.isfinite(fp).all())
+        one = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one.item())
+        if not blob_ok:  # never time a rank that decodes with other weights
+            raise SystemExit(f"rank {rank}: weight blob differs across ranks after the broadcast")
+    net.load_blob(blob)
+    if ddtype != "f32":
+        net.set_decoder_dtype(ddtype)
+    if fdtype != "f32":
+        net.set_flow_dtype(fdtype)
+
+    # ---- inputs: global utterance list -> batching.plan: LPT deal to ranks, then each rank's length-sorted shard
+    # cut into padded sub-batches (the plan is deterministic, every rank computes the same one)
+    total = batch * world
+    x, lens, sid = make_inputs(mname, n_vocab, n_speakers, total, phonemes, ragged)
+    pl = batching.plan(lens.tolist(), world, max_pad_frac=args.max_pad_frac, max_batch=args.max_batch)
+    my_buckets = pl.buckets[rank]
+    if args.buckets > 0:  # A/B: round 2's fixed number of equal-count buckets
+        my_buckets = batching.equal_count_buckets(pl.shards[rank], lens.tolist(), args.buckets)
+    nb = len(my_buckets)
+    host_buckets = []
+    for bk in my_buckets:
+        ii = torch.tensor(bk.indices, dtype=torch.long)
+        host_buckets.append((x[ii, :bk.tx].contiguous(), lens[ii].contiguous(), sid[ii].contiguous()))
+    dev_buckets = [tuple(t.to(dev) for t in hb) for hb in host_buckets]
+    torch.manual_seed(1 + rank)  # the library's Philox stream follows the device generator
+
+    def step(buckets=dev_buckets):
+        # eps_w / eps_z = None: both standard-normal draws come from the library's Philox kernel
+        outs, masks_ = [], []
+        for (xb_, lb_, sb_) in buckets:
+            o, attn, y_mask, _ = net.infer(xb_, lb_, sid=sb_, **infer_kw)
+            outs.append(o)
+            masks_.append(y_mask)
+        return outs, masks_
+
+    # untimed set-up, before the W warm-up steps of the contract: a fresh box starts with the GPU
+    # in a low power state and with lazy one-time initialisation pending (code objects, the MRF
+    # event pool); run the step for ~2.5 s so that neither lands inside the timed region
+    be.set_mrf_timing(net, True)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.presteps_s:
+        step()
+        be.sync()
+    be.read_mrf_timing(net)  # drains the set-up events
+    be.set_mrf_timing(net, False)
+    for _ in range(args.warmup):
+        step()
+    be.sync()
+    if world > 1:
+        dist.barrier()
+    be.set_mrf_timing(net, True)
+    frames = 0.0
+    be.sync()
+    t0 = time.perf_counter()
+    masks = []
+    for _ in range(args.steps):
+        o, y_masks = step()
+        masks.extend(y_masks)
+    be.sync()
+    my_elapsed = time.perf_counter() - t0  # this rank's own time, before it waits for the others
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    for ym in masks:
+        frames += float(ym.sum().item())
+    mrf_ms, mrf_launches = be.read_mrf_timing(net)
+    be.set_mrf_timing(net, False)
+    padded_frames = float(sum(ym.numel() for ym in masks))  # B*Ty: what the decoder computes
+
+    # PCIe-inclusive variant (SURVEY 8d's wall: H2D of the ids, D2H of the audio; the driver contract
+    # says inputs are resident when the timed region starts, so this is reported beside `value`,
+    # never as it): a few extra steps with pinned host buffers on both sides
+    pinned = [tuple(be.pin(t) for t in hb) for hb in host_buckets]
+    n_pcie = max(1, min(3, args.steps))
+    pcie_rate = be.pcie_pass(net, pinned, n_pcie, False, infer_kw)
+    n_pipe = max(n_pcie, min(8, args.steps))
+    be.pcie_pass(net, pinned, 1, True, infer_kw)  # allocates the pinned buffers outside the timed pass
+    pcie_pipe_rate = be.pcie_pass(net, pinned, n_pipe, True, infer_kw)
+
+    # ---- reduce over ranks: time = max, work = sum; every rank's own loop time is gathered for `rank_ms`
+    stat = torch.tensor([elapsed, frames, padded_frames, mrf_ms, float(mrf_launches), pcie_rate, pcie_pipe_rate],
                         dtype=torch.float64, device=dev)
+    rank_ms = [my_elapsed / args.steps * 1e3]
     if world > 1:
         mx = stat.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stat.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, frames, pcie_rate, pcie_pipe_rate = float(mx[0]), float(sm[1]), float(sm[5]), float(sm[6])
+        mine_t = torch.tensor([my_elapsed / args.steps * 1e3], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(allt, mine_t)
+        rank_ms = [float(t.item()) for t in allt]
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -431,58 +590,78 @@ def main():
 
     samples = frames * hop
     value = samples / elapsed
-    fl, by, mfl, mby = C.c_double(), C.c_double(), C.c_double(), C.c_double()
-    lib.wetts_hifigan_cost(C.byref(cfg), C.byref(fl), C.byref(by), C.byref(mfl), C.byref(mby))
+    mfl, mby = be.hifigan_cost(cfg)
     # dominant kernel: algorithmic FLOPs of the MRF convs over the frames rank 0 decoded
     # (padded frames: the decoder has no masks, decoders.py:63-82), / live device time
-    mrf_flops = mfl.value * padded_frames
-    mrf_tflops = mrf_flops / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-    mrf_gbs = mby.value * padded_frames / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0
-    traffic, traffic_src = None, None
-    try:  # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command
-        import glob
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
-        if files and args.config == "baker" and not (args.model or args.batch or args.phonemes):
-            dom = json.load(open(files[-1]))["dominant_conv_mfma"]
-            traffic, traffic_src = dom["hbm_bytes_per_launch"], os.path.basename(files[-1])
-    except Exception:
-        pass
-    if ddtype != "f32":
+    mrf_flops = mfl * padded_frames
+    mrf_tflops = mrf_flops / (mrf_ms * 1e-3) / 1e12 if mrf_ms > 0 else 0.0
+    mrf_gbs = mby * padded_frames / (mrf_ms * 1e-3) / 1e9 if mrf_ms > 0 else 0.0
+    nl_ = max(1, mrf_launches)
+    default_shape = not (args.model or args.batch or args.phonemes or args.buckets or args.speakers)
+
+    def pmc_traffic(key):
+        """Committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command (profiles/)."""
+        try:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+            for f in reversed(files):
+                d = json.load(open(f))
+                if key in d and default_shape:
+                    return d[key]["hbm_bytes_per_launch"], os.path.basename(f)
+        except Exception:
+            pass
+        return None, None
+
+    if ddtype == "uint8":
+        traffic, traffic_src = None, None
+        roofline = {
+            "kernel": "qconv_i8_kernel (v_mfma_i32_32x32x32_i8) + its quantisation passes; ConvTranspose1d stays f32",
+            "bound": "hbm", "achieved": mrf_gbs * 0.25 if mrf_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (mrf_gbs * 0.25 / HBM_PEAK_GBS) if mrf_ms > 0 else None, "traffic": None,
+            "launches": int(mrf_launches), "avg_launch_ms": mrf_ms / nl_ if mrf_ms > 0 else None,
+            "note": "per-conv algorithmic bytes at one byte per activation (SURVEY 8d accounting / 4); null when "
+                    "the uint8 path recorded no MRF timing",
+            "mrf_share_of_step": mrf_ms / (elapsed * 1e3),
+        }
+    elif ddtype != "f32":
         # 16-bit activations: per-conv algorithmic bytes (SURVEY 8d accounting: every conv reads its
         # input and writes its output once, each residual add reads x once more) are half the f32
-        # figure.  The fused ResBlock pair kernel moves fewer bytes than that through HBM (the
-        # intermediate stays in LDS), which is how `achieved` can approach the roofline; k=3 pairs
-        # are HBM/latency-bound, k=11 pairs MFMA-bound -- both views are reported.
+        # figure.  The fused ResBlock kernels move fewer bytes than that through HBM (intermediates stay
+        # on the CU), which is how `achieved` can approach the roofline; k=3 blocks are HBM/latency-bound,
+        # k=11 blocks MFMA-bound -- both views are reported.
         gbs = 0.5 * mrf_gbs
+        traffic, traffic_src = pmc_traffic(f"mrf16_{args.config}")
         roofline = {
-            "kernel": "resblock_pair16_kernel + conv_bf16_kernel (MRF ResBlock convs, "
-                      f"{ddtype} channel-last; C<=128 pairs fused)",
+            "kernel": "the 16-bit MRF ResBlock class: resblock_chain16_kernel / resblock_pair16_kernel / conv_bf16_kernel "
+                      f"({ddtype} channel-last)",
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-            "launches": int(nl.value), "avg_launch_ms": ms.value / max(1, nl.value),
-            "bytes_per_launch": 0.5 * mby.value * padded_frames / max(1, nl.value),
+            "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_unit": "HBM bytes per MRF launch (2*FETCH_SIZE+WRITE_SIZE)*1024, PMC",
+            "traffic_source": traffic_src,
+            "launches": int(mrf_launches), "avg_launch_ms": mrf_ms / nl_,
+            "bytes_per_launch": 0.5 * mby * padded_frames / nl_,
             "mfma_view": {"achieved": mrf_tflops, "peak": 2500.0, "unit": "TFLOP/s",
                           "frac": mrf_tflops / 2500.0},
-            "mrf_share_of_step": ms.value / (elapsed * 1e3),
+            "mrf_share_of_step": mrf_ms / (elapsed * 1e3),
         }
     else:
+        traffic, traffic_src = pmc_traffic("dominant_conv_mfma") if args.config == "baker" else (None, None)
         roofline = {
             "kernel": ("conv_mfma_kernel (Vocos ConvNeXt pointwise GEMMs 512<->1536)"
                        if "vocos" in mname else
                        "the MRF ResBlock conv class: conv_mfma_kernel<.., MRF=true, FAST=true> (single "
-                       "convs) + resblock_chain32_kernel (whole ResBlock1 at C=32 k<=7 / C=64 k=3, single "
-                       "pairs at C=32 k=11 / C=128 k=3)"),
+                       "convs) + resblock_chain32_kernel (whole ResBlock1 / single pairs)"),
             "bound": "mfma", "achieved": mrf_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": mrf_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
             "traffic_unit": "HBM bytes per MRF launch (2*FETCH_SIZE+WRITE_SIZE)*1024, PMC",
             "traffic_source": traffic_src,
-            "launches": int(nl.value), "avg_launch_ms": ms.value / max(1, nl.value),
-            "flops_per_launch": mrf_flops / max(1, nl.value),
+            "launches": int(mrf_launches), "avg_launch_ms": mrf_ms / nl_,
+            "flops_per_launch": mrf_flops / nl_,
             "hbm_view": {"achieved": mrf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": mrf_gbs / HBM_PEAK_GBS,
                          "note": "per-conv algorithmic bytes (SURVEY 8d); fp32 convs are "
                                  "compute-bound (AI 113 flop/B > ridge ~20)"},
-            "mrf_share_of_step": ms.value / (elapsed * 1e3),
+            "mrf_share_of_step": mrf_ms / (elapsed * 1e3),
         }
     backend = dist.get_backend() if world > 1 else "none"
     observed_world = dist.get_world_size() if world > 1 else 1
@@ -490,6 +669,7 @@ def main():
             "uint8 dynamic-quantised decoder convs (int32 accumulate)" if ddtype == "uint8" else
             ddtype + " decoder") + \
         ("" if fdtype == "f32" else f" + {fdtype} flow WaveNet layers")
+    valid_phonemes = float(lens.sum())
     out = {
         "metric": "audio samples/sec + RTF @22.05 kHz, VITS-Baker, 1/2/4/8 MI355X",
         "value": value, "unit": "samples/s", "n_gpus": observed_world, "steps": args.steps,
@@ -497,20 +677,32 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if ddtype == "f32" and fdtype == "f32" else
                  (prec if ddtype == "uint8" else f"{prec} (f32 accumulate)"),
-        "data": "synthetic (seeded phoneme ids, seeded random-init weights, ~6.5 frames/phoneme, "
-                "Philox noise drawn on the device)",
+        "data": "synthetic (seeded phoneme ids, seeded random-init weights, "
+                f"{frames / args.steps / max(1.0, valid_phonemes):.2f} frames/phoneme at length_scale "
+                f"{args.length_scale}, Philox noise drawn on the device)",
         "rtf": elapsed / (samples / sr), "x_realtime": (samples / sr) / elapsed,
         "config": {"workload": f"{args.config}_{mname} infer(): B={batch}/GPU x "
                                f"{phonemes} phonemes{' ragged U{32..' + str(phonemes) + '}' if ragged else ''}, "
                                f"{prec}, {n_speakers} speaker(s), {sr} Hz ({pre['tag']})",
                    "global_batch": total, "phonemes": phonemes, "hop": hop,
                    "padded_sub_batches_per_step": nb,
+                   "sub_batch_plan": {"chosen_by": "equal-count (--buckets)" if args.buckets > 0 else
+                                      "wetts_amd.batching.plan (DP over the length-sorted shard)",
+                                      "max_pad_frac": args.max_pad_frac, "phoneme_pad_frac": pl.stats["pad_frac"],
+                                      "sizes_rank0": [len(b) for b in my_buckets],
+                                      "tx_rank0": [b.tx for b in my_buckets]},
+                   "frame_pad_frac_rank0": 1.0 - (stat[1].item() / stat[2].item()) if stat[2].item() else 0.0,
                    "n_speakers": n_speakers, "sampling_rate": sr,
+                   "length_scale": args.length_scale,
+                   "frames_per_phoneme": frames / args.steps / max(1.0, valid_phonemes),
                    "valid_frames_per_step": frames / args.steps,
                    "parallelism": f"utterance-shard x{observed_world} (backend {backend}"
                                   f"{', all ranks on one device: dry run' if single_dev else ''}), "
                                   f"weights broadcast once ({numel * 4 / 1e6:.0f} MB, {bcast_ms:.1f} ms),"
                                   " no collectives in the decode loop"},
+        "ranks_seen": ranks_seen, "blob_checksum_ok": blob_ok,
+        "rank_ms": rank_ms, "imbalance": max(rank_ms) / (sum(rank_ms) / len(rank_ms)) - 1.0,
+        "plan_slot_imbalance": pl.stats["imbalance"],
         "pcie_inclusive_samples_per_s": pcie_rate,
         "pcie_inclusive_pipelined_samples_per_s": pcie_pipe_rate,
         "pcie_inclusive_note": "ids H2D + infer() + audio D2H per step (SURVEY 8(d)'s wall), reported beside `value`, "
@@ -518,9 +710,13 @@ def main():
                                f"double buffer, copy-out on its own stream under the next step ({n_pipe} steps)",
         "roofline": roofline,
     }
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, sd, x, lens, sid, min(args.cpu_sample, total), sr,
-                                           hop)
+    if be.label:
+        out["backend_label"] = be.label
+    # contract: the CPU baseline is a rank-0, N = 1 measurement; --cpu-baseline-multi adds it at N > 1 too
+    # (rank 0, after the timed region and its barrier; the other ranks wait at the final barrier)
+    if not args.no_cpu_baseline and (world == 1 or args.cpu_baseline_multi):
+        out["cpu_baseline"] = cpu_baseline(cfg, sd, x, lens, sid, min(args.cpu_sample, total), sr, hop,
+                                           args.length_scale)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

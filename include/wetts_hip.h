@@ -13,8 +13,12 @@
  *   - every data pointer is a DEVICE pointer owned by the caller unless the name ends in `_host`.
  *   - activations are contiguous float32, channel-first [B, C, T]; ids / lengths are int64;
  *     masks are float 0/1 [B, T] (the reference's [B,1,T] with the unit dim dropped).
- *   - all launches are stream-ordered and asynchronous; nothing allocates after wetts_create():
- *     scratch comes from the caller's workspace (wetts_workspace_bytes()).
+ *   - all launches are stream-ordered and asynchronous; the stage calls never allocate: scratch comes
+ *     from the caller's workspace (wetts_workspace_bytes()).  Device memory is allocated by wetts_create()
+ *     and by the two precision setters (wetts_set_decoder_precision / wetts_set_flow_precision), which build
+ *     their 16-bit / uint8 weight copies when called, on the default stream, and return after it has drained
+ *     (set-up calls, like create); wetts_dynamic_quant_conv1d and wetts_set_mrf_timing are validation / measurement
+ *     aids and say so at their declarations.
  *   - return value: 0 = ok, negative = error (WETTS_E_*); wetts_last_error() gives the message
  *     of the calling thread's last failure.  Kernels never fall back to a CPU path.
  *   - thread-compatible: one handle may be used from one thread at a time (the reference's
@@ -223,8 +227,8 @@ int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_st
 
 /* Decoder arithmetic: 0 = float32 (default; exact-f32 MFMA, the parity-gated path),
  * 1 = bfloat16, 2 = IEEE half activations / weights with f32 accumulation (BASELINE.json
- * configs[2] / configs[4] precision; the text encoder, duration predictor and flow stay f32).  Weights are re-packed on
- * first use.  At 16 bit every ResBlock1 (c1, c2) pair with <= 128 channels runs as ONE fused
+ * configs[2] / configs[4] precision; the text encoder, duration predictor and flow stay f32).  The 16-bit weight
+ * copies are packed by this call (all or nothing: a failure leaves the model unpacked and is returned here).  At 16 bit every ResBlock1 (c1, c2) pair with <= 128 channels runs as ONE fused
  * kernel (intermediate kept in LDS); OR-ing WETTS_DECODER_UNFUSED into `precision` forces the
  * two-launch form, which is bit-identical (diagnostics / tests). */
 /* 3 = uint8 dynamic quantisation: the decoder graph `export_onnx.py --quant` leaves behind
@@ -250,7 +254,7 @@ int32_t wetts_dynamic_quant_conv1d(const float* x, const float* w, const float* 
  * the residual / skip update): 0 = float32 (default, the parity-gated path), 1 = bfloat16,
  * 2 = IEEE half activations / weights with f32 accumulation and an f32 skip sum; pre / post /
  * cond_layer convs, the coupling and everything else stay f32.  BASELINE.json configs[2] ("bf16")
- * precision for the part of the step that dominates at B = 64.  Weights are re-packed on first use. */
+ * precision for the part of the step that dominates at B = 64.  The 16-bit weight copies are packed by this call. */
 int32_t wetts_set_flow_precision(const wetts_model_t* m, int32_t precision);
 
 /* a15 monotonic_align.maximum_path (utils/monotonic_align.py:6-57).  Needs no model.
@@ -282,7 +286,9 @@ int32_t wetts_mask_rows(const float* x, const float* mask, int32_t B, int32_t C,
  * *frames_out = max(y_lengths) (<= max_frames, else WETTS_E_WORKSPACE), y_lengths_host[B].
  * eps_w [B,2,Tx] and eps_z [B,inter,max_frames] (row stride max_frames) are standard-normal
  * draws; either may be NULL, in which case it is drawn here from the model's Philox stream
- * (wetts_set_seed).  Errors the reference raises from inside its modules come back as return codes
+ * (wetts_set_seed) -- eps_w as [B,2,Tx] before the duration predictor, eps_z as a packed [B,inter,*frames_out]
+ * tensor once the frame count is known, the two draws the Python and C++ hosts make: a seed gives the same
+ * audio whatever `max_frames` the caller passed.  Errors the reference raises from inside its modules come back as return codes
  * after that one synchronisation: WETTS_E_DOMAIN (spline discriminant, transforms.py:171; non-finite
  * durations) and WETTS_E_INVALID (phoneme / speaker id outside its table).  audio needs capacity
  * B*max_frames*hop floats and is written PACKED as [B, (*frames_out)*hop].  workspace >= wetts_infer_workspace_bytes(). */

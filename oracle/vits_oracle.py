@@ -525,13 +525,30 @@ def _dq_params(t):
     return scale, zp
 
 
+def dynamic_quantize_linear(x):
+    """ONNX DynamicQuantizeLinear (opset 11, published operator definition): returns
+    (y uint8, y_scale f32 scalar, y_zero_point uint8 scalar).  Pinned by the known-answer examples of the
+    operator specification (tests/test_oracle_golden.py::test_onnx_spec_*)."""
+    scale, zp = _dq_params(x)
+    y = torch.clamp(torch.round(x / scale) + zp, 0, 255)
+    return y.to(torch.uint8), scale, zp.to(torch.uint8)
+
+
+def conv_integer(xq, wq, x_zero_point, w_zero_point, dilation=1, padding=0):
+    """ONNX ConvInteger (opset 10) on 1-D data: int32 sum of (x_q - z_x)(w_q - z_w); the zero padding of the
+    convolution stands for x_q = z_x (contributes 0).  xq [B,Cin,T] uint8, wq [Cout,Cin,k] uint8 -> int32.
+    float64 holds the int32 sums exactly."""
+    acc = F.conv1d(xq.double() - float(x_zero_point), wq.double() - float(w_zero_point), None,
+                   dilation=dilation, padding=padding)
+    return acc.to(torch.int32)
+
+
 def dynamic_quant_conv1d(x, w, b, dilation=1, padding=0):
-    """One quantised Conv node.  Exact integer arithmetic (float64 holds the int32 sums exactly)."""
-    sx, zx = _dq_params(x)
-    xq = torch.clamp(torch.round(x / sx) + zx, 0, 255)
-    sw, zw = _dq_params(w)
-    wq = torch.clamp(torch.round(w / sw) + zw, 0, 255)
-    acc = F.conv1d((xq - zx).double(), (wq - zw).double(), None, dilation=dilation, padding=padding)
+    """One quantised Conv node of the graph quantize_dynamic emits: DynamicQuantizeLinear(x) -> ConvInteger
+    against the statically quantised weights -> Cast(float) * (s_x * s_w) + bias.  Exact integer arithmetic."""
+    xq, sx, zx = dynamic_quantize_linear(x)
+    wq, sw, zw = dynamic_quantize_linear(w)  # quant_utils.quantize_nparray: the same per-tensor formulas
+    acc = conv_integer(xq, wq, zx, zw, dilation, padding)
     y = acc.to(torch.float32) * (sx * sw)
     if b is not None:
         y = y + b.view(1, -1, 1)

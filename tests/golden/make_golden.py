@@ -54,6 +54,9 @@ BIG_CASES = {
     "v1_b4x128": ("v1", 256, 1, 4, 128, [128, 97, 113, 128], 31, 301, (0.667, 1.0, 0.8)),
     "v3_b3x128": ("v3", 256, 2, 3, 128, [128, 97, 64], 32, 302, (0.667, 1.0, 0.8)),
     "vits2_vocos_b2x64": ("vits2_vocos_v1", 128, 1, 2, 64, [64, 49], 34, 304, (0.667, 1.0, 0.8)),
+    # BASELINE.json configs[3] as benched: AISHELL-3 v1 with the 218-row speaker table (the row count is
+    # data derived, task.py:229-232), ragged lengths, speaker ids at both ends of the table
+    "aishell3_b4x128": ("v1", 256, 218, 4, 128, [128, 57, 100, 33], 35, 305, (0.667, 1.0, 0.8), [0, 57, 217, 3]),
 }
 ONLY = os.environ.get("WETTS_GOLDEN_ONLY")  # comma-separated case names (default: all)
 
@@ -106,7 +109,8 @@ def big_noise(seed, shape, which):
 
 def run_big_cases():
     import unittest.mock as mock
-    for name, (mname, n_vocab, n_spk, B, Tx, lens, wseed, nseed, scales) in BIG_CASES.items():
+    for name, spec in BIG_CASES.items():
+        mname, n_vocab, n_spk, B, Tx, lens, wseed, nseed, scales = spec[:9]
         if ONLY and name not in ONLY.split(","):
             continue
         cfg = config.make_config(config.MODEL_CONFIGS[mname], n_vocab, n_spk)
@@ -117,6 +121,8 @@ def run_big_cases():
         x = torch.randint(0, n_vocab, (B, Tx), generator=gi)
         x_len = torch.tensor(lens, dtype=torch.long)
         sid = torch.randint(0, n_spk, (B,), generator=gi)
+        if len(spec) > 9:  # explicit speaker ids
+            sid = torch.tensor(spec[9], dtype=torch.long)
         ns, ls, nsw = scales
         real_randn, real_randn_like = torch.randn, torch.randn_like
 

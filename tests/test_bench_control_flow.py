@@ -1,0 +1,76 @@
+"""CPU tier: bench.py's N = 2 control flow end to end (its own rank spawn, gloo process group, weight broadcast and
+its verification, batching plan, timed loop, max / sum reductions, per-rank times, the JSON line) against the
+device-free stub backend of tests/bench_stub.py -- argument, sharding and reduce bugs surface without a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env=None, args=()):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.update(WETTS_BENCH_TEST_BACKEND="tests.bench_stub:StubBackend", WETTS_DIST_BACKEND="gloo",
+               PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+    env.update(extra_env or {})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--config", "aishell3", "--model", "tiny", "--batch", "8", "--presteps-s", "0.02", "--no-cpu-baseline"] + list(args)
+    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_two_ranks_control_flow_and_reductions():
+    sys.path.insert(0, ROOT)
+    import bench
+    from tests import bench_stub
+    from wetts_amd import batching
+    p = _run()
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout  # exactly ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["backend_label"].startswith("STUB")
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["blob_checksum_ok"] is True
+    assert len(d["rank_ms"]) == 2 and all(t > 0 for t in d["rank_ms"]) and d["imbalance"] >= 0
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "samples/s"
+    assert "cpu_baseline" not in d
+    # work = SUM over ranks: the same global utterance list the ranks drew, through the stub's duration rule
+    x, lens, sid = bench.make_inputs("tiny", 256, 218, 16, 128, True)
+    want = bench_stub.expected_frames(lens.tolist(), 0.92)
+    assert abs(d["config"]["valid_frames_per_step"] - want) < 1e-6
+    assert d["config"]["global_batch"] == 16
+    # time = MAX over ranks, value = all ranks' samples / that time
+    assert d["ms_per_step"] >= max(d["rank_ms"]) - 1e-6
+    hop = d["config"]["hop"]
+    assert abs(d["value"] - want * hop / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # the plan in the line is the plan of rank 0's shard
+    pl = batching.plan(lens.tolist(), 2, max_pad_frac=0.08)
+    assert d["config"]["sub_batch_plan"]["sizes_rank0"] == [len(b) for b in pl.buckets[0]]
+    assert d["config"]["padded_sub_batches_per_step"] == len(pl.buckets[0])
+    assert d["config"]["sub_batch_plan"]["phoneme_pad_frac"] <= 0.08 + 1e-9
+    assert d["roofline"]["launches"] > 0 and d["roofline"]["frac"] > 0
+
+
+def test_bench_refuses_a_corrupted_broadcast():
+    p = _run({"WETTS_STUB_CORRUPT_RANK": "1"})
+    assert p.returncode != 0
+    assert "weight blob differs across ranks" in (p.stderr + p.stdout)
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_cpu_baseline_is_n1_only_unless_asked(tmp_path):
+    """--cpu-baseline-multi is parsed and reaches the N > 1 branch (the timing itself needs the full-size oracle
+    run, which the GPU-box bench does; here only the flag plumbing: without the flag no key, see above)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py", "--gpus", "2", "--cpu-baseline-multi"]
+        a = bench.parse_args()
+    finally:
+        sys.argv = old
+    assert a.cpu_baseline_multi and a.cpu_sample == 1 and abs(a.length_scale - 0.92) < 1e-9

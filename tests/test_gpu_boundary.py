@@ -327,3 +327,32 @@ def test_randn_kernel_is_philox_box_muller():
     m, v = float(b.mean()), float(b.var())
     kurt = float(((b - m) ** 4).mean() / v ** 2)
     assert abs(m) < 3e-3 and abs(v - 1) < 5e-3 and abs(kurt - 3) < 3e-2 and torch.isfinite(big).all()
+
+
+def test_manual_seed_rewinds_the_noise_stream():
+    """torch.manual_seed(s) makes a run reproducible the way it does for the reference -- also when `s` is the
+    seed already in use (`manual_seed(0); a = infer(); manual_seed(0); b = infer()` gives a == b), while two calls
+    without a re-seed draw different noise.  The Philox (seed, offset) pair is the device generator's own."""
+    net, case, *_ = _model("tiny_sdp_b3")
+    x, xl, sid = (util.t(case[k]).cuda() for k in ("x", "x_lengths", "sid"))
+
+    def run():
+        o, _, ym, (z, z_p, _, _) = net.infer(x, xl, sid=sid, noise_scale=0.667, length_scale=1.0, noise_scale_w=0.8)
+        return o.cpu(), z_p.cpu()
+    torch.manual_seed(0)
+    a = run()
+    b = run()
+    torch.manual_seed(0)
+    c = run()
+    d = run()
+    torch.manual_seed(1)
+    e = run()
+    assert a[0].shape == c[0].shape and torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    assert b[0].shape == d[0].shape and torch.equal(b[0], d[0])  # the continuation is reproducible too
+    assert a[1].shape != b[1].shape or not torch.equal(a[1], b[1])
+    assert a[1].shape != e[1].shape or not torch.equal(a[1], e[1])
+    # an ATen draw from the same generator advances the stream like any other consumer
+    torch.manual_seed(0)
+    torch.randn(8, device="cuda")
+    f = run()
+    assert a[1].shape != f[1].shape or not torch.equal(a[1], f[1])

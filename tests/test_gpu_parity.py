@@ -144,6 +144,34 @@ def test_mas_large_matches_oracle_and_properties():
         assert ((d == 0) | (d == 1)).all() and cols[0] == 0 and cols[-1] == xx - 1
 
 
+@pytest.mark.parametrize("b,ty,tx", [(5, 300, 50), (3, 700, 128), (4, 500, 200), (2, 400, 300), (2, 300, 600),
+                                     (64, 1000, 200)])
+def test_mas_wave_kernel_shapes_bit_exact_vs_c_oracle(b, ty, tx):
+    """Every column-per-lane variant of mas_wave_kernel (Tx <= 64 / 128 / 256 / 512 / 1024) and the bench's large
+    shape against oracle/mas_oracle.c (pinned to the reference's own maximum_path by mas_kat.npz in the CPU tier),
+    bit for bit, ragged t_y / t_x, plus a batch item with all-equal scores (ties: the strict `<` of the
+    backtrack) and, in the small cases, items with t_x > t_y -- not a valid alignment problem, but the reference
+    returns something for it (wrapped row reads) and so does the general kernel those items fall back to."""
+    from tests.test_oracle_golden import _c_mas
+    from wetts_amd import monotonic_align
+    run = _c_mas()
+    g = torch.Generator().manual_seed(b * 7 + tx)
+    neg = torch.randn(b, ty, tx, generator=g)
+    neg[b - 1] = 0.25
+    t_y = torch.randint(ty // 2, ty + 1, (b,), generator=g)
+    t_x = torch.minimum(torch.randint(1, tx + 1, (b,), generator=g), t_y)
+    if b <= 5 and tx < ty:
+        t_y[0] = max(1, tx // 2)  # t_x > t_y
+        t_x[0] = tx
+    t_y[b - 1], t_x[b - 1] = ty, min(tx, ty)
+    mask = ((torch.arange(ty).view(1, ty, 1) < t_y.view(b, 1, 1)) &
+            (torch.arange(tx).view(1, 1, tx) < t_x.view(b, 1, 1))).float()
+    p = monotonic_align.maximum_path(neg.cuda(), mask.cuda()).cpu().numpy().astype(np.int32)
+    ref = run(neg.numpy(), t_y.numpy().astype(np.int32), t_x.numpy().astype(np.int32))
+    for i in range(b):
+        assert np.array_equal(p[i], ref[i]), f"item {i}: t_y={int(t_y[i])} t_x={int(t_x[i])}"
+
+
 def test_audio_to_int16():
     from oracle import vits_oracle as vo
     case = util.load_case("tiny_sdp_b3")
@@ -324,6 +352,48 @@ def test_dynamic_quant_conv1d_is_bit_exact_to_its_restatement(B, Cin, Cout, k, d
     got = out.cpu()
     assert torch.isfinite(got).all()
     assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
+def test_dynamic_quant_conv1d_reproduces_the_onnx_spec_known_answers():
+    """The pin of the uint8 variant: the published ONNX operator-specification examples of
+    DynamicQuantizeLinear-11 and ConvInteger-10 (tests/test_oracle_golden.py holds the literals and checks the
+    oracle against them on the CPU) through the HIP conv node `wetts_dynamic_quant_conv1d`.
+    * DynamicQuantizeLinear: x = the spec's X as [1,1,N]; a 1x1 weight tensor [[1],[255]] quantises to
+      w_q = [1,255], s_w = 1, z_w = 0, so output channel 0 = (Y - Y_ZeroPoint) * Y_Scale, bit for bit.
+    * ConvInteger: the spec's uint8 x (3x3, zero point 1) and 2x2 kernel of ones in the 1-D form of
+      onnx_convinteger_as_conv1d(); float x = (x_q - 1) / 4 plus one extra batch item holding q = 0 and q = 255,
+      which makes DynamicQuantizeLinear return exactly that x_q with scale 1/4 and zero point 1; a second output
+      channel holding 255 pins s_w = 1.  Channel 0 of items 0..3 = the spec's y_with_padding / 4 (and its inner
+      2x2 = the unpadded y)."""
+    from tests.test_oracle_golden import ONNX_DQL_KATS, ONNX_CONVINT_XZP, onnx_convinteger_as_conv1d
+    from wetts_amd import _lib
+    lib = _lib.load()
+
+    def run(x, w, k, pad):
+        B, Cin, T = x.shape
+        Cout = w.shape[0]
+        xd, wd = x.cuda().contiguous(), w.cuda().contiguous()
+        out = torch.full((B, Cout, T), float("nan"), device="cuda")
+        _lib.check(lib.wetts_dynamic_quant_conv1d(_lib.ptr(xd), _lib.ptr(wd), None, B, Cin, Cout, k, 1, pad, T,
+                                                  _lib.ptr(out), None), "dynamic_quant_conv1d")
+        return out.cpu().numpy()
+
+    for name, X, shape, Y, scale, zp in ONNX_DQL_KATS:
+        x = torch.tensor(X, dtype=torch.float32).view(1, 1, -1)
+        got = run(x, torch.tensor([[[1.0]], [[255.0]]]), 1, 0)
+        want = (np.array(Y, np.float32) - np.float32(zp)) * np.float32(scale)
+        assert np.array_equal(got[0, 0], want), (name, got[0, 0], want)
+        assert np.array_equal(got[0, 1], want * np.float32(255.0)), name
+
+    xq, wq, want = onnx_convinteger_as_conv1d()
+    s = np.float32(0.25)
+    x = (xq.astype(np.float32) - ONNX_CONVINT_XZP) * s
+    pin = np.full((1, 2, 4), 0.0, np.float32)
+    pin[0, 0, 0], pin[0, 1, 3] = (0 - ONNX_CONVINT_XZP) * s, (255 - ONNX_CONVINT_XZP) * s
+    w = np.concatenate([wq.astype(np.float32), np.zeros((1, 2, 3), np.float32)])
+    w[1, 0, 1] = 255.0
+    got = run(torch.from_numpy(np.concatenate([x, pin])), torch.from_numpy(w), 3, 1)
+    assert np.array_equal(got[:4, 0], want[:, 0].astype(np.float32) * s), got[:4, 0]
 
 
 @pytest.mark.parametrize("name", ["tiny_sdp_b3", "v1_b2", "v3_b2"])

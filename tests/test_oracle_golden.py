@@ -124,3 +124,86 @@ def test_philox_oracle_matches_random123_known_answers():
     x = vo.philox_randn(200000, 9, 3)
     assert abs(float(x.mean())) < 1e-2 and abs(float(x.std()) - 1) < 1e-2
     assert np.array_equal(vo.philox_randn(64, 9, 5), vo.philox_randn(72, 9, 3)[8:])
+
+
+# ------------------------------------------------------------------------------------------------
+# ONNX operator-specification known answers for the uint8 dynamic-quantisation variant
+# (wetts/vits/export_onnx.py:149-157 -> onnxruntime quantize_dynamic; ORT itself is a third-party
+# dependency absent from the reference tree, v1.13.1 per runtime/core/cmake/onnxruntime.cmake:3-11).
+# The inputs below are the literal examples of the published operator definitions
+# (onnx/docs/Operators.md, DynamicQuantizeLinear-11 and ConvInteger-10); ConvInteger's expected outputs are
+# literal in the specification, DynamicQuantizeLinear's are the specification's own numpy reference
+# formula evaluated on its inputs (= the contents of the backend test data test_dynamicquantizelinear*).
+# ------------------------------------------------------------------------------------------------
+ONNX_DQL_KATS = [  # (name, X, shape, Y, Y_Scale, Y_ZeroPoint)
+    ("dynamicquantizelinear", [0, 2, -3, -2.5, 1.34, 0.5], (6,),
+     [153, 255, 0, 26, 221, 179], 0.019607844, 153),
+    ("dynamicquantizelinear_max_adjusted", [-1.0, -2.1, -1.3, -2.5, -3.34, -4.0], (6,),
+     [191, 121, 172, 96, 42, 0], 0.015686275, 255),
+    ("dynamicquantizelinear_min_adjusted", [1, 2.1, 1.3, 2.5, 3.34, 4.0, 1.5, 2.6, 3.9, 4.0, 3.0, 2.345], (3, 4),
+     [64, 134, 83, 159, 213, 255, 96, 166, 249, 255, 191, 149], 0.015686275, 0),
+]
+# ConvInteger-10 example: x uint8 3x3 = 2..10 with x_zero_point 1, w uint8 2x2 of ones (w_zero_point 0)
+ONNX_CONVINT_X = np.arange(2, 11, dtype=np.uint8).reshape(3, 3)
+ONNX_CONVINT_XZP = 1
+ONNX_CONVINT_Y = np.array([12, 16, 24, 28], np.int32).reshape(2, 2)                         # no padding
+ONNX_CONVINT_Y_PADDED = np.array([1, 3, 5, 3, 5, 12, 16, 9, 11, 24, 28, 15, 7, 15, 17, 9],  # pads [1,1,1,1]
+                                 np.int32).reshape(4, 4)
+
+
+def onnx_spec_dql(X):
+    """The specification's reference formula for DynamicQuantizeLinear, transcribed."""
+    x_min = np.minimum(0, np.min(X))
+    x_max = np.maximum(0, np.max(X))
+    y_scale = np.float32((x_max - x_min) / (255 - 0))
+    y_zp = np.clip(round((0 - x_min) / y_scale), 0, 255).astype(np.uint8)
+    y = np.clip(np.round(X / y_scale) + y_zp, 0, 255).astype(np.uint8)
+    return y, y_scale, y_zp
+
+
+def onnx_convinteger_as_conv1d():
+    """The ConvInteger example (2-D, 2x2 kernel) restated as the 1-D conv the decoder uses: output row i of the
+    padded result convolves input rows (i-1, i) -- those two rows become the two input CHANNELS of batch item
+    i, a padding row is a row of x_zero_point -- and the kernel row [1, 1] over columns (j-1, j) becomes a
+    3-tap "same" kernel [1, 1, 0] over a row widened by one x_zero_point column.  Returns
+    (xq uint8 [4,2,4], wq uint8 [1,2,3], expected int32 [4,1,4] = ONNX_CONVINT_Y_PADDED)."""
+    zp = ONNX_CONVINT_XZP
+    rows = np.full((5, 4), zp, np.uint8)  # rows -1 .. 3, columns 0 .. 3 (column 3 = padding)
+    rows[1:4, 0:3] = ONNX_CONVINT_X
+    xq = np.stack([np.stack([rows[i], rows[i + 1]]) for i in range(4)])
+    wq = np.array([[[1, 1, 0], [1, 1, 0]]], np.uint8)
+    return xq, wq, ONNX_CONVINT_Y_PADDED.reshape(4, 1, 4)
+
+
+@pytest.mark.parametrize("name,X,shape,Y,scale,zp", ONNX_DQL_KATS)
+def test_onnx_spec_dynamicquantizelinear_known_answers(name, X, shape, Y, scale, zp):
+    X = np.array(X, np.float32).reshape(shape)
+    y_ref, s_ref, z_ref = onnx_spec_dql(X)  # the transcription reproduces the literals ...
+    assert y_ref.reshape(-1).tolist() == Y and float(s_ref) == float(np.float32(scale)) and int(z_ref) == zp
+    y, s, z = vo.dynamic_quantize_linear(torch.from_numpy(X))  # ... and the oracle reproduces both
+    assert y.dtype == torch.uint8 and y.numpy().reshape(-1).tolist() == Y
+    assert float(s) == float(np.float32(scale)) and int(z) == zp
+
+
+def test_onnx_spec_convinteger_known_answers():
+    # the published literals, by the definition itself (direct 2-D sums) ...
+    xs = ONNX_CONVINT_X.astype(np.int32) - ONNX_CONVINT_XZP
+    direct = np.array([[xs[i:i + 2, j:j + 2].sum() for j in range(2)] for i in range(2)], np.int32)
+    assert np.array_equal(direct, ONNX_CONVINT_Y)
+    assert np.array_equal(ONNX_CONVINT_Y_PADDED[1:3, 1:3], ONNX_CONVINT_Y)
+    # ... and through the oracle's ConvInteger in the 1-D form the decoder uses
+    xq, wq, want = onnx_convinteger_as_conv1d()
+    got = vo.conv_integer(torch.from_numpy(xq), torch.from_numpy(wq), ONNX_CONVINT_XZP, 0, padding=1)
+    assert got.dtype == torch.int32 and np.array_equal(got.numpy(), want)
+
+
+def test_dynamic_quant_conv1d_composes_the_spec_operators():
+    """The float-in / float-out conv node = DQL -> ConvInteger -> Cast * (s_x s_w) + bias, on the spec inputs:
+    a 1x1 conv whose weight tensor is [[1], [255]] quantises to w_q = [1, 255], s_w = 1, z_w = 0, so output
+    channel 0 is exactly (Y - Y_ZeroPoint) * Y_Scale of the DynamicQuantizeLinear example."""
+    for name, X, shape, Y, scale, zp in ONNX_DQL_KATS:
+        x = torch.tensor(X, dtype=torch.float32).view(1, 1, -1)
+        w = torch.tensor([[[1.0]], [[255.0]]])
+        out = vo.dynamic_quant_conv1d(x, w, None)
+        want = (np.array(Y, np.float32) - np.float32(zp)) * np.float32(scale)
+        assert np.array_equal(out[0, 0].numpy(), want), name

@@ -13,8 +13,9 @@ INFER_CASES = ["tiny_sdp_b3", "tiny_dp_b2", "tiny_sdp_nonoise", "tiny_sdp_single
                "tiny_preconv2_spk_b3",  # pre_conv2 flows (flows.py:16-92) + speaker-conditioned encoder
                # BASELINE-size phoneme counts (make_golden.py BIG_CASES): MFMA / flash attention, the
                # 128x128 and 64x256 conv tiles and fused ResBlock launches with >= 128 time tiles
-               "v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64"]
-BIG_CASES = ["v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64"]
+               "v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64",
+               "aishell3_b4x128"]  # configs[3]: 218-row speaker table, ragged, sids at both ends
+BIG_CASES = ["v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64", "aishell3_b4x128"]
 
 
 def big_case_noise(seed, shape, which):

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(1024) void mas_kernel(const float* __restrict__ neg
                                                    const int32_t* __restrict__ t_ys,
                                                    const int32_t* __restrict__ t_xs, int Ty, int Tx,
                                                    int32_t* __restrict__ path,
-                                                   float* __restrict__ values) {
+                                                   float* __restrict__ values, int only_irregular) {
   extern __shared__ float rows[];  // [2][Tx] previous / current DP row
   const int b = blockIdx.x;
   const int t_y = t_ys[b], t_x = t_xs[b];
@@ -26,6 +26,7 @@ __global__ __launch_bounds__(1024) void mas_kernel(const float* __restrict__ neg
   int32_t* pth = path + (int64_t)b * Ty * Tx;
   const float max_neg_val = -1e9f;
   if (t_y <= 0 || t_x <= 0 || t_y > Ty || t_x > Tx) return;
+  if (only_irregular && t_x <= t_y) return;  // answered by mas_wave_kernel
 
   // the reference copies neg_cent (astype) and updates the copy in place
   for (int64_t i = threadIdx.x; i < (int64_t)t_y * Tx; i += blockDim.x) val[i] = nc[i];
@@ -73,15 +74,180 @@ __global__ __launch_bounds__(1024) void mas_kernel(const float* __restrict__ neg
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The fast form (round 3): ONE wave walks one utterance; lane l owns the C consecutive columns
+// l*C .. l*C+C-1 (C = 1, 2, 4, 8, 16 => Tx <= 1024).
+//   forward   the previous DP row lives in registers; the only cross-lane operand of a row step is
+//             the left neighbour's last column, one DPP `wave_shr:1` move -- no LDS, no barrier in
+//             the row loop.  neg_cent rows are fetched D rows ahead through a register ring.  The
+//             comparison the backtrack will make at cell (y, x) -- value[y-1][x] < value[y-1][x-1],
+//             or the forced step x == y (monotonic_align.py:52-57) -- has both operands in hand
+//             during the forward step of that cell, so it is recorded there as ONE BIT per cell in
+//             LDS (Ty*Tx/8 bytes: 12.8 KB at 800 x 128) and the DP table itself is never stored.
+//             (Only in-band cells matter: the path stays inside the band, and an in-band cell's
+//             two comparison operands are in-band cells of the previous row -- see DESIGN 3.7.)
+//   backtrack a scalar walk over the bit table: one LDS read per 32/C rows (every lane reads its own
+//             word of the row group, the next group's read is in flight during the walk), then
+//             v_readlane + bit test per row; the column of every row goes to a u16 array in LDS.
+//   output    all four waves of the block write the path rows (zeros included) as full coalesced rows, so
+//             there is no memset pass and no scattered store.
+// Bit-exact with the reference for t_x <= t_y (the only case MAS is defined for); utterances with
+// t_x > t_y (the reference then reads wrapped / unwritten rows) are left to mas_kernel above.
+template <int C, int D>
+__global__ __launch_bounds__(256) void mas_wave_kernel(const float* __restrict__ neg_cent,
+                                                       const int32_t* __restrict__ t_ys,
+                                                       const int32_t* __restrict__ t_xs, int Ty, int Tx,
+                                                       int32_t* __restrict__ path) {
+  extern __shared__ uint32_t mas_lds[];
+  constexpr int R = 32 / C;  // rows per bit word
+  const int G = (Ty + R - 1) / R;
+  uint32_t* bits = mas_lds;                                         // [G][64]
+  unsigned short* idx = (unsigned short*)(mas_lds + (size_t)G * 64);  // [Ty] path column per row
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t_y = __builtin_amdgcn_readfirstlane(t_ys[b]);
+  const int t_x = __builtin_amdgcn_readfirstlane(t_xs[b]);
+  const bool valid = t_y > 0 && t_x > 0 && t_y <= Ty && t_x <= Tx && t_x <= t_y;
+  const float* nc = neg_cent + (int64_t)b * Ty * Tx;
+  int32_t* pth = path + (int64_t)b * Ty * Tx;
+  const float max_neg_val = -1e9f;
+  for (int y = threadIdx.x; y < Ty; y += blockDim.x) idx[y] = 0xFFFFu;
+  __syncthreads();
+
+  if (wave == 0 && valid) {
+    const int x0 = lane * C;
+    int64_t off[C];  // clamped column offsets (columns >= Tx read column Tx-1: loaded, never used)
+#pragma unroll
+    for (int c = 0; c < C; ++c) off[c] = min(x0 + c, Tx - 1);
+    float ring[D][C];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int yy = min(d, t_y - 1);
+#pragma unroll
+      for (int c = 0; c < C; ++c) ring[d][c] = nc[(int64_t)yy * Tx + off[c]];
+    }
+    float prev[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) prev[c] = 0.f;
+    uint32_t word = 0;
+    for (int yb = 0; yb < t_y; yb += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int y = yb + d;
+        if (y < t_y) {  // uniform
+          float raw[C];
+#pragma unroll
+          for (int c = 0; c < C; ++c) raw[c] = ring[d][c];
+          {  // refill this ring slot with row y + D
+            const int yy = min(y + D, t_y - 1);
+#pragma unroll
+            for (int c = 0; c < C; ++c) ring[d][c] = nc[(int64_t)yy * Tx + off[c]];
+          }
+          const int x_lo = max(0, t_x + y - t_y);
+          const int x_hi = min(t_x, y + 1);
+          // left neighbour's last column of the previous row
+          const float left = __int_as_float(__builtin_amdgcn_update_dpp(
+              0, __float_as_int(prev[C - 1]), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+          float cur[C];
+          uint32_t rowbits = 0;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const int x = x0 + c;
+            const float pl = (c == 0) ? left : prev[c - 1];  // value[y-1][x-1]
+            const float pc = prev[c];                        // value[y-1][x]
+            const float v_cur = (x == y) ? max_neg_val : pc;
+            const float v_prev = (x == 0) ? ((y == 0) ? 0.f : max_neg_val) : pl;
+            const bool in_band = x >= x_lo && x < x_hi;
+            cur[c] = in_band ? raw[c] + fmaxf(v_prev, v_cur) : raw[c];
+            const bool step = (x == y) || (pc < pl);
+            rowbits |= (step && x > 0) ? (1u << c) : 0u;
+          }
+#pragma unroll
+          for (int c = 0; c < C; ++c) prev[c] = cur[c];
+          const int r = y % R;
+          word |= rowbits << (r * C);
+          if (r == R - 1 || y == t_y - 1) {
+            bits[(size_t)(y / R) * 64 + lane] = word;
+            word = 0;
+          }
+        }
+      }
+    }
+    // the wave's own LDS writes are ordered before its reads by the compiler's waitcnt; no other wave reads
+    int index = t_x - 1;
+    int g = (t_y - 1) / R;
+    uint32_t w = bits[(size_t)g * 64 + lane];
+    for (; g >= 0; --g) {
+      const uint32_t wn = bits[(size_t)max(g - 1, 0) * 64 + lane];  // next group's word, in flight
+      const int y_top = min(t_y - 1, g * R + R - 1);
+      for (int y = y_top; y >= g * R; --y) {
+        if (lane == 0) idx[y] = (unsigned short)index;
+        const uint32_t ws = (uint32_t)__builtin_amdgcn_readlane((int)w, index / C);
+        const int bit = (ws >> ((y % R) * C + (index % C))) & 1u;
+        index -= (index != 0) ? bit : 0;
+      }
+      w = wn;
+    }
+  }
+  __syncthreads();
+
+  // path rows, zeros included: every wave writes whole rows (coalesced); lane l covers columns l*C..
+  for (int y = wave; y < Ty; y += (int)(blockDim.x >> 6)) {
+    const int col = idx[y];  // 0xFFFF: no path cell in this row
+    for (int xb = 0; xb < Tx; xb += 64 * C) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int x = xb + c * 64 + lane;  // stride-64 columns: each store instruction is one contiguous run
+        if (x < Tx) pth[(int64_t)y * Tx + x] = (x == col) ? 1 : 0;
+      }
+    }
+  }
+}
+
+template <int C, int D>
+static void launch_mas_wave(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, int B, int Ty,
+                            int Tx, int32_t* path, size_t lds, hipStream_t s) {
+  hipLaunchKernelGGL((mas_wave_kernel<C, D>), dim3(B), dim3(256), lds, s, neg_cent, t_ys, t_xs, Ty, Tx, path);
+}
+
+// utterances with t_x > t_y: the reference's arithmetic there (wrapped row reads) is reproduced by the
+// general kernel; `only_irregular` makes it skip the utterances the wave kernel has already answered
 int32_t k_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, int B, int Ty,
               int Tx, int32_t* path, float* values, hipStream_t s) {
   if (B == 0 || Ty == 0 || Tx == 0) return WETTS_OK;
-  WETTS_HIP_CHECK(hipMemsetAsync(path, 0, (size_t)B * Ty * Tx * sizeof(int32_t), s));
   int threads = Tx >= 1024 ? 1024 : ((Tx + 63) / 64) * 64;
   size_t lds = (size_t)2 * Tx * sizeof(float);
   WETTS_REQUIRE(lds <= 64 * 1024, "MAS: Tx=%d too large for the LDS row buffers", Tx);
+  // wave kernel: C columns per lane, bit table + row index array in LDS
+  int C = 1;
+  while (C * 64 < Tx) C *= 2;
+  const int R = C <= 32 ? 32 / C : 0;
+  const size_t wave_lds = R ? ((size_t)((Ty + R - 1) / R) * 64 * 4 + (size_t)Ty * 2 + 16) : 0;
+  const bool fast = C <= 16 && wave_lds <= 150 * 1024 && Ty < 0xFFFF && Tx < 0xFFFF;
+  if (fast) {
+    static bool attr_done = false;
+    if (!attr_done) {  // > 64 KB of dynamic LDS needs the opt-in
+      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done = true;
+    }
+    switch (C) {
+      case 1: launch_mas_wave<1, 8>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
+      case 2: launch_mas_wave<2, 8>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
+      case 4: launch_mas_wave<4, 8>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
+      case 8: launch_mas_wave<8, 4>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
+      default: launch_mas_wave<16, 2>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
+    }
+    WETTS_LAUNCH_CHECK();
+  } else {
+    WETTS_HIP_CHECK(hipMemsetAsync(path, 0, (size_t)B * Ty * Tx * sizeof(int32_t), s));
+  }
   hipLaunchKernelGGL(mas_kernel, dim3(B), dim3(threads), lds, s, neg_cent, t_ys, t_xs, Ty, Tx, path,
-                     values);
+                     values, fast ? 1 : 0);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

@@ -395,7 +395,7 @@ struct wetts_model {
   // MRF chains: the n_k ResBlocks of a stage are independent until their sum, so they run on
   // separate HIP streams (forked from / joined to the caller's stream with events); one chain's
   // launch tail and prologue/epilogue phases overlap another chain's MFMA work.
-  // bf16 decoder (opt-in, wetts_set_decoder_precision): weights packed on first use
+  // bf16 decoder (opt-in, wetts_set_decoder_precision): weights packed by the setter
   mutable int dec_precision = 0;  // 0 = f32, 1 = bf16, 2 = f16
   mutable int dec_unfused = 0;    // diagnostic: run ResBlock1 pairs as two conv launches
   int fuse32_lds = 160 * 1024;    // largest f32 pair tile run fused (WETTS_FUSE32_LDS, bytes)
@@ -418,15 +418,17 @@ struct wetts_model {
   int chain_pair_kmax = 3;        // WETTS_CHAIN_PAIR_KMAX: ... and pairs with at most this many taps at any width
   int fuse2_waste_pct = 15;       // ResBlock2 chains: max % of tile columns lost to c2's halo at C = 32
                                   // (HBM-bound, +6..30 %); half of it at C >= 64 (profiles/r01_conv32_rb2_chain.txt)
-  // 16-bit WaveNet layers of the flow (opt-in, wetts_set_flow_precision): weights packed on first use
+  // 16-bit WaveNet layers of the flow (opt-in, wetts_set_flow_precision): weights packed by the setter
   mutable int flow_precision = 0;  // 0 = f32, 1 = bf16, 2 = f16
   mutable std::vector<std::vector<PackedConvB>> b_wn_in, b_wn_rs;  // [flow][layer]
   mutable PackedConvB b_post;          // conv_post as a 32-row conv (row 0 = the weights), 32-channel models
   mutable float* b_post_wpad = nullptr;
-  // uint8 dynamic-quantisation decoder (precision 3): Conv1d weights quantised on first use
+  // uint8 dynamic-quantisation decoder (precision 3): Conv1d weights quantised by the setter
   mutable PackedQConv q_pre, q_cond, q_post;
   mutable std::vector<std::vector<PackedQConv>> q_c1, q_c2;  // per resblock
   mutable bool q_packed = false;
+  // which 16-bit type the flow / decoder copies currently hold (0 = none); set only after EVERY layer is packed
+  mutable int flow_packed_prec = 0, dec_packed_prec = 0;
   mutable std::vector<PackedConvB> b_ups;
   mutable std::vector<std::vector<PackedConvB>> b_c1, b_c2;  // per resblock
   // device status word the stage calls OR their WETTS_STATUS_* bits into (wetts_set_status_word)
@@ -1269,11 +1271,15 @@ namespace wetts {
 // 128-row, 64-channel-chunk tile those epilogues are instantiated for (conv_bf16.hip)
 static bool wn16_fused(int H) { return H % 16 == 0 && H >= 128; }
 
-static int32_t pack_flow_bf16(const wetts_model* m, hipStream_t s) {
-  const int f16 = m->flow_precision == 2 ? 1 : 0;
-  if (!m->b_wn_in.empty() && m->b_wn_in[0][0].f16 == f16) return WETTS_OK;
+static void free_flow_bf16(const wetts_model* m) {
   for (auto& v : m->b_wn_in) for (auto& pc : v) free_packed_bf16(&pc);
   for (auto& v : m->b_wn_rs) for (auto& pc : v) free_packed_bf16(&pc);
+  m->b_wn_in.clear();
+  m->b_wn_rs.clear();
+  m->flow_packed_prec = 0;
+}
+
+static int32_t pack_flow_bf16_layers(const wetts_model* m, int f16, hipStream_t s) {
   const wetts_config_t* c = &m->cfg;
   const int H = c->hidden_channels, NL = c->flow_wn_layers, fk = c->flow_kernel_size;
   m->b_wn_in.assign(c->flow_n_flows, std::vector<PackedConvB>(NL));
@@ -1293,6 +1299,21 @@ static int32_t pack_flow_bf16(const wetts_model* m, hipStream_t s) {
   }
   return WETTS_OK;
 }
+
+// 16-bit copies of the flow's WN weights for the precision in force.  All or nothing: a failure part-way
+// (hipMalloc) frees what was built and leaves the model "not packed", so the next call retries cleanly.
+static int32_t pack_flow_bf16(const wetts_model* m, hipStream_t s) {
+  const int want = m->flow_precision;
+  if (want == 0 || m->flow_packed_prec == want) return WETTS_OK;
+  free_flow_bf16(m);
+  const int32_t rc = pack_flow_bf16_layers(m, want == 2 ? 1 : 0, s);
+  if (rc != WETTS_OK) {
+    free_flow_bf16(m);
+    return rc;
+  }
+  m->flow_packed_prec = want;
+  return WETTS_OK;
+}
 }  // namespace wetts
 
 int32_t wetts_set_flow_precision(const wetts_model_t* m, int32_t precision) {
@@ -1301,6 +1322,9 @@ int32_t wetts_set_flow_precision(const wetts_model_t* m, int32_t precision) {
   WETTS_REQUIRE(precision == 0 || m->cfg.hidden_channels % 32 == 0,
                 "the 16-bit flow needs hidden_channels to be a multiple of 32");
   m->flow_precision = precision;
+  // packed here, not on first use: the stage calls never allocate (header contract)
+  WETTS_TRY(pack_flow_bf16(m, nullptr));
+  if (precision) WETTS_HIP_CHECK(hipStreamSynchronize(nullptr));
   return WETTS_OK;
 }
 
@@ -1608,6 +1632,9 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
     }
     const bool forked = m->mrf_streams > 1;
     if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_fork, s));
+    // the chain kernel addresses one utterance's [C][T] plane with 32-bit byte offsets and buffer descriptors: a
+    // plane of 2 GiB or more (one utterance above ~16.7 M samples at C = 32) takes the conv-by-conv path instead
+    const bool chain_addr_ok = (int64_t)ch * len * 4 < (int64_t)INT32_MAX;
     for (int j = 0; j < nk; ++j) {
       const RB& rb = m->rbs[i * nk + j];
       hipStream_t sj = (forked && j > 0 && j < m->mrf_streams) ? m->aux_stream[j] : s;
@@ -1618,7 +1645,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
       const float* rx = xu;  // current resblock x
       // a whole ResBlock1 in one launch (resblock_chain32.hip): x read once, the MRF sum written once
       if (c->resblock == 1 && !m->dec_unfused && !forked && nd <= RESCHAIN32_MAX_PAIRS &&
-          ch <= m->chain_whole_maxc && m->chain_whole_waste_pct > 0 && len % 4 == 0 &&
+          ch <= m->chain_whole_maxc && m->chain_whole_waste_pct > 0 && len % 4 == 0 && chain_addr_ok &&
           resblock_chain32_supported(rb.c1.data(), rb.c2.data(), nd, m->fuse32_lds / 2,
                                      m->chain_whole_waste_pct)) {
         int dl[RESCHAIN32_MAX_PAIRS];
@@ -1681,7 +1708,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
         // it over 4x as many CUs (bench.py --stream: 3.4 -> 2.8 ms per window)
         const int pair_tiles = cdiv(len, pair_nto(ch, rb.c1[d].ktaps)) * B;
         // one (c1, c2) pair on the chain kernel: every pair of the C = 32 stage, k = 3 pairs at any width
-        const bool chain1 = c->resblock == 1 && !m->dec_unfused && len % 4 == 0 &&
+        const bool chain1 = c->resblock == 1 && !m->dec_unfused && len % 4 == 0 && chain_addr_ok &&
                             (ch <= m->chain_pair_maxc || rb.c1[d].ktaps <= m->chain_pair_kmax) &&
                             resblock_chain32_supported(&rb.c1[d], &rb.c2[d], 1, m->fuse32_lds / 2, 100) &&
                             pair_tiles >= m->fuse_min_blocks;
@@ -1787,13 +1814,18 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
 }  // namespace wetts
 
 namespace wetts {
-static int32_t pack_decoder_bf16(const wetts_model* m, hipStream_t s) {
-  const int f16 = m->dec_precision == 2 ? 1 : 0;
-  if (!m->b_ups.empty() && m->b_ups[0].f16 == f16) return WETTS_OK;
+static void free_decoder_bf16(const wetts_model* m) {
   for (auto& pc : m->b_ups) free_packed_bf16(&pc);
   for (auto& v : m->b_c1) for (auto& pc : v) free_packed_bf16(&pc);
   for (auto& v : m->b_c2) for (auto& pc : v) free_packed_bf16(&pc);
   free_packed_bf16(&m->b_post);
+  m->b_ups.clear();
+  m->b_c1.clear();
+  m->b_c2.clear();
+  m->dec_packed_prec = 0;
+}
+
+static int32_t pack_decoder_bf16_layers(const wetts_model* m, int f16, hipStream_t s) {
   const wetts_config_t* c = &m->cfg;
   const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
   m->b_ups.resize(c->n_upsamples);
@@ -1832,6 +1864,20 @@ static int32_t pack_decoder_bf16(const wetts_model* m, hipStream_t s) {
                                    hipMemcpyDeviceToDevice, s));
     WETTS_TRY(pack_conv_weight_bf16(m->b_post_wpad, nullptr, 32, ch, 7, 1, 3, 0, 0, f16, s, &m->b_post));
   }
+  return WETTS_OK;
+}
+
+// all or nothing, like pack_flow_bf16
+static int32_t pack_decoder_bf16(const wetts_model* m, hipStream_t s) {
+  const int want = m->dec_precision;
+  if ((want != 1 && want != 2) || m->dec_packed_prec == want) return WETTS_OK;
+  free_decoder_bf16(m);
+  const int32_t rc = pack_decoder_bf16_layers(m, want == 2 ? 1 : 0, s);
+  if (rc != WETTS_OK) {
+    free_decoder_bf16(m);
+    return rc;
+  }
+  m->dec_packed_prec = want;
   return WETTS_OK;
 }
 
@@ -1987,8 +2033,18 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
 }  // namespace wetts
 
 namespace wetts {
-static int32_t pack_decoder_u8(const wetts_model* m, hipStream_t s) {
-  if (m->q_packed) return WETTS_OK;
+static void free_decoder_u8(const wetts_model* m) {
+  free_packed_qconv(&m->q_pre);
+  free_packed_qconv(&m->q_cond);
+  free_packed_qconv(&m->q_post);
+  for (auto& v : m->q_c1) for (auto& pc : v) free_packed_qconv(&pc);
+  for (auto& v : m->q_c2) for (auto& pc : v) free_packed_qconv(&pc);
+  m->q_c1.clear();
+  m->q_c2.clear();
+  m->q_packed = false;
+}
+
+static int32_t pack_decoder_u8_layers(const wetts_model* m, hipStream_t s) {
   const wetts_config_t* c = &m->cfg;
   const int I = c->inter_channels, C0 = c->upsample_initial_channel;
   const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
@@ -2022,6 +2078,18 @@ static int32_t pack_decoder_u8(const wetts_model* m, hipStream_t s) {
     }
   }
   WETTS_TRY(pack_qconv_weight(m->T("dec.conv_post.weight"), nullptr, 1, ch, 7, 1, 3, s, &m->q_post));
+  return WETTS_OK;
+}
+
+// all or nothing: a failure part-way frees the buffers already created (a retry does not leak them)
+static int32_t pack_decoder_u8(const wetts_model* m, hipStream_t s) {
+  if (m->q_packed) return WETTS_OK;
+  free_decoder_u8(m);
+  const int32_t rc = pack_decoder_u8_layers(m, s);
+  if (rc != WETTS_OK) {
+    free_decoder_u8(m);
+    return rc;
+  }
   m->q_packed = true;
   return WETTS_OK;
 }
@@ -2176,6 +2244,10 @@ int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision) {
                   "bf16 decoder needs every stage width to be a multiple of 32 channels");
   }
   m->dec_precision = precision;
+  // packed here, not on first use: the stage calls never allocate (header contract)
+  if (precision == 1 || precision == 2) WETTS_TRY(pack_decoder_bf16(m, nullptr));
+  if (precision == 3) WETTS_TRY(pack_decoder_u8(m, nullptr));
+  if (precision) WETTS_HIP_CHECK(hipStreamSynchronize(nullptr));
   return WETTS_OK;
 }
 
@@ -2392,11 +2464,6 @@ int32_t wetts_infer(const wetts_model_t* m, const int64_t* x, const int64_t* x_l
     m->rng_offset += ((uint64_t)B * 2 * Tx + 3) / 4;
     eps_w = own_eps_w;
   }
-  if (!eps_z) {
-    WETTS_TRY(k_randn(own_eps_z, (int64_t)B * I * max_frames, m->rng_seed, m->rng_offset, s));
-    m->rng_offset += ((uint64_t)B * I * max_frames + 3) / 4;
-    eps_z = own_eps_z;
-  }
   WETTS_TRY(wetts_speaker_embedding(m, sid, B, g, stream));
   const float* gp = has_g(c) ? g : nullptr;
   WETTS_TRY(wetts_text_encoder(m, x, x_lengths, gp, B, Tx, x_enc, stats, x_mask, scratch,
@@ -2435,9 +2502,18 @@ int32_t wetts_infer(const wetts_model_t* m, const int64_t* x, const int64_t* x_l
     set_error("infer: predicted %lld frames > capacity %d", (long long)Ty, max_frames);
     return WETTS_E_WORKSPACE;
   }
-  WETTS_TRY(wetts_length_regulate(m, stats, cum, x_mask, ylen, eps_z, (int64_t)I * max_frames,
-                                  max_frames, noise_scale, B, Tx, (int)Ty, f2p, y_mask, nullptr,
-                                  nullptr, nullptr, z_p, stream));
+  // models.py:267 `torch.randn_like(m_p)`: drawn now that Ty is known, packed [B, I, Ty] -- the same draw the
+  // Python and C++ hosts make, so a seed gives the same audio whatever capacity the caller passed
+  int64_t eps_bs = (int64_t)I * max_frames, eps_cs = max_frames;  // a caller's eps_z: [B, I, max_frames]
+  if (!eps_z) {
+    WETTS_TRY(k_randn(own_eps_z, (int64_t)B * I * Ty, m->rng_seed, m->rng_offset, s));
+    m->rng_offset += ((uint64_t)B * I * Ty + 3) / 4;
+    eps_z = own_eps_z;
+    eps_bs = (int64_t)I * Ty;
+    eps_cs = Ty;
+  }
+  WETTS_TRY(wetts_length_regulate(m, stats, cum, x_mask, ylen, eps_z, eps_bs, eps_cs, noise_scale, B, Tx,
+                                  (int)Ty, f2p, y_mask, nullptr, nullptr, nullptr, z_p, stream));
   WETTS_TRY(wetts_flow_reverse(m, z_p, y_mask, gp, B, (int)Ty, z, scratch, scratch_bytes, stream));
   // o = dec((z * y_mask), g); audio rows are packed with stride Ty*hop
   WETTS_TRY(wetts_hifigan(m, z, (int64_t)I * Ty, Ty, y_mask, Ty, gp, B, (int)Ty, audio, scratch,

@@ -6,8 +6,9 @@ same wav output) running the MI355X HIP path.
 
 test-file line: `wav_path|speaker|ph ph ph ...` (inference.py:83-85); tables are `symbol id` lines
 (inference.py:55-64).  Writes outdir/basename(wav_path) as int16 at hps.data.sampling_rate with
-the reference's peak normalisation (inference.py:100-110).  Extra: --batch N groups lines into
-padded batches (the reference loops one utterance at a time)."""
+the reference's peak normalisation (inference.py:100-110).  Extra: --batch N plans the whole test file into
+length-sorted padded sub-batches of at most N utterances (wetts_amd/batching.py; the reference loops one utterance
+at a time) and writes the files in the order of the test file."""
 import argparse
 import sys
 import time
@@ -16,7 +17,7 @@ import numpy as np
 import torch
 from scipy.io import wavfile
 
-from . import config as _config
+from . import batching, config as _config
 from .models import SynthesizerTrn, load_checkpoint
 
 
@@ -29,7 +30,10 @@ def get_args(argv=None):
     parser.add_argument("--speaker_table", default=True, help="speaker table")
     parser.add_argument("--test_file", required=True, help="test file")
     parser.add_argument("--gpu", type=int, default=0, help="gpu id for this local rank")
-    parser.add_argument("--batch", type=int, default=1, help="utterances per infer() call")
+    parser.add_argument("--batch", type=int, default=1,
+                        help="largest padded sub-batch per infer() call (1 = the reference's loop)")
+    parser.add_argument("--max_pad_frac", type=float, default=0.08,
+                        help="padding share the sub-batch plan may spend (with --batch > 1)")
     parser.add_argument("--seed", type=int, default=None, help="seed for the sampling noise")
     return parser.parse_args(argv)
 
@@ -68,32 +72,35 @@ def main(argv=None):
     net_g = build_model(args, phone_dict, speaker_dict, hps)
     if args.seed is not None:
         torch.manual_seed(args.seed)
-    device = net_g.device
     lines = [l.strip().split("|") for l in open(args.test_file) if l.strip()]
     sr = hps.data.sampling_rate
-    for i in range(0, len(lines), max(1, args.batch)):
-        group = lines[i:i + max(1, args.batch)]
-        seqs = [[phone_dict[s] for s in text.split()] for (_, _, text) in group]  # KeyError like ref
-        sids = [speaker_dict[spk] for (_, spk, _) in group]
-        T = max(len(s) for s in seqs)
-        x = torch.zeros(len(seqs), T, dtype=torch.long)
-        for b, s in enumerate(seqs):
-            x[b, :len(s)] = torch.tensor(s, dtype=torch.long)
-        x_len = torch.tensor([len(s) for s in seqs], dtype=torch.long)
+    seqs = [[phone_dict[s] for s in text.split()] for (_, _, text) in lines]  # KeyError like the reference
+    sids = [speaker_dict[spk] for (_, spk, _) in lines]
+    if args.batch <= 1:
+        # the reference's loop: one utterance per infer() call (inference.py:83-110)
+        buckets = [batching.Bucket([i], max(1, len(s))) for i, s in enumerate(seqs)]
+    else:
+        # --batch N: the whole file is planned at once -- length-sorted padded sub-batches of at most N
+        # utterances with a bounded padding share (wetts_amd/batching.py), written back in file order
+        buckets = batching.plan([len(s) for s in seqs], 1, max_pad_frac=args.max_pad_frac,
+                                max_batch=args.batch).buckets[0]
+    for bk in buckets:
         st = time.time()
-        o, _, y_mask, _ = net_g.infer(x.to(device), x_len.to(device),
-                                      sid=torch.tensor(sids, dtype=torch.long, device=device),
-                                      noise_scale=0.667, noise_scale_w=0.8, length_scale=1)
-        n_valid = (y_mask[:, 0].sum(1) * net_g.hop_length).long()
-        pcm = net_g.audio_to_int16(o, n_valid).cpu().numpy()
+        audio = batching.synthesize(net_g, seqs, sids, noise_scale=0.667, noise_scale_w=0.8, length_scale=1,
+                                    buckets=[bk])
+        n_total = 0
+        pcms = []
+        for i in bk.indices:
+            a = audio[i].reshape(1, -1)
+            pcms.append((i, net_g.audio_to_int16(a).cpu().numpy()[0]))  # per-utterance peak normalisation (:100-110)
+            n_total += a.shape[1]
         torch.cuda.synchronize()
         dt = time.time() - st
-        n_valid = n_valid.cpu().numpy()
-        for b, (audio_path, _, _) in enumerate(group):
+        for i, pcm in pcms:
+            audio_path = lines[i][0]
             print(audio_path)
-            wavfile.write(args.outdir + "/" + audio_path.split("/")[-1], sr,
-                          pcm[b, :int(n_valid[b])].astype(np.int16))
-        print("RTF {}".format(dt / (float(n_valid.sum()) / sr)))
+            wavfile.write(args.outdir + "/" + audio_path.split("/")[-1], sr, pcm.astype(np.int16))
+        print("RTF {}".format(dt / (float(n_total) / sr)))
         sys.stdout.flush()
 
 

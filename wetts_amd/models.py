@@ -10,8 +10,8 @@ scope and raise.
 Extra, optional keyword arguments (not in the reference): `eps_w` / `eps_z` inject the two
 standard-normal draws the reference makes with torch.randn (duration_predictors.py:257,
 models.py:267) so results can be compared bit-for-noise with a CPU run.  Without them the draws
-come from the library's Philox kernel (`wetts_randn`), seeded from torch.initial_seed() so that
-torch.manual_seed() makes a run reproducible the way it does for the reference.
+come from the library's Philox kernel (`wetts_randn`), driven by the device generator's (seed, offset) so
+that torch.manual_seed() makes a run reproducible the way it does for the reference.
 
 One host synchronisation per infer(): y_lengths and the device status word (errors the reference
 raises from inside its modules: IndexError of nn.Embedding, the spline's discriminant assert) come
@@ -80,8 +80,6 @@ class SynthesizerTrn:
         self._ws = _Workspace()
         self.quiet = True      # the reference prints stage timers on every call (:273-279)
         self.last_status = 0
-        self._rng_seed = None  # torch.initial_seed() the Philox offset below belongs to
-        self._rng_offset = 0
 
     # ---- nn.Module-shaped plumbing the reference's callers use -------------------------------
     def eval(self):
@@ -260,16 +258,21 @@ class SynthesizerTrn:
             lib.wetts_set_status_word(self._handle, None, s)
 
     def _randn(self, *shape):
-        """Standard-normal tensor from the library's Philox kernel (replaces torch.randn)."""
+        """Standard-normal tensor from the library's Philox kernel (replaces torch.randn).
+
+        The (seed, offset) pair is the device generator's own -- torch.cuda.default_generators[device] -- read
+        and advanced here exactly as an ATen kernel would: torch.manual_seed(s) therefore rewinds the stream
+        (also when s is the seed already in use: the reference's `manual_seed(0); a = infer(); manual_seed(0);
+        b = infer()` gives a == b, and so does this), successive calls continue it, and no ATen kernel runs."""
         lib = self._require()
-        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-        if seed != self._rng_seed:
-            self._rng_seed, self._rng_offset = seed, 0
+        gen = torch.cuda.default_generators[self.device.index]
+        seed = gen.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        offset = int(gen.get_offset())
         out = torch.empty(*shape, dtype=torch.float32, device=self.device)
         n = out.numel()
-        _lib.check(lib.wetts_randn(_lib.ptr(out), n, seed, self._rng_offset,
-                                   _lib.current_stream_ptr()), "randn")
-        self._rng_offset += (n + 3) // 4
+        _lib.check(lib.wetts_randn(_lib.ptr(out), n, seed, offset, _lib.current_stream_ptr()), "randn")
+        used = (n + 3) // 4  # Philox counters consumed (4 normals each)
+        gen.set_offset(offset + (used + 3) // 4 * 4)  # ATen keeps the offset a multiple of 4
         return out
 
     def _encode_stages(self, lib, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w,

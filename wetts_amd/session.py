@@ -41,7 +41,20 @@ class _SessionBase:
 
 
 class InferenceSession(_SessionBase):
-    """The non-streaming model (export_forward, models.py:333-344)."""
+    """The non-streaming model (export_forward, models.py:333-344).
+
+    `max_pad_frac=None` (default) is the reference's call: the whole feed is ONE padded batch.  With a float, a
+    B > 1 feed of ragged `input_lengths` is decoded as the length-sorted padded sub-batches `batching.plan`
+    chooses (padding share <= max_pad_frac) and the rows are put back in feed order: `output` keeps its shape
+    [B,1,T_audio]; row b holds its utterance's valid audio (what infer() returns for it inside its sub-batch)
+    followed by zeros instead of the decoded padding tail.  `max_batch` caps a sub-batch (the Triton
+    `generator` model's max_batch_size is 32, generator/config.pbtxt)."""
+
+    def __init__(self, model: SynthesizerTrn, max_pad_frac=None, max_batch=0):
+        super().__init__(model)
+        self.max_pad_frac = max_pad_frac
+        self.max_batch = max_batch
+        self.last_plan_stats = None
 
     def get_inputs(self):
         return [_Arg("input", ["B", "T"], "tensor(int64)"),
@@ -53,14 +66,37 @@ class InferenceSession(_SessionBase):
 
     def run(self, output_names, feeds, run_options=None):
         self._check(output_names)
-        x = self._dev(feeds["input"], torch.int64)
-        xl = self._dev(feeds["input_lengths"], torch.int64)
         scales = np.asarray(feeds["scales"], dtype=np.float32)
+        ids = np.asarray(feeds["input"])
+        lens = np.asarray(feeds["input_lengths"]).reshape(-1)  # Triton feeds [B,1] (tts/1/model.py:128)
         sid = feeds.get("sid")  # the Triton `generator` model omits it (config.pbtxt:21-46)
+        B = ids.shape[0]
+        if self.max_pad_frac is not None and B > 1 and len(set(int(v) for v in lens)) > 1:
+            return [self._run_bucketed(ids, lens, scales, sid)]
+        x = self._dev(ids, torch.int64)
+        xl = self._dev(lens, torch.int64)
         sid = self._dev(sid, torch.int64) if sid is not None else \
             torch.zeros(x.shape[0], dtype=torch.int64, device=self.model.device)
         audio = self.model.export_forward(x, xl, torch.from_numpy(scales), sid)
         return [audio.cpu().numpy()]
+
+    def _run_bucketed(self, ids, lens, scales, sid):
+        from . import batching
+        m = self.model
+        B = ids.shape[0]
+        seqs = [ids[b, :int(lens[b])] for b in range(B)]
+        sids = np.zeros(B, np.int64) if sid is None else np.asarray(sid).reshape(-1)
+        # row 0 of `scales` applies to the whole batch, as in export_forward (models.py:333-344)
+        outs, st = batching.synthesize(m, seqs, sids, noise_scale=float(scales[0][0]),
+                                       length_scale=float(scales[0][1]), noise_scale_w=float(scales[0][2]),
+                                       max_pad_frac=self.max_pad_frac, max_batch=self.max_batch,
+                                       return_stats=True)
+        self.last_plan_stats = st
+        T = max(int(o.numel()) for o in outs)
+        audio = torch.zeros(B, 1, T, dtype=torch.float32, device=m.device)
+        for b, o in enumerate(outs):
+            audio[b, 0, :o.numel()] = o
+        return audio.cpu().numpy()
 
 
 class EncoderSession(_SessionBase):

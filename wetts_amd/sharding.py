@@ -52,7 +52,10 @@ def launch_ranks(n, script, argv, require_gpus=True):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(script)]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    # the deployment image exports HSA_ENABLE_IPC_MODE_LEGACY=0 (its host driver only supports dmabuf IPC; without
+    # it RCCL fails in hipIpcGetMemHandle); a child environment built here must carry the same setting, and an
+    # operator's own value wins
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd + list(argv), env=env)
 
 
