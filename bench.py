@@ -55,6 +55,10 @@ def parse_args():
                     help="0 = sub-batches chosen by wetts_amd.batching.plan (SURVEY 8e: each rank buckets its "
                          "length-sorted shard); N > 0 = N equal-count buckets (round-2 behaviour, for A/B)")
     ap.add_argument("--max-pad-frac", type=float, default=0.08, help="padding share batching.plan may spend")
+    ap.add_argument("--decode", default=None, choices=["padded", "ragged"],
+                    help="padded = the reference's batched call (every row decoded to the longest of its sub-batch); "
+                         "ragged = SynthesizerTrn.infer(ragged=True): every utterance decoded over its own frames, "
+                         "the audio the reference's one-utterance-per-call CLI produces (default for ragged presets)")
     ap.add_argument("--max-batch", type=int, default=0, help="largest padded sub-batch (0 = no cap)")
     ap.add_argument("--length-scale", type=float, default=0.92,
                     help="calibrated so the synthetic duration heads give 6.0 +- 0.5 frames/phoneme (SURVEY 8d)")
@@ -193,7 +197,7 @@ PRESETS = {
     # configs[3]: AISHELL-3 v1 (examples/aishell-3/configs/v1.json: baker v1 at sampling_rate 44100),
     # 218-row speaker table, 64 ragged utterances per GPU (512 over 8 GPUs)
     "aishell3": dict(model="v1", batch=64, phonemes=128, ragged=True, n_speakers=218, sr=44100,
-                     decoder_dtype="f32", flow_dtype="f32", tag="BASELINE.json configs[3]"),
+                     decoder_dtype="f32", flow_dtype="f32", decode="ragged", tag="BASELINE.json configs[3]"),
     # configs[4]: builder-defined 48 kHz stress shape (no such reference recipe), fp16
     "stress48k": dict(model="stress48k", batch=16, phonemes=128, ragged=False, n_speakers=1,
                       sr=48000, decoder_dtype="f16", flow_dtype="f16", tag="BASELINE.json configs[4]"),
@@ -465,6 +469,9 @@ def main():
     # SURVEY 8(d) duration pinning: 6.0 +- 0.5 frames per phoneme.  The synthetic duration heads give
     # ceil(6 e^{0.1 z}) = 6.57 on average at length_scale 1; 0.92 calibrates the mean to 6.0-6.1
     infer_kw = dict(noise_scale=0.667, length_scale=args.length_scale, noise_scale_w=0.8)
+    decode = args.decode or pre.get("decode", "padded")
+    if decode == "ragged":
+        infer_kw["ragged"] = True
 
     # ---- weights: rank 0 builds the blob, one broadcast over RCCL, every rank repacks locally
     numel = checkpoint.blob_numel(cfg)
@@ -504,7 +511,8 @@ def main():
     # cut into padded sub-batches (the plan is deterministic, every rank computes the same one)
     total = batch * world
     x, lens, sid = make_inputs(mname, n_vocab, n_speakers, total, phonemes, ragged)
-    pl = batching.plan(lens.tolist(), world, max_pad_frac=args.max_pad_frac, max_batch=args.max_batch)
+    pl = batching.plan(lens.tolist(), world, max_pad_frac=args.max_pad_frac, max_batch=args.max_batch,
+                       ragged=decode == "ragged")
     my_buckets = pl.buckets[rank]
     if args.buckets > 0:  # A/B: round 2's fixed number of equal-count buckets
         my_buckets = batching.equal_count_buckets(pl.shards[rank], lens.tolist(), args.buckets)
@@ -557,7 +565,8 @@ def main():
         frames += float(ym.sum().item())
     mrf_ms, mrf_launches = be.read_mrf_timing(net)
     be.set_mrf_timing(net, False)
-    padded_frames = float(sum(ym.numel() for ym in masks))  # B*Ty: what the decoder computes
+    padded_frames = float(sum(ym.numel() for ym in masks))  # B*Ty: what a padded decode computes
+    decoded_frames = frames if decode == "ragged" else padded_frames  # ragged: every row over its own frames
 
     # PCIe-inclusive variant (SURVEY 8d's wall: H2D of the ids, D2H of the audio; the driver contract
     # says inputs are resident when the timed region starts, so this is reported beside `value`,
@@ -570,7 +579,7 @@ def main():
     pcie_pipe_rate = be.pcie_pass(net, pinned, n_pipe, True, infer_kw)
 
     # ---- reduce over ranks: time = max, work = sum; every rank's own loop time is gathered for `rank_ms`
-    stat = torch.tensor([elapsed, frames, padded_frames, mrf_ms, float(mrf_launches), pcie_rate, pcie_pipe_rate],
+    stat = torch.tensor([elapsed, frames, decoded_frames, mrf_ms, float(mrf_launches), pcie_rate, pcie_pipe_rate],
                         dtype=torch.float64, device=dev)
     rank_ms = [my_elapsed / args.steps * 1e3]
     if world > 1:
@@ -593,9 +602,9 @@ def main():
     mfl, mby = be.hifigan_cost(cfg)
     # dominant kernel: algorithmic FLOPs of the MRF convs over the frames rank 0 decoded
     # (padded frames: the decoder has no masks, decoders.py:63-82), / live device time
-    mrf_flops = mfl * padded_frames
+    mrf_flops = mfl * decoded_frames
     mrf_tflops = mrf_flops / (mrf_ms * 1e-3) / 1e12 if mrf_ms > 0 else 0.0
-    mrf_gbs = mby * padded_frames / (mrf_ms * 1e-3) / 1e9 if mrf_ms > 0 else 0.0
+    mrf_gbs = mby * decoded_frames / (mrf_ms * 1e-3) / 1e9 if mrf_ms > 0 else 0.0
     nl_ = max(1, mrf_launches)
     default_shape = not (args.model or args.batch or args.phonemes or args.buckets or args.speakers)
 
@@ -639,7 +648,7 @@ def main():
             "traffic_unit": "HBM bytes per MRF launch (2*FETCH_SIZE+WRITE_SIZE)*1024, PMC",
             "traffic_source": traffic_src,
             "launches": int(mrf_launches), "avg_launch_ms": mrf_ms / nl_,
-            "bytes_per_launch": 0.5 * mby * padded_frames / nl_,
+            "bytes_per_launch": 0.5 * mby * decoded_frames / nl_,
             "mfma_view": {"achieved": mrf_tflops, "peak": 2500.0, "unit": "TFLOP/s",
                           "frac": mrf_tflops / 2500.0},
             "mrf_share_of_step": mrf_ms / (elapsed * 1e3),
@@ -685,13 +694,13 @@ def main():
                                f"{phonemes} phonemes{' ragged U{32..' + str(phonemes) + '}' if ragged else ''}, "
                                f"{prec}, {n_speakers} speaker(s), {sr} Hz ({pre['tag']})",
                    "global_batch": total, "phonemes": phonemes, "hop": hop,
-                   "padded_sub_batches_per_step": nb,
+                   "padded_sub_batches_per_step": nb, "decode": decode,
                    "sub_batch_plan": {"chosen_by": "equal-count (--buckets)" if args.buckets > 0 else
                                       "wetts_amd.batching.plan (DP over the length-sorted shard)",
                                       "max_pad_frac": args.max_pad_frac, "phoneme_pad_frac": pl.stats["pad_frac"],
                                       "sizes_rank0": [len(b) for b in my_buckets],
                                       "tx_rank0": [b.tx for b in my_buckets]},
-                   "frame_pad_frac_rank0": 1.0 - (stat[1].item() / stat[2].item()) if stat[2].item() else 0.0,
+                   "frame_pad_frac_rank0": 1.0 - (stat[1].item() / padded_frames) if padded_frames else 0.0,
                    "n_speakers": n_speakers, "sampling_rate": sr,
                    "length_scale": args.length_scale,
                    "frames_per_phoneme": frames / args.steps / max(1.0, valid_phonemes),

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define WETTS_ABI_VERSION 5
+#define WETTS_ABI_VERSION 6
 
 #define WETTS_OK 0
 #define WETTS_E_INVALID (-1)   /* bad argument / unsupported configuration */
@@ -224,6 +224,20 @@ int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_st
                       int64_t z_channel_stride, const float* y_mask, int64_t mask_stride,
                       const float* g, int32_t B, int32_t L, float* audio, void* workspace,
                       int64_t workspace_bytes, void* stream);
+
+/* Ragged form of wetts_hifigan.  The generator has no masks (decoders.py:63-82), so in a padded batch every
+ * utterance is decoded to the batch's longest -- and the reference's own CLI avoids that by synthesising one
+ * utterance per call (inference.py:83-110).  This entry gives a batch that call's arithmetic: utterance b is
+ * decoded over its OWN y_lengths[b] frames (int64 device array, each <= L), exactly as
+ * `dec(z[b:b+1, :, :y_lengths[b]], g[b:b+1])` would decode it alone -- zero padding at its own end, tiles behind
+ * its end are not computed -- while z / audio keep their dense [B, ., L] / [B, L*hop] layout; samples of row b
+ * behind y_lengths[b]*hop are written as 0.  float32 ResBlock1 HiFi-GAN models (wetts_hifigan_ragged_supported
+ * returns 1); same workspace as wetts_hifigan. */
+int32_t wetts_hifigan_ragged_supported(const wetts_model_t* m);
+int32_t wetts_hifigan_ragged(const wetts_model_t* m, const float* z, int64_t z_batch_stride,
+                             int64_t z_channel_stride, const int64_t* y_lengths, const float* g,
+                             int32_t B, int32_t L, float* audio, void* workspace,
+                             int64_t workspace_bytes, void* stream);
 
 /* Decoder arithmetic: 0 = float32 (default; exact-f32 MFMA, the parity-gated path),
  * 1 = bfloat16, 2 = IEEE half activations / weights with f32 accumulation (BASELINE.json

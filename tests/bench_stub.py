@@ -34,7 +34,7 @@ class StubNet:
     def set_flow_dtype(self, d):
         return self
 
-    def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0):
+    def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0, ragged=False):
         assert x.dim() == 2 and x_lengths.shape == (x.shape[0],) and sid.shape == (x.shape[0],)
         assert int(x_lengths.max()) == x.shape[1], "a bucket must be cut to its longest utterance"
         yl = torch.ceil(x_lengths.double() * 6.0 * float(length_scale)).long()  # deterministic 'durations'

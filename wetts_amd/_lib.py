@@ -22,7 +22,7 @@ class WettsError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5  # WETTS_ABI_VERSION of include/wetts_hip.h this binding was written against
+ABI_VERSION = 6  # WETTS_ABI_VERSION of include/wetts_hip.h this binding was written against
 
 
 class Config(C.Structure):
@@ -97,6 +97,8 @@ SIGNATURES = {
                                      _P, _P, _P, _P, _P, _P, _P]),
     "wetts_flow_reverse": (_I32, [_P, _P, _P, _P, _I32, _I32, _P, _P, _I64, _P]),
     "wetts_hifigan": (_I32, [_P, _P, _I64, _I64, _P, _I64, _P, _I32, _I32, _P, _P, _I64, _P]),
+    "wetts_hifigan_ragged_supported": (_I32, [_P]),
+    "wetts_hifigan_ragged": (_I32, [_P, _P, _I64, _I64, _P, _P, _I32, _I32, _P, _P, _I64, _P]),
     "wetts_set_decoder_precision": (_I32, [_P, _I32]),
     "wetts_set_flow_precision": (_I32, [_P, _I32]),
     "wetts_dynamic_quant_conv1d": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),

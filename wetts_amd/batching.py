@@ -24,9 +24,13 @@ from typing import List, Sequence
 from . import sharding
 
 # price of one infer() call in phoneme slots (a slot = one phoneme position of one utterance).  Measured on
-# MI355X with Baker v1 (profiles/r03_bucket_sweep.txt): a call costs ~1.5 ms beyond its per-slot work and a
-# slot ~0.036 ms (72.8 ms / 2048 slots)
-DEFAULT_CALL_COST = 40.0
+# MI355X with AISHELL-3 v1, 64 ragged utterances (profiles/r03_bucket_sweep.txt): going from 4 to 9 calls removed
+# 9 % of the padded work and gained nothing -- a call costs ~3.7 ms beyond its per-slot work (launch-bound stages,
+# the host sync, the decoder's tail at small batch), a slot ~0.036 ms: ~100 slots
+DEFAULT_CALL_COST = 100.0
+# share of a step that is spent in the MASKED stages (text encoder, durations, flow): with a ragged decode
+# (SynthesizerTrn.infer(ragged=True)) only they pay for padding, so a padded slot costs this fraction of a slot
+RAGGED_PAD_WEIGHT = 0.1
 
 
 @dataclass
@@ -82,27 +86,39 @@ def pad_fraction(sorted_lengths, cuts):
     return 0.0 if padded == 0 else 1.0 - valid / padded
 
 
+def weighted_pad_fraction(sorted_lengths, cuts, pad_weight):
+    """Padding share of the COST: a padded slot costs `pad_weight` of a valid one (1 = padded decode)."""
+    padded = sum((b - a) * max(1, int(sorted_lengths[a])) for a, b in cuts)
+    valid = sum(max(1, int(v)) for v in sorted_lengths)
+    pad = (padded - valid) * pad_weight
+    return 0.0 if padded == 0 else pad / (valid + pad)
+
+
 def plan(lengths: Sequence[int], world: int = 1, max_pad_frac: float = 0.08, call_cost: float = DEFAULT_CALL_COST,
-         max_batch: int = 0) -> Plan:
+         max_batch: int = 0, ragged: bool = False) -> Plan:
     """Work list of every rank for `lengths` (phoneme counts).  `max_pad_frac` bounds the padding share of
-    every rank's buckets (singleton buckets always satisfy it, so the bound is always met)."""
+    every rank's buckets (singleton buckets always satisfy it, so the bound is always met).  `ragged`: the
+    buckets will be decoded with infer(ragged=True), where only the masked stages pay for padding
+    (RAGGED_PAD_WEIGHT of a slot) -- the plan then makes few, large calls."""
     lengths = [int(v) for v in lengths]
     shards = sharding.shard_utterances(lengths, world)
+    w = RAGGED_PAD_WEIGHT if ragged else 1.0
     all_buckets, fracs, used_cost = [], [], call_cost
     for idxs in shards:
         ls = [lengths[i] for i in idxs]
         cost = call_cost
-        cuts = bucketize(ls, cost, max_batch)
-        while pad_fraction(ls, cuts) > max_pad_frac and cost > 1e-3:
+        cuts = bucketize(ls, cost / w, max_batch)
+        while weighted_pad_fraction(ls, cuts, w) > max_pad_frac and cost > 1e-3:
             cost *= 0.5
-            cuts = bucketize(ls, cost, max_batch)
-        if pad_fraction(ls, cuts) > max_pad_frac:
+            cuts = bucketize(ls, cost / w, max_batch)
+        if weighted_pad_fraction(ls, cuts, w) > max_pad_frac:
             cuts = bucketize(ls, 0.0, max_batch)
         used_cost = min(used_cost, cost)
         fracs.append(pad_fraction(ls, cuts))
         all_buckets.append([Bucket([idxs[k] for k in range(a, b)], max(1, ls[a])) for a, b in cuts])
     loads = [sum(len(b) * b.tx for b in bs) for bs in all_buckets]
-    stats = {"world": world, "utterances": len(lengths), "buckets_per_rank": [len(b) for b in all_buckets],
+    stats = {"world": world, "utterances": len(lengths), "ragged": bool(ragged),
+             "buckets_per_rank": [len(b) for b in all_buckets],
              "pad_frac_per_rank": fracs, "pad_frac": max(fracs) if fracs else 0.0,
              "padded_slots_per_rank": loads,
              "imbalance": (max(loads) / (sum(loads) / len(loads)) - 1.0) if loads and sum(loads) else 0.0}
@@ -123,16 +139,24 @@ def unshard(plan_: Plan, per_rank_results):
 
 
 def synthesize(net, seqs, sids=None, noise_scale=0.667, length_scale=1.0, noise_scale_w=0.8,
-               max_pad_frac=0.08, max_batch=0, call_cost=DEFAULT_CALL_COST, buckets=None, return_stats=False):
+               max_pad_frac=0.08, max_batch=0, call_cost=DEFAULT_CALL_COST, buckets=None, return_stats=False,
+               ragged="auto"):
     """Synthesises a list of phoneme-id sequences on `net`'s device: plans buckets (or takes `buckets`, a list of
     `Bucket`), runs one `net.infer()` per bucket and returns the VALID audio of every utterance (1-D float32
-    device tensors, `y_lengths * hop` samples each) in input order.  Every utterance's audio is what the
-    reference's infer() returns for it inside the padded batch of its bucket."""
+    device tensors, `y_lengths * hop` samples each) in input order.
+
+    ragged = True / "auto" (when the model supports it: float32 ResBlock1 HiFi-GAN): every utterance is decoded
+    over its own frames -- the audio the reference returns when it synthesises that utterance alone, its CLI's
+    call shape (inference.py:83-110) -- and the plan makes few large calls, because padding then only costs in the
+    masked stages.  ragged = False: every utterance's audio is what the reference's infer() returns for it inside
+    the padded batch of its bucket (runtime/gpu_triton/model_repo/tts/1/model.py:85-165)."""
     import torch
     n = len(seqs)
     lens = [len(s) for s in seqs]
+    if ragged == "auto":
+        ragged = bool(net.ragged_supported())
     if buckets is None:
-        buckets = plan(lens, 1, max_pad_frac, call_cost, max_batch).buckets[0] if n else []
+        buckets = plan(lens, 1, max_pad_frac, call_cost, max_batch, ragged=ragged).buckets[0] if n else []
     dev = net.device
     out = [None] * n
     valid_frames = padded_frames = 0
@@ -145,7 +169,7 @@ def synthesize(net, seqs, sids=None, noise_scale=0.667, length_scale=1.0, noise_
         sid = None if sids is None else torch.tensor([int(sids[i]) for i in b.indices], dtype=torch.long)
         o, _, y_mask, _ = net.infer(x.to(dev), xl.to(dev), sid=None if sid is None else sid.to(dev),
                                     noise_scale=noise_scale, length_scale=length_scale,
-                                    noise_scale_w=noise_scale_w)
+                                    noise_scale_w=noise_scale_w, ragged=ragged)
         yl = net._last["y_lengths_host"]
         hop = net.hop_length
         for r, i in enumerate(b.indices):
@@ -153,6 +177,7 @@ def synthesize(net, seqs, sids=None, noise_scale=0.667, length_scale=1.0, noise_
         valid_frames += int(yl.sum())
         padded_frames += B * int(y_mask.shape[-1])
     if return_stats:
-        return out, {"calls": len(buckets), "valid_frames": valid_frames, "padded_frames": padded_frames,
+        return out, {"calls": len(buckets), "ragged": bool(ragged), "valid_frames": valid_frames,
+                     "padded_frames": padded_frames,
                      "frame_pad_frac": 0.0 if not padded_frames else 1.0 - valid_frames / padded_frames}
     return out

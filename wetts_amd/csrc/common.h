@@ -95,6 +95,11 @@ struct ConvParams {
   float out_div;         // final true division (MRF mean: xs / num_kernels), 1 = none
   int B;
   int tag;               // 1: MRF ResBlock launch (separate kernel symbol for profiles)
+  // ragged batch (wetts_hifigan_ragged): utterance b's input holds lens[b] * len_mul time steps -- it is
+  // convolved as if it were alone (zero padding at ITS end) -- while Tin / Tout / N stay the dense row
+  // geometry of the tensors; blocks whose tile starts behind an utterance's end exit at once.  null = dense.
+  const int64_t* lens;
+  int len_mul;
 };
 
 // default-initialised ConvParams for a plain contiguous [B,C,T] -> [B,Cout,T] conv

@@ -166,6 +166,14 @@ void conv_mfma_kernel(const ConvParams p) {
   const int b = bid / mtiles;
 
   const int n0 = ntile * NT;
+  // this utterance's own extent (ragged batches), else the dense geometry
+  int Tin = p.Tin, Tout = p.Tout, N = p.N;
+  if (p.lens) {
+    Tin = min((int)p.lens[b] * p.len_mul, p.Tin);
+    Tout = p.up > 0 ? Tin * p.up : Tin;
+    N = p.up > 0 ? Tin + p.ktaps - 1 : Tout;
+    if (n0 >= N) return;  // uniform per block
+  }
   const int W = FAST ? ((NT + p.span + 3 + 3) & ~3) : NT + p.span;  // LDS row stride
   float* buf0 = smem;
   float* buf1 = smem + CK * W;
@@ -184,7 +192,7 @@ void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
   for (int q = 0; q < Q4; ++q) {
     const int piece = lane + 64 * q, tp = tstart + 4 * piece;
-    okq[q] = piece < W4 && tp >= 0 && tp + 4 <= p.Tin;  // rows hold a multiple of 4 samples
+    okq[q] = piece < W4 && tp >= 0 && tp + 4 <= Tin;  // rows hold a multiple of 4 samples
   }
   const bool wrq_last = lane + 64 * (Q4 - 1) < W4;  // LDS: only the last piece column can be partial
   __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
@@ -230,7 +238,7 @@ void conv_mfma_kernel(const ConvParams p) {
     for (int i = 0; i < MAXCI; ++i) {
       int col = lane + 64 * i;
       int t = n0 + p.off_lo + col;
-      bool ok = (col < W) && (t >= 0) && (t < p.Tin);
+      bool ok = (col < W) && (t >= 0) && (t < Tin);
       tcol[i] = ok ? t : -1;
       mcol[i] = (ok && mrow) ? mrow[t] : 1.f;
     }
@@ -289,7 +297,7 @@ void conv_mfma_kernel(const ConvParams p) {
   // then every address is  uniform 64-bit base + 32-bit (row*stride + lane) offset  and there are
   // no per-element bounds checks -- the prologue/epilogue shrink from ~25 to ~4 instructions per
   // element, which matters most for the C=32/64 stages whose MFMA loop is only a few k-steps.
-  const bool full_tile = (p.up == 0) && (n0 + NT <= p.N) && (mtile * MT + MT <= p.M);
+  const bool full_tile = (p.up == 0) && (n0 + NT <= N) && (mtile * MT + MT <= p.M);
   const int wrow0 = mtile * MT + wm * MB * 32;  // first row of this wave (uniform)
   const int wcol0 = n0 + wn * (32 * NB);        // first column of this wave (uniform)
   if (pre_res && full_tile) {
@@ -329,7 +337,7 @@ void conv_mfma_kernel(const ConvParams p) {
         for (int r = 0; r < 16; ++r) {
           const int row = mrow0 + (r & 3) + 8 * (r >> 2);
           float v = 0.f;
-          if (col < p.N && row < p.M) {
+          if (col < N && row < p.M) {
             if (p.res) v = p.res[rb0 + (int64_t)row * p.r_cs + col];
             if (p.accum) v += p.out[ob0 + (int64_t)row * p.o_cs + col];
           }
@@ -481,7 +489,7 @@ void conv_mfma_kernel(const ConvParams p) {
         for (int j = 0; j < NB; ++j) {
           const int col = wcol0 + 32 * j + (lane & 31);
           const int t = (col << sh) + ph - p.up_pad;
-          if (row < p.M && col < p.N && t >= 0 && t < p.Tout)
+          if (row < p.M && col < N && t >= 0 && t < Tout)
             *reinterpret_cast<float*>(obase + (rowoff + (unsigned)t * 4u)) = acc[i][j][r] + bia[i][r];
         }
       }
@@ -494,7 +502,7 @@ void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int col = n0 + wn * (32 * NB) + j * 32 + (lane & 31);
-      if (col >= p.N) continue;
+      if (col >= N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mrow0 + (r & 3) + 8 * (r >> 2);
@@ -503,7 +511,7 @@ void conv_mfma_kernel(const ConvParams p) {
         if (p.up > 0) {
           co = row / p.up;
           t = col * p.up + (row - co * p.up) - p.up_pad;
-          if (t < 0 || t >= p.Tout) continue;
+          if (t < 0 || t >= Tout) continue;
         }
         float v = acc[i][j][r];
         if (p.bias) v += p.bias[co];
@@ -546,7 +554,8 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
   const bool fast = p.in_mask == nullptr && p.in_rev_base < 0 && (p.Cin % kConvCK) == 0 &&
                     (p.x_cs & 3) == 0 && (p.x_bs & 3) == 0 && (p.Tin & 3) == 0 && p.span <= 125 &&
                     (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 &&
-                    ((int64_t)p.Cin * p.x_cs) < (1ll << 29);
+                    ((int64_t)p.Cin * p.x_cs) < (1ll << 29) &&
+                    (p.lens == nullptr || (p.len_mul & 3) == 0);  // ragged: every utterance a multiple of 4 samples
   const size_t lds = (size_t)2 * kConvCK * (fast ? ((NT + p.span + 3 + 3) & ~3) : NT + p.span) * sizeof(float);
   const dim3 grid((unsigned)blocks), blk(256);
   // epilogue specialisation: residual / running sum are folded into the accumulator init
@@ -613,7 +622,7 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
     p.N = p.Tout;
   }
   // launches of at most ~one small tile per CU are latency-, not throughput-bound: own schedule
-  if (conv_variant() == 0) {
+  if (conv_variant() == 0 && p.lens == nullptr) {
     bool taken = false;
     WETTS_TRY(launch_conv_small(p, stream, &taken));
     if (taken) return WETTS_OK;

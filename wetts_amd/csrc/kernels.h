@@ -64,8 +64,9 @@ int32_t k_coupling_flip(const float* xin, const float* m, const float* mask, int
                         float* out, hipStream_t s);
 
 // conv_post: lrelu(0.01) -> Conv1d(C,1,7,pad 3, no bias) -> tanh  (decoders.py:78-80)
+// lens != null: ragged batch -- utterance b holds lens[b] * len_mul samples, the rest of its output row is 0
 int32_t k_conv_post_tanh(const float* x, const float* w, int k, int B, int C, int T, float* out,
-                         hipStream_t s);
+                         hipStream_t s, const int64_t* lens = nullptr, int len_mul = 0);
 
 // a10 (models.py:254-256)
 int32_t k_durations_to_lengths(const float* logw, const float* mask, float length_scale, int B,

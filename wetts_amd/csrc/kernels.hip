@@ -558,7 +558,8 @@ int32_t k_coupling_flip(const float* xin, const float* m, const float* mask, int
 __global__ __launch_bounds__(256) void conv_post_tanh_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ w, int k,
                                                              int B, int C, int T,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out,
+                                                             const int64_t* __restrict__ lens, int len_mul) {
   extern __shared__ float wsh[];
   for (int i = threadIdx.x; i < C * k; i += blockDim.x) wsh[i] = w[i];
   __syncthreads();
@@ -570,12 +571,20 @@ __global__ __launch_bounds__(256) void conv_post_tanh_kernel(const float* __rest
   const int pad = (k - 1) / 2;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const float* xb = x + (int64_t)b * C * T;
+  // ragged batch: utterance b ends at Tb (it is convolved as if alone); the rest of its row reads as 0
+  const int Tb = lens ? min((int)lens[b] * len_mul, T) : T;
+  if (t0 >= Tb) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      if (t0 + o < T) out[(int64_t)b * T + t0 + o] = 0.f;
+    return;
+  }
   for (int c = 0; c < C; ++c) {
     const float* xr = xb + (int64_t)c * T;
     float win[4 + 15];
     for (int i = 0; i < 3 + k; ++i) {
       int tt = t0 - pad + i;
-      float v = (tt >= 0 && tt < T) ? xr[tt] : 0.f;
+      float v = (tt >= 0 && tt < Tb) ? xr[tt] : 0.f;
       win[i] = v > 0.f ? v : v * 0.01f;  // F.leaky_relu default slope, decoders.py:78
     }
     for (int j = 0; j < k; ++j) {
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(256) void conv_post_tanh_kernel(const float* __rest
   }
 #pragma unroll
   for (int o = 0; o < 4; ++o)
-    if (t0 + o < T) out[(int64_t)b * T + t0 + o] = tanhf(acc[o]);
+    if (t0 + o < T) out[(int64_t)b * T + t0 + o] = (t0 + o < Tb) ? tanhf(acc[o]) : 0.f;
 }
 
 // conv_post for launches too small to fill the chip (a streaming window is 15 k samples = 15 blocks of
@@ -637,18 +646,18 @@ __global__ __launch_bounds__(256) void conv_post_tanh_small_kernel(const float* 
 }
 
 int32_t k_conv_post_tanh(const float* x, const float* w, int k, int B, int C, int T, float* out,
-                         hipStream_t s) {
+                         hipStream_t s, const int64_t* lens, int len_mul) {
   WETTS_REQUIRE(k <= 15, "conv_post kernel size %d unsupported", k);
   int64_t n = (int64_t)B * ((T + 3) / 4);
   if (n == 0) return WETTS_OK;
-  if (k == 7 && C <= 64 && n <= 64 * 256) {  // fewer than 64 blocks of the kernel above
+  if (k == 7 && C <= 64 && n <= 64 * 256 && !lens) {  // fewer than 64 blocks of the kernel above
     hipLaunchKernelGGL(conv_post_tanh_small_kernel<7>, dim3((unsigned)(B * cdiv(T, 32))), dim3(256), 0, s, x, w,
                        B, C, T, out);
     WETTS_LAUNCH_CHECK();
     return WETTS_OK;
   }
   hipLaunchKernelGGL(conv_post_tanh_kernel, grid1d(n, 256), dim3(256), (size_t)C * k * 4, s, x, w,
-                     k, B, C, T, out);
+                     k, B, C, T, out, lens, len_mul);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

@@ -94,13 +94,21 @@ __global__ __launch_bounds__(1024) void mas_kernel(const float* __restrict__ neg
 //             there is no memset pass and no scattered store.
 // Bit-exact with the reference for t_x <= t_y (the only case MAS is defined for); utterances with
 // t_x > t_y (the reference then reads wrapped / unwritten rows) are left to mas_kernel above.
-template <int C, int D>
+// one v_max_f32: fmaxf() costs two extra canonicalising v_max per operand in the row recurrence (the values are
+// never signalling NaNs; for ordinary NaNs v_max_f32 returns the other operand exactly like fmaxf)
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <int C>
 __global__ __launch_bounds__(256) void mas_wave_kernel(const float* __restrict__ neg_cent,
                                                        const int32_t* __restrict__ t_ys,
                                                        const int32_t* __restrict__ t_xs, int Ty, int Tx,
                                                        int32_t* __restrict__ path) {
   extern __shared__ uint32_t mas_lds[];
-  constexpr int R = 32 / C;  // rows per bit word
+  constexpr int R = 32 / C;  // rows per bit word = rows per block of the forward loop = depth of the row ring
   const int G = (Ty + R - 1) / R;
   uint32_t* bits = mas_lds;                                         // [G][64]
   unsigned short* idx = (unsigned short*)(mas_lds + (size_t)G * 64);  // [Ty] path column per row
@@ -117,62 +125,66 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float* __restrict__
 
   if (wave == 0 && valid) {
     const int x0 = lane * C;
-    int64_t off[C];  // clamped column offsets (columns >= Tx read column Tx-1: loaded, never used)
+    int offc[C];  // clamped column offsets (columns >= Tx read column Tx-1: loaded, never used)
 #pragma unroll
-    for (int c = 0; c < C; ++c) off[c] = min(x0 + c, Tx - 1);
-    float ring[D][C];
+    for (int c = 0; c < C; ++c) offc[c] = min(x0 + c, Tx - 1);
+    // the row ring: R rows x C columns = 32 loads in flight per lane.  Every load below is issued
+    // UNCONDITIONALLY (row index clamped) and every block of R rows is straight-line code: a load under a
+    // branch makes the compiler wait with vmcnt(0) at the first use -- a memory round trip per row (what the
+    // first version of this kernel did: 680 cycles per row).  Row base pointers are wave-uniform (scalar
+    // registers), the per-lane part of an address is one 32-bit offset.
+    float ring[R][C];
+    const int last = t_y - 1;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int yy = min(d, t_y - 1);
+    for (int d = 0; d < R; ++d) {
+      const float* rowp = nc + (int64_t)min(d, last) * Tx;
 #pragma unroll
-      for (int c = 0; c < C; ++c) ring[d][c] = nc[(int64_t)yy * Tx + off[c]];
+      for (int c = 0; c < C; ++c) ring[d][c] = rowp[offc[c]];
     }
     float prev[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) prev[c] = 0.f;
-    uint32_t word = 0;
-    for (int yb = 0; yb < t_y; yb += D) {
+    // column 0 never steps left (the backtrack tests index != 0 first): its bit is masked out once per row
+    const uint32_t lanemask = (lane == 0) ? ~1u : ~0u;
+    for (int yb = 0; yb < t_y; yb += R) {  // rows >= t_y of the last block have an empty band: they change nothing
+      uint32_t word = 0;
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
+      for (int d = 0; d < R; ++d) {
         const int y = yb + d;
-        if (y < t_y) {  // uniform
-          float raw[C];
+        float raw[C];
 #pragma unroll
-          for (int c = 0; c < C; ++c) raw[c] = ring[d][c];
-          {  // refill this ring slot with row y + D
-            const int yy = min(y + D, t_y - 1);
+        for (int c = 0; c < C; ++c) raw[c] = ring[d][c];
+        {  // refill this ring slot with row y + R
+          const float* rowp = nc + (int64_t)min(y + R, last) * Tx;
 #pragma unroll
-            for (int c = 0; c < C; ++c) ring[d][c] = nc[(int64_t)yy * Tx + off[c]];
-          }
-          const int x_lo = max(0, t_x + y - t_y);
-          const int x_hi = min(t_x, y + 1);
-          // left neighbour's last column of the previous row
-          const float left = __int_as_float(__builtin_amdgcn_update_dpp(
-              0, __float_as_int(prev[C - 1]), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-          float cur[C];
-          uint32_t rowbits = 0;
-#pragma unroll
-          for (int c = 0; c < C; ++c) {
-            const int x = x0 + c;
-            const float pl = (c == 0) ? left : prev[c - 1];  // value[y-1][x-1]
-            const float pc = prev[c];                        // value[y-1][x]
-            const float v_cur = (x == y) ? max_neg_val : pc;
-            const float v_prev = (x == 0) ? ((y == 0) ? 0.f : max_neg_val) : pl;
-            const bool in_band = x >= x_lo && x < x_hi;
-            cur[c] = in_band ? raw[c] + fmaxf(v_prev, v_cur) : raw[c];
-            const bool step = (x == y) || (pc < pl);
-            rowbits |= (step && x > 0) ? (1u << c) : 0u;
-          }
-#pragma unroll
-          for (int c = 0; c < C; ++c) prev[c] = cur[c];
-          const int r = y % R;
-          word |= rowbits << (r * C);
-          if (r == R - 1 || y == t_y - 1) {
-            bits[(size_t)(y / R) * 64 + lane] = word;
-            word = 0;
-          }
+          for (int c = 0; c < C; ++c) ring[d][c] = rowp[offc[c]];
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the refill where it is: R rows ahead of its use
+        const int x_lo = max(0, t_x + y - t_y);
+        const unsigned band = (unsigned)(min(t_x, y + 1) - x_lo);  // x in band <=> (unsigned)(x - x_lo) < band
+        // value[y-1][x-1] of the lane's first column: the left neighbour's last column of the previous row, one
+        // DPP move; lane 0 has no neighbour and keeps `old` = the reference's boundary value for x == 0
+        const float edge = (y == 0) ? 0.f : max_neg_val;
+        const float left = __int_as_float(__builtin_amdgcn_update_dpp(
+            __float_as_int(edge), __float_as_int(prev[C - 1]), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+        float cur[C];
+        uint32_t rowbits = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const int x = x0 + c;
+          const float pl = (c == 0) ? left : prev[c - 1];  // value[y-1][x-1]  (v_prev)
+          const float pc = prev[c];                        // value[y-1][x]
+          const bool diag = (x == y);
+          const float v_cur = diag ? max_neg_val : pc;
+          const bool in_band = (unsigned)(x - x_lo) < band;
+          cur[c] = in_band ? raw[c] + vmax(pl, v_cur) : raw[c];
+          rowbits |= (diag || (pc < pl)) ? (1u << c) : 0u;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) prev[c] = cur[c];
+        word |= (rowbits & lanemask) << (d * C);
       }
+      bits[(size_t)(yb / R) * 64 + lane] = word;
     }
     // the wave's own LDS writes are ordered before its reads by the compiler's waitcnt; no other wave reads
     int index = t_x - 1;
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float* __restrict__
   }
   __syncthreads();
 
-  // path rows, zeros included: every wave writes whole rows (coalesced); lane l covers columns l*C..
+  // path rows, zeros included: every wave writes whole rows (coalesced)
   for (int y = wave; y < Ty; y += (int)(blockDim.x >> 6)) {
     const int col = idx[y];  // 0xFFFF: no path cell in this row
     for (int xb = 0; xb < Tx; xb += 64 * C) {
@@ -205,10 +217,10 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float* __restrict__
   }
 }
 
-template <int C, int D>
+template <int C>
 static void launch_mas_wave(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, int B, int Ty,
                             int Tx, int32_t* path, size_t lds, hipStream_t s) {
-  hipLaunchKernelGGL((mas_wave_kernel<C, D>), dim3(B), dim3(256), lds, s, neg_cent, t_ys, t_xs, Ty, Tx, path);
+  hipLaunchKernelGGL((mas_wave_kernel<C>), dim3(B), dim3(256), lds, s, neg_cent, t_ys, t_xs, Ty, Tx, path);
 }
 
 // utterances with t_x > t_y: the reference's arithmetic there (wrapped row reads) is reproduced by the
@@ -228,19 +240,19 @@ int32_t k_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, i
   if (fast) {
     static bool attr_done = false;
     if (!attr_done) {  // > 64 KB of dynamic LDS needs the opt-in
-      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_done = true;
     }
     switch (C) {
-      case 1: launch_mas_wave<1, 8>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
-      case 2: launch_mas_wave<2, 8>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
-      case 4: launch_mas_wave<4, 8>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
-      case 8: launch_mas_wave<8, 4>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
-      default: launch_mas_wave<16, 2>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
+      case 1: launch_mas_wave<1>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
+      case 2: launch_mas_wave<2>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
+      case 4: launch_mas_wave<4>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
+      case 8: launch_mas_wave<8>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
+      default: launch_mas_wave<16>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
     }
     WETTS_LAUNCH_CHECK();
   } else {

@@ -1566,10 +1566,12 @@ static int pair_nto(int C, int ktaps) {
   return nto > 0 ? nto : 1;
 }
 
+// lens != null: ragged batch (wetts_hifigan_ragged) -- utterance b is decoded over its own lens[b] frames, as if
+// it were alone in the call; ResBlock1 models at f32 only (the caller checks)
 static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, int64_t z_cs,
                            const float* y_mask, int64_t mask_stride, const float* g, int B, int L,
                            float* audio, void* workspace, int64_t workspace_bytes, hipStream_t s,
-                           DecTiming* tm) {
+                           DecTiming* tm, const int64_t* lens = nullptr) {
   const wetts_config_t* c = &m->cfg;
   const int I = c->inter_channels, C0 = c->upsample_initial_channel;
   const int64_t mx = dec_max_elems(c, B, L);
@@ -1600,9 +1602,12 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
       p.bias_b = cond;
       p.bias_b_stride = C0;
     }
+    p.lens = lens;
+    p.len_mul = 1;
     WETTS_TRY(launch_conv(m->conv_pre, p, s));
   }
   int ch = C0, len = L;
+  int spf = 1;  // samples per input frame at the current stage (ragged batches: lens[b] * spf samples)
   float* x = bx;   // stage input / MRF output
   float* xs = bs;  // MRF accumulator
   const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
@@ -1616,10 +1621,13 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
       p.Tout = len * u;  // (len-1)*u - 2*pad + k with pad=(k-u)/2
       p.o_bs = (int64_t)(ch / 2) * len * u;
       p.o_cs = (int64_t)len * u;
+      p.lens = lens;
+      p.len_mul = spf;
       WETTS_TRY(launch_conv(m->ups[i], p, s));
     }
     ch /= 2;
     len *= u;
+    spf *= u;
     float* xu = bt;                     // upsampled x, input of every resblock of this stage
     float* xsum = (x == bx) ? bs : bx;  // MRF accumulator for this stage
     (void)xs;
@@ -1660,6 +1668,8 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           cp.accum = (j > 0) ? 1 : 0;
           cp.out_div = (j == nk - 1) ? (float)nk : 1.f;  // x = xs / self.num_kernels
           cp.slope = 0.1f;
+          cp.lens = lens;
+          cp.len_mul = spf;
           WETTS_TRY(launch_resblock_chain32(rb.c1.data(), rb.c2.data(), nd, cp, sj));
           if (tm && tm->on) tm->launches += 1;
           if (m->mrf_timing) m->mrf_launches += 1;
@@ -1723,13 +1733,15 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           cp.accum = accum;
           cp.out_div = odiv;
           cp.slope = 0.1f;
+          cp.lens = lens;
+          cp.len_mul = spf;
           WETTS_TRY(launch_resblock_chain32(&rb.c1[d], &rb.c2[d], 1, cp, sj));
           if (tm && tm->on) tm->launches += 1;
           if (m->mrf_timing) m->mrf_launches += 1;
           rx = outp;
           continue;
         }
-        const bool fuse32 = c->resblock == 1 && !m->dec_unfused &&
+        const bool fuse32 = c->resblock == 1 && !m->dec_unfused && !lens &&
                             resblock_pair32_supported(rb.c1[d], rb.c2[d], m->fuse32_lds) &&
                             !(ch >= 128 && rb.c1[d].ktaps >= m->fuse32_kmax128) &&
                             (ch <= m->fuse32_maxc || rb.c1[d].ktaps <= m->fuse32_kwide) &&
@@ -1756,6 +1768,8 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           p1.in_act = IN_LRELU;
           p1.in_slope = 0.1f;
           p1.tag = 1;
+          p1.lens = lens;
+          p1.len_mul = spf;
           WETTS_TRY(launch_conv(rb.c1[d], p1, sj));
           // the running sum is ordered chain j-1 -> chain j
           if (forked && last_d && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
@@ -1768,6 +1782,8 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           p2.accum = accum;
           p2.out_div = odiv;
           p2.tag = 1;
+          p2.lens = lens;
+          p2.len_mul = spf;
           WETTS_TRY(launch_conv(rb.c2[d], p2, sj));
           if (tm && tm->on) tm->launches += 2;
           if (m->mrf_timing) m->mrf_launches += 2;
@@ -1807,7 +1823,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
     x = xsum;
   }
   // x = tanh(conv_post(leaky_relu(x)))   (default slope 0.01, decoders.py:78)
-  WETTS_TRY(k_conv_post_tanh(x, m->conv_post_w, 7, B, ch, len, audio, s));
+  WETTS_TRY(k_conv_post_tanh(x, m->conv_post_w, 7, B, ch, len, audio, s, lens, spf));
   if (m->mrf_timing) m->mrf_calls += 1;
   return WETTS_OK;
 }
@@ -2269,6 +2285,28 @@ int32_t wetts_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_st
                             audio, workspace, workspace_bytes, (hipStream_t)stream);
   return run_hifigan(m, z, z_batch_stride, z_channel_stride, y_mask, mask_stride, g, B, L, audio,
                      workspace, workspace_bytes, (hipStream_t)stream, nullptr);
+}
+
+int32_t wetts_hifigan_ragged_supported(const wetts_model_t* m) {
+  if (!m) return 0;
+  const wetts_config_t* c = &m->cfg;
+  if (c->vocoder_type != 0 || c->resblock != 1 || m->dec_precision != 0) return 0;
+  for (int i = 0; i < c->n_upsamples; ++i)
+    if (c->upsample_rates[i] <= 0) return 0;
+  return 1;
+}
+
+int32_t wetts_hifigan_ragged(const wetts_model_t* m, const float* z, int64_t z_batch_stride,
+                             int64_t z_channel_stride, const int64_t* y_lengths, const float* g,
+                             int32_t B, int32_t L, float* audio, void* workspace, int64_t workspace_bytes,
+                             void* stream) {
+  WETTS_REQUIRE(m && z && audio && y_lengths, "null argument");
+  WETTS_REQUIRE(wetts_hifigan_ragged_supported(m),
+                "ragged decode covers the float32 HiFi-GAN generator with ResBlock1 (set_decoder_precision 0)");
+  SmallConvScope small_scope(0);  // the small-launch schedule has no per-utterance extents
+  if (B == 0 || L == 0) return WETTS_OK;
+  return run_hifigan(m, z, z_batch_stride, z_channel_stride, nullptr, 0, g, B, L, audio, workspace,
+                     workspace_bytes, (hipStream_t)stream, nullptr, y_lengths);
 }
 
 int32_t wetts_profile_hifigan(const wetts_model_t* m, const float* z, int64_t z_batch_stride,

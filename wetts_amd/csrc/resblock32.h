@@ -49,6 +49,9 @@ struct ResChain32Params {
   float out_div;
   float slope;
   int S, Mmin, NTO, ntiles, nblocks, Wp;  // filled by the launcher
+  // ragged batch: utterance b holds lens[b] * len_mul samples (a multiple of 4); T stays the row stride (common.h)
+  const int64_t* lens;
+  int len_mul;
 };
 
 // c1 / c2: npairs descriptors each.  max_waste_pct bounds the share of tile columns the chain's halo

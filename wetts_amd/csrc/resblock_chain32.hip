@@ -85,8 +85,11 @@ void resblock_chain32_kernel(const ResChain32Params p) {
   const int M = p.Mmin + ((t0 - p.Mmin) & 3);      // left margin: (t0 - M) % 4 == 0
   const int tx0 = t0 - M;                          // time of LDS column 0
   const int Wp = p.Wp;
-  const int T = p.T;
-  const bool interior = tx0 >= 0 && tx0 + Wp <= T;
+  const int T = p.T;  // row stride of the [C][T] planes
+  // Tb: where THIS utterance ends (ragged batches: it is convolved as if alone, zero padding at its own end)
+  const int Tb = p.lens ? __builtin_amdgcn_readfirstlane(min((int)p.lens[b] * p.len_mul, T)) : T;
+  if (n0 >= Tb) return;
+  const bool interior = tx0 >= 0 && tx0 + Wp <= Tb;
 
   // (b, t0, ... derive from blockIdx through an integer division, which lives in vector registers: the
   // readfirstlane round trips tell the compiler what it cannot prove -- these are uniform -- so that
@@ -116,7 +119,7 @@ void resblock_chain32_kernel(const ResChain32Params p) {
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int t = t0 + wcol + 32 * j;
-    mcol[j] = (t >= 0 && t < T) ? 1.f : 0.f;
+    mcol[j] = (t >= 0 && t < Tb) ? 1.f : 0.f;
   }
   // ---- 1. stage lrelu(x): wave w takes rows w, w+4, ...; a lane takes aligned 16-byte pieces ----
   {
@@ -149,10 +152,10 @@ void resblock_chain32_kernel(const ResChain32Params p) {
             const int t = tx0 + 4 * seg;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (seg < ppr) {  // sequence edge: element-wise, zero outside [0, T)
-              if (t >= 0 && t < T) v.x = xrow[t];
-              if (t + 1 >= 0 && t + 1 < T) v.y = xrow[t + 1];
-              if (t + 2 >= 0 && t + 2 < T) v.z = xrow[t + 2];
-              if (t + 3 >= 0 && t + 3 < T) v.w = xrow[t + 3];
+              if (t >= 0 && t < Tb) v.x = xrow[t];
+              if (t + 1 >= 0 && t + 1 < Tb) v.y = xrow[t + 1];
+              if (t + 2 >= 0 && t + 2 < Tb) v.z = xrow[t + 2];
+              if (t + 3 >= 0 && t + 3 < Tb) v.w = xrow[t + 3];
             }
             st[r][q] = v;
           }
@@ -288,7 +291,7 @@ void resblock_chain32_kernel(const ResChain32Params p) {
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int col = wcol + 32 * (jj + u);
-            const bool ok = col >= p.S && col < NTC - p.S && t0 + col < T;
+            const bool ok = col >= p.S && col < NTC - p.S && t0 + col < Tb;
             pv[u][r] = 0.f;
             if (ok) pv[u][r] = buf_load_f32(rso0, lane_off + 128 * (jj + u), soff);
           }
@@ -336,7 +339,7 @@ void resblock_chain32_kernel(const ResChain32Params p) {
   for (int j = 0; j < NB; ++j) {
     const int col = wcol + 32 * j;
     const int t = t0 + col;
-    const bool ok = col >= p.S && col < NTC - p.S && t < T;  // t >= n0 >= 0 inside the window
+    const bool ok = col >= p.S && col < NTC - p.S && t < Tb;  // t >= n0 >= 0 inside the window
     if (!ok) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

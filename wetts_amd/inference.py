@@ -76,18 +76,22 @@ def main(argv=None):
     sr = hps.data.sampling_rate
     seqs = [[phone_dict[s] for s in text.split()] for (_, _, text) in lines]  # KeyError like the reference
     sids = [speaker_dict[spk] for (_, spk, _) in lines]
+    ragged = False
     if args.batch <= 1:
         # the reference's loop: one utterance per infer() call (inference.py:83-110)
         buckets = [batching.Bucket([i], max(1, len(s))) for i, s in enumerate(seqs)]
     else:
         # --batch N: the whole file is planned at once -- length-sorted padded sub-batches of at most N
         # utterances with a bounded padding share (wetts_amd/batching.py), written back in file order
+        # ragged decode where the model supports it: every utterance's audio is then what the one-at-a-time loop
+        # of the reference CLI produces for it, whatever it is batched with
+        ragged = net_g.ragged_supported()
         buckets = batching.plan([len(s) for s in seqs], 1, max_pad_frac=args.max_pad_frac,
-                                max_batch=args.batch).buckets[0]
+                                max_batch=args.batch, ragged=ragged).buckets[0]
     for bk in buckets:
         st = time.time()
         audio = batching.synthesize(net_g, seqs, sids, noise_scale=0.667, noise_scale_w=0.8, length_scale=1,
-                                    buckets=[bk])
+                                    buckets=[bk], ragged=ragged)
         n_total = 0
         pcms = []
         for i in bk.indices:

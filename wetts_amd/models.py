@@ -344,14 +344,25 @@ class SynthesizerTrn:
                     y_lengths=y_lengths, y_lengths_host=y_host, frame2phone=f2p, y_mask=y_mask,
                     attn=attn, m_p=m_p, logs_p=logs_p, z_p=z_p, z=z, B=B, Tx=Tx, Ty=Ty)
 
-    def _decode(self, z, g, y_mask, L):
-        """dec((z * y_mask)[:, :, :L], g) without materialising the masked / sliced copy."""
+    def ragged_supported(self):
+        """True when the decoder can run a batch ragged (`infer(..., ragged=True)`): float32 ResBlock1 HiFi-GAN."""
+        lib = self._require()
+        return bool(lib.wetts_hifigan_ragged_supported(self._handle))
+
+    def _decode(self, z, g, y_mask, L, y_lengths=None):
+        """dec((z * y_mask)[:, :, :L], g) without materialising the masked / sliced copy.  With `y_lengths`
+        (int64 device tensor [B]) the batch is decoded ragged: every utterance over its own frames, as if alone."""
         lib = self._require()
         B = z.shape[0]
         if B == 0 or L == 0:  # (z * y_mask)[:, :, :0] -> empty audio, nothing to launch
             return torch.empty(B, 1, 0, dtype=torch.float32, device=self.device)
         ws, nws = self._workspace(B, 0, L)
         audio = torch.empty(B, 1, L * self.hop_length, dtype=torch.float32, device=self.device)
+        if y_lengths is not None:
+            _lib.check(lib.wetts_hifigan_ragged(self._handle, _lib.ptr(z), z.stride(0), z.stride(1),
+                                                _lib.ptr(y_lengths), _lib.ptr(g), B, L, _lib.ptr(audio),
+                                                _lib.ptr(ws), nws, _lib.current_stream_ptr()), "hifigan_ragged")
+            return audio
         _lib.check(lib.wetts_hifigan(self._handle, _lib.ptr(z), z.stride(0), z.stride(1),
                                      _lib.ptr(y_mask),
                                      y_mask.stride(0) if y_mask is not None else 0,
@@ -361,14 +372,19 @@ class SynthesizerTrn:
 
     # ---- the reference's public inference API ----------------------------------------------------
     def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0,
-              max_len=None, eps_w=None, eps_z=None):
+              max_len=None, eps_w=None, eps_z=None, ragged=False):
         """models.py:228-280.  Returns (o [B,1,Ty*hop], attn [B,1,Ty,Tx], y_mask [B,1,Ty],
-        (z, z_p, m_p, logs_p) [B,inter,Ty]); z is unmasked, as in the reference."""
+        (z, z_p, m_p, logs_p) [B,inter,Ty]); z is unmasked, as in the reference.
+
+        `ragged=True` (not in the reference): the generator has no masks, so the reference decodes every row of a
+        padded batch to the longest utterance; ragged decodes row b over its own y_lengths[b] frames -- the audio
+        the reference returns when that utterance is synthesised alone (its CLI's call shape) -- and writes zeros
+        behind it.  The masked stages (encoder, durations, flow) are batch independent either way."""
         st = self._encode(x, x_lengths, sid, float(noise_scale), float(length_scale),
                           float(noise_scale_w), eps_w, eps_z)
         Ty = st["Ty"]
         L = Ty if max_len is None else max(0, min(Ty, int(max_len)))
-        o = self._decode(st["z"], st["g"], st["y_mask"], L)
+        o = self._decode(st["z"], st["g"], st["y_mask"], L, st["y_lengths"] if ragged else None)
         self._last = st
         return (o, st["attn"].unsqueeze(1), st["y_mask"].unsqueeze(1),
                 (st["z"], st["z_p"], st["m_p"], st["logs_p"]))

@@ -50,10 +50,11 @@ class InferenceSession(_SessionBase):
     followed by zeros instead of the decoded padding tail.  `max_batch` caps a sub-batch (the Triton
     `generator` model's max_batch_size is 32, generator/config.pbtxt)."""
 
-    def __init__(self, model: SynthesizerTrn, max_pad_frac=None, max_batch=0):
+    def __init__(self, model: SynthesizerTrn, max_pad_frac=None, max_batch=0, ragged=False):
         super().__init__(model)
         self.max_pad_frac = max_pad_frac
         self.max_batch = max_batch
+        self.ragged = ragged  # batching.synthesize(ragged=): rows decoded as the reference decodes them alone
         self.last_plan_stats = None
 
     def get_inputs(self):
@@ -90,7 +91,7 @@ class InferenceSession(_SessionBase):
         outs, st = batching.synthesize(m, seqs, sids, noise_scale=float(scales[0][0]),
                                        length_scale=float(scales[0][1]), noise_scale_w=float(scales[0][2]),
                                        max_pad_frac=self.max_pad_frac, max_batch=self.max_batch,
-                                       return_stats=True)
+                                       return_stats=True, ragged=self.ragged)
         self.last_plan_stats = st
         T = max(int(o.numel()) for o in outs)
         audio = torch.zeros(B, 1, T, dtype=torch.float32, device=m.device)
