@@ -383,7 +383,9 @@ def test_dynamic_quant_conv1d_reproduces_the_onnx_spec_known_answers():
         got = run(x, torch.tensor([[[1.0]], [[255.0]]]), 1, 0)
         want = (np.array(Y, np.float32) - np.float32(zp)) * np.float32(scale)
         assert np.array_equal(got[0, 0], want), (name, got[0, 0], want)
-        assert np.array_equal(got[0, 1], want * np.float32(255.0)), name
+        # channel 1 (w_q = 255): the int32 sum is (Y - zp) * 255, THEN the cast and one multiply by s_x * s_w
+        want1 = ((np.array(Y, np.int32) - zp) * 255).astype(np.float32) * np.float32(scale)
+        assert np.array_equal(got[0, 1], want1), (name, got[0, 1], want1)
 
     xq, wq, want = onnx_convinteger_as_conv1d()
     s = np.float32(0.25)

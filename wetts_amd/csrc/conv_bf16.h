@@ -45,6 +45,7 @@ struct ConvBParams {
   float* wn_skip;         // [B][T][H] f32
   const float* wn_mask;   // [B][T]
   int wn_H, wn_last, wn_first;
+  int basic;  // 1: always conv_bf16_kernel (the decoder's UNFUSED diagnostic mode: the form the newer kernels are held to)
 };
 
 // fused ResBlock1 pair (resblock16.hip): out = (x + c2(lrelu(c1(lrelu(x)))) [+ out]) / div
@@ -76,6 +77,10 @@ int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cou
                               PackedConvB* out, int gate_h = 0);
 void free_packed_bf16(PackedConvB* pc);
 int32_t launch_conv_bf16(const PackedConvB& pc, ConvBParams p, hipStream_t stream);
+// conv16_mb2.hip: plain stride-1 convs with >= 256 output channels on 64-row wave tiles (two MFMAs per LDS read)
+bool conv16_mb2_supported(const PackedConvB& pc, const ConvBParams& p);
+int32_t launch_conv16_mb2(const ConvBParams& p, bool f16, hipStream_t stream);
+int resblock_pair16_ntc(int C);
 int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, int f16,
                        hipStream_t s);
 // ---- 16-bit WaveNet layers of the flow (wn16.hip), channel-last like the 16-bit decoder ----------

@@ -108,8 +108,9 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ t_xs, int Ty, int Tx,
                                                        int32_t* __restrict__ path) {
   extern __shared__ uint32_t mas_lds[];
-  constexpr int R = 32 / C;  // rows per bit word = rows per block of the forward loop = depth of the row ring
-  const int G = (Ty + R - 1) / R;
+  constexpr int R = 32 / C;   // rows per bit word
+  constexpr int RD = 4 * R;   // rows per block of the forward loop = depth of the row ring (128 loads in flight per lane)
+  const int G = (Ty + RD - 1) / RD * 4;  // bit words per lane, rounded up to whole blocks
   uint32_t* bits = mas_lds;                                         // [G][64]
   unsigned short* idx = (unsigned short*)(mas_lds + (size_t)G * 64);  // [Ty] path column per row
   const int b = blockIdx.x;
@@ -128,15 +129,17 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float* __restrict__
     int offc[C];  // clamped column offsets (columns >= Tx read column Tx-1: loaded, never used)
 #pragma unroll
     for (int c = 0; c < C; ++c) offc[c] = min(x0 + c, Tx - 1);
-    // the row ring: R rows x C columns = 32 loads in flight per lane.  Every load below is issued
+    // the row ring: RD rows x C columns = 128 loads in flight per lane -- one wave walks the utterance, so the ring
+    // is all the memory-level parallelism there is: at 32 loads (the first straight-line version) a row still
+    // took 230 ns, the round trip of a cold HBM line divided by 16 rows.  Every load below is issued
     // UNCONDITIONALLY (row index clamped) and every block of R rows is straight-line code: a load under a
     // branch makes the compiler wait with vmcnt(0) at the first use -- a memory round trip per row (what the
     // first version of this kernel did: 680 cycles per row).  Row base pointers are wave-uniform (scalar
     // registers), the per-lane part of an address is one 32-bit offset.
-    float ring[R][C];
+    float ring[RD][C];
     const int last = t_y - 1;
 #pragma unroll
-    for (int d = 0; d < R; ++d) {
+    for (int d = 0; d < RD; ++d) {
       const float* rowp = nc + (int64_t)min(d, last) * Tx;
 #pragma unroll
       for (int c = 0; c < C; ++c) ring[d][c] = rowp[offc[c]];
@@ -146,20 +149,20 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float* __restrict__
     for (int c = 0; c < C; ++c) prev[c] = 0.f;
     // column 0 never steps left (the backtrack tests index != 0 first): its bit is masked out once per row
     const uint32_t lanemask = (lane == 0) ? ~1u : ~0u;
-    for (int yb = 0; yb < t_y; yb += R) {  // rows >= t_y of the last block have an empty band: they change nothing
+    for (int yb = 0; yb < t_y; yb += RD) {  // rows >= t_y of the last block have an empty band: they change nothing
       uint32_t word = 0;
 #pragma unroll
-      for (int d = 0; d < R; ++d) {
+      for (int d = 0; d < RD; ++d) {
         const int y = yb + d;
         float raw[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) raw[c] = ring[d][c];
-        {  // refill this ring slot with row y + R
-          const float* rowp = nc + (int64_t)min(y + R, last) * Tx;
+        {  // refill this ring slot with row y + RD
+          const float* rowp = nc + (int64_t)min(y + RD, last) * Tx;
 #pragma unroll
           for (int c = 0; c < C; ++c) ring[d][c] = rowp[offc[c]];
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the refill where it is: R rows ahead of its use
+        __builtin_amdgcn_sched_barrier(0);  // keep the refill where it is: RD rows ahead of its use
         const int x_lo = max(0, t_x + y - t_y);
         const unsigned band = (unsigned)(min(t_x, y + 1) - x_lo);  // x in band <=> (unsigned)(x - x_lo) < band
         // value[y-1][x-1] of the lane's first column: the left neighbour's last column of the previous row, one
@@ -182,9 +185,12 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float* __restrict__
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) prev[c] = cur[c];
-        word |= (rowbits & lanemask) << (d * C);
+        word |= (rowbits & lanemask) << ((d % R) * C);
+        if (d % R == R - 1) {
+          bits[(size_t)((yb + d) / R) * 64 + lane] = word;
+          word = 0;
+        }
       }
-      bits[(size_t)(yb / R) * 64 + lane] = word;
     }
     // the wave's own LDS writes are ordered before its reads by the compiler's waitcnt; no other wave reads
     int index = t_x - 1;
@@ -235,7 +241,7 @@ int32_t k_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, i
   int C = 1;
   while (C * 64 < Tx) C *= 2;
   const int R = C <= 32 ? 32 / C : 0;
-  const size_t wave_lds = R ? ((size_t)((Ty + R - 1) / R) * 64 * 4 + (size_t)Ty * 2 + 16) : 0;
+  const size_t wave_lds = R ? ((size_t)((Ty + 4 * R - 1) / (4 * R)) * 4 * 64 * 4 + (size_t)Ty * 2 + 16) : 0;
   const bool fast = C <= 16 && wave_lds <= 150 * 1024 && Ty < 0xFFFF && Tx < 0xFFFF;
   if (fast) {
     static bool attr_done = false;

@@ -2016,8 +2016,11 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           WETTS_TRY(launch_resblock_pair16(m->b_c1[n][d], m->b_c2[n][d], pp, s));
           if (m->mrf_timing) m->mrf_launches += 1;
         } else if (c->resblock == 1) {
-          WETTS_TRY(launch_conv_bf16(m->b_c1[n][d], convb_io(rx, ch, len, ft, ch, len, B), s));
+          ConvBParams p1 = convb_io(rx, ch, len, ft, ch, len, B);
+          p1.basic = m->dec_unfused;
+          WETTS_TRY(launch_conv_bf16(m->b_c1[n][d], p1, s));
           ConvBParams p2 = convb_io(ft, ch, len, outp, ch, len, B);
+          p2.basic = m->dec_unfused;
           p2.res = rx;
           p2.r_bs = (int64_t)ch * len;
           p2.accum = accum;

@@ -19,6 +19,8 @@
 // once -- 2 tensor passes instead of 5.  Arithmetic (operation order, rounding points) is exactly
 // that of two conv_bf16_kernel launches, so the fused and unfused paths agree bit for bit
 // (tests/test_gpu_parity.py::test_fused_resblock_pair_bit_identical).
+#include <stdlib.h>
+
 #include "common.h"
 #include "conv_bf16.h"
 #include "conv16_dev.h"
@@ -32,10 +34,18 @@ namespace wetts {
 // c2 shares c1's column -> time mapping, so the rounded t1 a lane needs as c2's residual is what its
 // accumulators just produced; lrelu(t1) is written h2 rows down the tile, valid outputs are the
 // middle columns [h2, NTC - h2)  (see resblock32.hip).
-template <int C, bool F16, int NR, int OCC, bool RB2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
+// MB = 32-row m-blocks per wave.  MB = 2 (C >= 64; round 3): one B fragment -- one ds_read_b128 -- feeds TWO MFMAs.
+// The round-1 ablation of the 16-bit loop (profiles/r01_conv16_ablation.txt) put the loop with everything but
+// the MFMAs and the LDS B reads removed at 53 % of the bf16 peak: with one LDS read per 32-cycle MFMA the LDS
+// issue, not the matrix pipe, sets the pace.  A wave now owns 64 rows x 128 columns (8 accumulators), a block is
+// two waves (C = 128: 2 x 1, C = 64: 1 x 2) on the same 128 / 256-column tile as before, so the LDS tile, the
+// column -> time mapping, the K order of every accumulator and therefore the results are unchanged.
+template <int C, bool F16, int NR, int OCC, bool RB2, int MB>
+__global__ __launch_bounds__(64 * (C / (32 * MB)) * (MB == 2 ? (C == 128 ? 1 : 2) : 4 / (C / 32)))
+__attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 void resblock_pair16_kernel(const ResPairParams p) {
-  constexpr int WM = C / 32, WN = 4 / WM, NB = 4;
+  constexpr int WM = C / (32 * MB), WN = MB == 2 ? (C == 128 ? 1 : 2) : 4 / (C / 32), NB = 4;
+  constexpr int NTH = 64 * WM * WN;            // threads per block
   constexpr int NTC = 32 * NB * WN;            // columns computed per conv
   constexpr int CKB = C >= 64 ? 64 : 32;       // K chunk of the packed weights (pack_bf16_kernel)
   constexpr int NCH = C / CKB, KS = CKB / 16;
@@ -44,8 +54,8 @@ void resblock_pair16_kernel(const ResPairParams p) {
   // widest halo the staging loop is sized for; the C = 32 ResBlock2 chain also takes v3's k = 7 block
   // (dilations 3 / 12: 72 columns, 14 % of the 512-column tile)
   constexpr int MAXSPAN = (RB2 && C == 32) ? RESPAIR2_MAX_SPAN32 : RESPAIR_MAX_SPAN;
-  constexpr int MAXU = ((NTC + MAXSPAN) * SEG + 255) / 256;
-  static_assert(256 % SEG == 0, "piece index must not depend on the unit");
+  constexpr int MAXU = ((NTC + MAXSPAN) * SEG + NTH - 1) / NTH;
+  static_assert(NTH % SEG == 0, "piece index must not depend on the unit");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
 
@@ -76,36 +86,43 @@ void resblock_pair16_kernel(const ResPairParams p) {
 
   // ---- A streams -----------------------------------------------------------------------------
   const int G = NCH * p.ktaps;
-  const uint4* abase1 = reinterpret_cast<const uint4*>(p.wpk1) + ((int64_t)wm * G * KS) * 64 + lane;
-  const uint4* abase2 = reinterpret_cast<const uint4*>(p.wpk2) + ((int64_t)wm * G * KS) * 64 + lane;
-  uint4 aa[NR][KS];
+  const uint4* abase1 = reinterpret_cast<const uint4*>(p.wpk1) + ((int64_t)(wm * MB) * G * KS) * 64 + lane;
+  const uint4* abase2 = reinterpret_cast<const uint4*>(p.wpk2) + ((int64_t)(wm * MB) * G * KS) * 64 + lane;
+  const int64_t mstride = (int64_t)G * KS * 64;  // uint4 elements between consecutive m-blocks
+  uint4 aa[NR][MB][KS];
   auto a_prologue = [&](const uint4* abase) {  // groups 0 .. NR-2 in flight
 #pragma unroll
     for (int r = 0; r < NR - 1; ++r)
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
-        aa[r][s] = abase[((int64_t)(r < G ? r : 0) * KS + s) * 64];
+      for (int i = 0; i < MB; ++i)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) aa[NR - 1][s] = aa[0][s];
+        for (int s = 0; s < KS; ++s)
+          aa[r][i][s] = abase[i * mstride + ((int64_t)(r < G ? r : 0) * KS + s) * 64];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) aa[NR - 1][i][s] = aa[0][i][s];
   };
   a_prologue(abase1);
 
   // ResBlock2: raw x at c1's columns (time n0 - h2 + col) initialises c1's accumulators; requested
   // first so it is the oldest load in flight
-  const int co_blk = wm * 32;
+  const int co_blk = wm * 32 * MB;
   const int wcol = wn * (32 * NB) + (lane & 31);  // this lane's column of n-block 0
-  uint4 rres[NB][2];
+  uint4 rres[MB][NB][2];
   if (RB2) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int t = n0 - h2 + wcol + 32 * j;
       const bool ok = t >= 0 && t < p.T;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (ok) v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + co_blk + 16 * i + 8 * half);
-        rres[j][i] = v;
-      }
+      for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          uint4 v = make_uint4(0u, 0u, 0u, 0u);
+          if (ok) v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half);
+          rres[mi][j][i] = v;
+        }
     }
   }
 
@@ -115,7 +132,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
     uint4 st[MAXU];
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) {
-      const int row = (tid + 256 * i) / SEG;
+      const int row = (tid + NTH * i) / SEG;
       const int t = tx0 + row;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (row < W1 && t >= 0 && t < p.T)
@@ -124,7 +141,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
     }
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) {
-      const int row = (tid + 256 * i) / SEG;
+      const int row = (tid + NTH * i) / SEG;
       if (row < W1) {
         uint4 v = st[i];
         v.x = lrelu_pk<F16>(v.x, p.slope); v.y = lrelu_pk<F16>(v.y, p.slope);
@@ -135,62 +152,108 @@ void resblock_pair16_kernel(const ResPairParams p) {
   }
   __syncthreads();
 
-  f32x16 acc[NB];
+  f32x16 acc[MB][NB];
 #pragma unroll
-  for (int j = 0; j < NB; ++j)
+  for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.f;
 
   const unsigned char* bcol = smem_r + (size_t)wcol * RS + half * 16;
   if (RB2) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
+    for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const unsigned w4[4] = {rres[j][i].x, rres[j][i].y, rres[j][i].z, rres[j][i].w};
+      for (int j = 0; j < NB; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[j][8 * i + 2 * e] = lo16<F16>(w4[e]);
-          acc[j][8 * i + 2 * e + 1] = hi16<F16>(w4[e]);
+        for (int i = 0; i < 2; ++i) {
+          const unsigned w4[4] = {rres[mi][j][i].x, rres[mi][j][i].y, rres[mi][j][i].z, rres[mi][j][i].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[mi][j][8 * i + 2 * e] = lo16<F16>(w4[e]);
+            acc[mi][j][8 * i + 2 * e + 1] = hi16<F16>(w4[e]);
+          }
         }
-      }
   }
 
   // one conv over the LDS tile: groups g = chunk*ktaps + tap, A fragments from the register ring.
   // The prefetch of group g+NR-1 is issued UNCONDITIONALLY (index clamped to the last group):
   // a conditional load makes the compiler's s_waitcnt insertion assume it may not be pending, and
   // the vmcnt it then emits also waits for the load just issued -- i.e. a full L2 round trip per
-  // group.  Straight-line issue gives exact counts (vmcnt((NR-1)*KS) ... ).
-  auto mma_group = [&](const uint4* av, int tap, int chunk, int dil) {
+  // group.  Straight-line issue gives exact counts (vmcnt((NR-1)*KS*MB) ... ).
+  auto mma_group = [&](const uint4 (&av)[MB][KS], int tap, int chunk, int dil) {
     const unsigned char* bb = bcol + (size_t)(tap * dil) * RS + chunk * (CKB * 2);
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           const uint4 bw = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
-          acc[j] = mfma16<F16>(av[s], bw, acc[j]);
+#pragma unroll
+          for (int mi = 0; mi < MB; ++mi) acc[mi][j] = mfma16<F16>(av[mi][s], bw, acc[mi][j]);
         }
       }
   };
+  // MB = 2: B fragments software-pipelined one k-step ahead (pinned by sched_barriers): the four ds_read_b128 of
+  // step s+1 are issued in front of the eight MFMAs of step s, across group boundaries too (`nxt` = the next
+  // group's tile position), so a wave hides its own LDS latency instead of relying on its SIMD neighbour
+  uint4 bq[2][NB];
+  auto b_load = [&](uint4 (&dst)[NB], const unsigned char* bb, int s) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dst[j] = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
+  };
+  auto mma_group2 = [&](const uint4 (&av)[MB][KS], const unsigned char* cur, const unsigned char* nxt) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 1 < KS) b_load(bq[(s + 1) & 1], cur, s + 1);
+      else b_load(bq[(s + 1) & 1], nxt, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) acc[mi][j] = mfma16<F16>(av[mi][s], bq[s & 1][j], acc[mi][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   auto conv_loop = [&](const uint4* abase, int dil) {
     int chunk = 0, tap = 0, g = 0;
+    auto bpos = [&](int tp, int ch) { return bcol + (size_t)(tp * dil) * RS + ch * (CKB * 2); };
+    auto advance = [&](int& tp, int& ch) { if (++tp == p.ktaps) { tp = 0; ++ch; } };
+    if (MB == 2) b_load(bq[0], bpos(0, 0), 0);
     for (; g + NR <= G; g += NR) {
 #pragma unroll
       for (int par = 0; par < NR; ++par) {
         int gn = g + par + NR - 1;
         gn = gn < G ? gn : G - 1;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) aa[(par + NR - 1) % NR][s] = abase[((int64_t)gn * KS + s) * 64];
+        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+          for (int s = 0; s < KS; ++s)
+            aa[(par + NR - 1) % NR][mi][s] = abase[mi * mstride + ((int64_t)gn * KS + s) * 64];
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch at the top of its group
-        mma_group(aa[par], tap, chunk, dil);
-        if (++tap == p.ktaps) { tap = 0; ++chunk; }
+        if (MB == 2) {
+          int ntap = tap, nchunk = chunk;
+          advance(ntap, nchunk);
+          if (nchunk >= NCH) { ntap = tap; nchunk = chunk; }  // last group: a harmless re-read of its own tile
+          mma_group2(aa[par], bpos(tap, chunk), bpos(ntap, nchunk));
+        } else {
+          mma_group(aa[par], tap, chunk, dil);
+        }
+        advance(tap, chunk);
       }
     }
 #pragma unroll
     for (int par = 0; par < NR - 1; ++par) {  // tail: fewer than NR groups left, all in the ring
       if (g + par < G) {
-        mma_group(aa[par], tap, chunk, dil);
-        if (++tap == p.ktaps) { tap = 0; ++chunk; }
+        if (MB == 2) {
+          int ntap = tap, nchunk = chunk;
+          advance(ntap, nchunk);
+          if (nchunk >= NCH) { ntap = tap; nchunk = chunk; }
+          mma_group2(aa[par], bpos(tap, chunk), bpos(ntap, nchunk));
+        } else {
+          mma_group(aa[par], tap, chunk, dil);
+        }
+        advance(tap, chunk);
       }
     }
   };
@@ -198,26 +261,34 @@ void resblock_pair16_kernel(const ResPairParams p) {
   // ---- 2. c1 ---------------------------------------------------------------------------------
   conv_loop(abase1, p.dil);
 
-  // c2's first A groups and the raw residual are requested now; they land during step 3
+  // c2's first A groups are requested now; they land during step 3.  (MB = 1 also requests the raw residual
+  // here; with two m-blocks per wave its 64 registers on top of the 128 accumulators spill, so MB = 2 loads it
+  // in step 4, when c1's accumulators are dead -- an L2 hit: the same rows were staged a moment ago.)
   a_prologue(abase2);
+  if (MB == 1) {
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int col = wcol + 32 * j;
-    const int t = n0 + col;
-    const bool ok = !RB2 && col < NTO && t < p.T;
+    for (int j = 0; j < NB; ++j) {
+      const int col = wcol + 32 * j;
+      const int t = n0 + col;
+      const bool ok = !RB2 && col < NTO && t < p.T;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + co_blk + 16 * i + 8 * half);
-      rres[j][i] = v;
+      for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          uint4 v = make_uint4(0u, 0u, 0u, 0u);
+          if (ok) v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half);
+          rres[mi][j][i] = v;
+        }
     }
   }
 
   // ---- 3. ft = lrelu(round16(c1 + b1)) over the x tile ----------------------------------------
   {
-    float bia[16];
+    float bia[MB][16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bia[r] = p.bias1[co_blk + 16 * (r >> 3) + 8 * half + (r & 7)];
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bia[mi][r] = p.bias1[co_blk + 32 * mi + 16 * (r >> 3) + 8 * half + (r & 7)];
     __syncthreads();  // every wave has finished reading lrelu(x)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -225,21 +296,23 @@ void resblock_pair16_kernel(const ResPairParams p) {
       const int t = n0 - h2 + col;
       const bool inside = t >= 0 && t < p.T;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        unsigned w[4];
+      for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const unsigned r16 = pk2<F16>(acc[j][8 * i + 2 * e] + bia[8 * i + 2 * e],
-                                        acc[j][8 * i + 2 * e + 1] + bia[8 * i + 2 * e + 1]);
-          if (RB2) {  // the rounded t1 is c2's residual: it stays in the accumulators
-            acc[j][8 * i + 2 * e] = lo16<F16>(r16);
-            acc[j][8 * i + 2 * e + 1] = hi16<F16>(r16);
+        for (int i = 0; i < 2; ++i) {
+          unsigned w[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned r16 = pk2<F16>(acc[mi][j][8 * i + 2 * e] + bia[mi][8 * i + 2 * e],
+                                          acc[mi][j][8 * i + 2 * e + 1] + bia[mi][8 * i + 2 * e + 1]);
+            if (RB2) {  // the rounded t1 is c2's residual: it stays in the accumulators
+              acc[mi][j][8 * i + 2 * e] = lo16<F16>(r16);
+              acc[mi][j][8 * i + 2 * e + 1] = hi16<F16>(r16);
+            }
+            w[e] = inside ? lrelu_pk<F16>(r16, p.slope) : 0u;
           }
-          w[e] = inside ? lrelu_pk<F16>(r16, p.slope) : 0u;
+          *reinterpret_cast<uint4*>(smem_r + (size_t)(col + (RB2 ? h2 : 0)) * RS +
+                                    (co_blk + 32 * mi + 16 * i + 8 * half) * 2) = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        *reinterpret_cast<uint4*>(smem_r + (size_t)(col + (RB2 ? h2 : 0)) * RS +
-                                  (co_blk + 16 * i + 8 * half) * 2) = make_uint4(w[0], w[1], w[2], w[3]);
-      }
     }
     __syncthreads();
   }
@@ -247,38 +320,59 @@ void resblock_pair16_kernel(const ResPairParams p) {
   // ---- 4. c2, accumulator = residual (+ running sum) -------------------------------------------
   unsigned short* ob = p.out + (int64_t)b * p.T * C;
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int col = wcol + 32 * j;
-    const int t = RB2 ? n0 - h2 + col : n0 + col;
-    const bool ok = (RB2 ? (col >= h2 && col < NTC - h2 && t >= 0) : col < NTO) && t < p.T;
+  for (int mi = 0; mi < MB; ++mi) {
+    if (MB == 2 && !RB2) {  // one m-block's residual at a time: 32 registers in flight, not 64
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const unsigned w4[4] = {rres[j][i].x, rres[j][i].y, rres[j][i].z, rres[j][i].w};
-      float v[8];
+      for (int j = 0; j < NB; ++j) {
+        const int col = wcol + 32 * j;
+        const int t = n0 + col;
+        const bool ok = col < NTO && t < p.T;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[2 * e] = RB2 ? acc[j][8 * i + 2 * e] : lo16<F16>(w4[e]);
-        v[2 * e + 1] = RB2 ? acc[j][8 * i + 2 * e + 1] : hi16<F16>(w4[e]);
-      }
-      if (p.accum && ok) {
-        const uint4 oo = *reinterpret_cast<const uint4*>(ob + (int64_t)t * C + co_blk + 16 * i + 8 * half);
-        const unsigned o4[4] = {oo.x, oo.y, oo.z, oo.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[2 * e] += lo16<F16>(o4[e]);
-          v[2 * e + 1] += hi16<F16>(o4[e]);
+        for (int i = 0; i < 2; ++i) {
+          uint4 v = make_uint4(0u, 0u, 0u, 0u);
+          if (ok) v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half);
+          rres[mi][j][i] = v;
         }
       }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[j][8 * i + e] = v[e];
     }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int col = wcol + 32 * j;
+      const int t = RB2 ? n0 - h2 + col : n0 + col;
+      const bool ok = (RB2 ? (col >= h2 && col < NTC - h2 && t >= 0) : col < NTO) && t < p.T;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned w4[4] = {rres[mi][j][i].x, rres[mi][j][i].y, rres[mi][j][i].z, rres[mi][j][i].w};
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] = RB2 ? acc[mi][j][8 * i + 2 * e] : lo16<F16>(w4[e]);
+          v[2 * e + 1] = RB2 ? acc[mi][j][8 * i + 2 * e + 1] : hi16<F16>(w4[e]);
+        }
+        if (p.accum && ok) {
+          const uint4 oo =
+              *reinterpret_cast<const uint4*>(ob + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half);
+          const unsigned o4[4] = {oo.x, oo.y, oo.z, oo.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] += lo16<F16>(o4[e]);
+            v[2 * e + 1] += hi16<F16>(o4[e]);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[mi][j][8 * i + e] = v[e];
+      }
+    }
+    if (MB == 2) __builtin_amdgcn_sched_barrier(0);
   }
   conv_loop(abase2, dil2);
 
   // ---- 5. epilogue -----------------------------------------------------------------------------
-  float bia[16];
+  float bia[MB][16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) bia[r] = p.bias2[co_blk + 16 * (r >> 3) + 8 * half + (r & 7)];
+  for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bia[mi][r] = p.bias2[co_blk + 32 * mi + 16 * (r >> 3) + 8 * half + (r & 7)];
   const bool dodiv = p.out_div != 1.f;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -287,24 +381,36 @@ void resblock_pair16_kernel(const ResPairParams p) {
     if (RB2 ? (col < h2 || col >= NTC - h2 || t < 0) : col >= NTO) continue;
     if (t >= p.T) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float v[8];
+    for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] = acc[j][8 * i + e] + bia[8 * i + e];
-        if (dodiv) v[e] = v[e] / p.out_div;
+      for (int i = 0; i < 2; ++i) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = acc[mi][j][8 * i + e] + bia[mi][8 * i + e];
+          if (dodiv) v[e] = v[e] / p.out_div;
+        }
+        uint4 o;
+        o.x = pk2<F16>(v[0], v[1]); o.y = pk2<F16>(v[2], v[3]);
+        o.z = pk2<F16>(v[4], v[5]); o.w = pk2<F16>(v[6], v[7]);
+        *reinterpret_cast<uint4*>(ob + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half) = o;
       }
-      uint4 o;
-      o.x = pk2<F16>(v[0], v[1]); o.y = pk2<F16>(v[2], v[3]);
-      o.z = pk2<F16>(v[4], v[5]); o.w = pk2<F16>(v[6], v[7]);
-      *reinterpret_cast<uint4*>(ob + (int64_t)t * C + co_blk + 16 * i + 8 * half) = o;
-    }
   }
 }
 
-template <int C, int NR, int OCC, bool RB2>
+static int g_pair16_mb = -1;  // WETTS_PAIR16_MB=1: the round-2 one-m-block wave tiles (A/B switch for the microbenchmarks)
+static int pair16_mb() {
+  if (g_pair16_mb < 0) {
+    const char* e = getenv("WETTS_PAIR16_MB");
+    g_pair16_mb = e ? atoi(e) : 2;
+  }
+  return g_pair16_mb;
+}
+
+template <int C, int NR, int OCC, bool RB2, int MB>
 static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream) {
-  constexpr int WM = C / 32, WN = 4 / WM, NTC = 128 * WN, RS = C * 2 + 16;
+  constexpr int WM = C / (32 * MB), WN = MB == 2 ? (C == 128 ? 1 : 2) : 4 / (C / 32);
+  constexpr int NTC = 128 * WN, RS = C * 2 + 16, NTH = 64 * WM * WN;
   ResPairParams p = p0;
   const int h2 = (p.ktaps - 1) / 2 * (RB2 ? p.dil2 : 1), h1 = (p.ktaps - 1) / 2 * p.dil;
   const int NTO = NTC - 2 * h2;
@@ -317,11 +423,17 @@ static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream
   const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);
   const size_t lds = (size_t)(NTC + 2 * (h1 > h2 ? h1 : h2)) * RS;
   if (f16)
-    hipLaunchKernelGGL((resblock_pair16_kernel<C, true, NR, OCC, RB2>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, true, NR, OCC, RB2, MB>), dim3(grid), dim3(NTH), lds, stream, p);
   else
-    hipLaunchKernelGGL((resblock_pair16_kernel<C, false, NR, OCC, RB2>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, false, NR, OCC, RB2, MB>), dim3(grid), dim3(NTH), lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
+}
+
+// output columns a block of the pair kernel computes per conv (the decoder's tile arithmetic, model.hip)
+int resblock_pair16_ntc(int C) {
+  if (pair16_mb() == 2 && C >= 64) return C == 128 ? 128 : 256;
+  return 128 * (4 / (C / 32));
 }
 
 bool resblock_pair16_supported(const PackedConvB& c1, const PackedConvB& c2) {
@@ -345,10 +457,11 @@ int32_t launch_resblock_pair16(const PackedConvB& c1, const PackedConvB& c2, Res
   // ring depth 2 at 3 waves/SIMD measured best (profiles/r01_conv16_fused_pair.txt: deeper rings
   // cost occupancy or issue slots and lose 5-15 %)
   p.dil2 = 1;
+  const bool mb2 = pair16_mb() == 2;
   switch (c1.Cin) {
-    case 32: return launch_pair<32, 2, 3, false>(p, h, stream);
-    case 64: return launch_pair<64, 2, 3, false>(p, h, stream);
-    default: return launch_pair<128, 2, 3, false>(p, h, stream);
+    case 32: return launch_pair<32, 2, 3, false, 1>(p, h, stream);
+    case 64: return mb2 ? launch_pair<64, 2, 2, false, 2>(p, h, stream) : launch_pair<64, 2, 3, false, 1>(p, h, stream);
+    default: return mb2 ? launch_pair<128, 2, 2, false, 2>(p, h, stream) : launch_pair<128, 2, 3, false, 1>(p, h, stream);
   }
 }
 
@@ -360,7 +473,7 @@ bool resblock2_chain16_supported(const PackedConvB& c1, const PackedConvB& c2, i
   if (c1.pad != (c1.ktaps - 1) / 2 * c1.dil || c2.pad != (c2.ktaps - 1) / 2 * c2.dil) return false;
   if ((c1.ktaps - 1) * (c1.dil > c2.dil ? c1.dil : c2.dil) > (C == 32 ? RESPAIR2_MAX_SPAN32 : RESPAIR_MAX_SPAN))
     return false;
-  const int NTC = 128 * (4 / (C / 32));
+  const int NTC = resblock_pair16_ntc(C);
   return (c2.ktaps - 1) * c2.dil * 100 <= max_waste_pct * NTC;
 }
 
@@ -374,10 +487,11 @@ int32_t launch_resblock2_chain16(const PackedConvB& c1, const PackedConvB& c2, R
   p.dil = c1.dil;
   p.dil2 = c2.dil;
   const bool h = c1.f16 != 0;
+  const bool mb2 = pair16_mb() == 2;
   switch (c1.Cin) {
-    case 32: return launch_pair<32, 2, 3, true>(p, h, stream);
-    case 64: return launch_pair<64, 2, 3, true>(p, h, stream);
-    default: return launch_pair<128, 2, 3, true>(p, h, stream);
+    case 32: return launch_pair<32, 2, 3, true, 1>(p, h, stream);
+    case 64: return mb2 ? launch_pair<64, 2, 2, true, 2>(p, h, stream) : launch_pair<64, 2, 3, true, 1>(p, h, stream);
+    default: return mb2 ? launch_pair<128, 2, 2, true, 2>(p, h, stream) : launch_pair<128, 2, 3, true, 1>(p, h, stream);
   }
 }
 

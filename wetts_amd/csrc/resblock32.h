@@ -52,6 +52,7 @@ struct ResChain32Params {
   // ragged batch: utterance b holds lens[b] * len_mul samples (a multiple of 4); T stays the row stride (common.h)
   const int64_t* lens;
   int len_mul;
+  int bstride;  // filled by the launcher: utterance walk stride of the ragged block order
 };
 
 // c1 / c2: npairs descriptors each.  max_waste_pct bounds the share of tile columns the chain's halo

@@ -79,7 +79,11 @@ void resblock_chain32_kernel(const ResChain32Params p) {
     if (bid >= p.nblocks) return;
   }
   const int ntile = bid % p.ntiles;
-  const int b = bid / p.ntiles;
+  int b = bid / p.ntiles;
+  // ragged batches arrive sorted by length: an XCD's contiguous run of (utterance, tile) pairs would hold the few
+  // longest (or shortest) utterances and the XCDs would finish far apart.  Walk the utterances with a stride
+  // coprime to B instead, so that every run mixes long and short ones.
+  if (p.lens) b = (int)(((int64_t)b * p.bstride) % p.B);
   const int n0 = ntile * p.NTO;
   const int t0 = __builtin_amdgcn_readfirstlane(n0 - p.S);  // time of accumulator column 0
   const int M = p.Mmin + ((t0 - p.Mmin) & 3);      // left margin: (t0 - M) % 4 == 0
@@ -429,6 +433,13 @@ int32_t launch_resblock_chain32(const PackedConv* c1, const PackedConv* c2, int 
                 "resblock chain shape not supported by the fused f32 kernel");
   p.npairs = npairs;
   p.ktaps = c1[0].ktaps;
+  p.bstride = 1;
+  if (p.lens) {  // smallest stride >= 8 coprime to B (8 XCDs take the runs)
+    auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+    int st = p.B > 8 ? 8 : 1;
+    while (st < p.B && gcd(st, p.B) != 1) ++st;
+    p.bstride = st < p.B ? st : 1;
+  }
   for (int pr = 0; pr < npairs; ++pr) {
     WETTS_REQUIRE(c1[pr].wpk && c2[pr].wpk, "conv weight not packed");
     p.wpk[2 * pr] = c1[pr].wpk;
