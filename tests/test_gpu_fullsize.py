@@ -323,7 +323,7 @@ def test_aishell3_bucketed_ragged_shard_matches_oracle_and_unshards_in_order():
     seqs = [x[i, :int(lens[i])].tolist() for i in range(64)]
     outs, st = batching.synthesize(net, seqs, sid.tolist(), noise_scale=0.0, length_scale=1.0, noise_scale_w=0.0,
                                    max_pad_frac=0.08, return_stats=True, ragged=False)
-    assert st["calls"] == len(buckets) and len(outs) == 64 and st["frame_pad_frac"] < 0.12 and not st["ragged"]
+    assert st["calls"] == len(buckets) and len(outs) == 64 and st["frame_pad_frac"] < 0.15 and not st["ragged"]
     alone = {}
     for i in (0, 17, 40, 63, bk.indices[0]):
         oi, _, ymi, _ = net.infer(x[i:i + 1, :int(lens[i])].cuda(), lens[i:i + 1].cuda(), sid=sid[i:i + 1].cuda(),

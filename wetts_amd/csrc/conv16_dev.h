@@ -51,12 +51,19 @@ __device__ __forceinline__ float hi16(unsigned w) {
   if (F16) return cv_in<true>((unsigned short)(w >> 16));
   return __uint_as_float(w & 0xffff0000u);
 }
-// leaky-relu of a packed pair, computed in f32 and rounded back (the 16-bit numerics spec)
+// leaky-relu of a packed pair, computed in f32 and rounded back (the 16-bit numerics spec).
+// max(x, slope * x) == (x > 0 ? x : slope * x) for 0 <= slope <= 1 (also for +-0): one v_max_f32 per element
+// instead of a compare + select (+ the wait states between them) -- these sit in the staging and epilogue phases
+// of every 16-bit conv, where the vector ALU work is as long as the MFMA work for the k = 3 shapes
+__device__ __forceinline__ float lrelu_max(float x, float slope) {
+  const float m = x * slope;
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m));
+  return r;
+}
 template <bool F16>
 __device__ __forceinline__ unsigned lrelu_pk(unsigned w, float slope) {
-  float a = lo16<F16>(w), c = hi16<F16>(w);
-  a = a > 0.f ? a : a * slope;
-  c = c > 0.f ? c : c * slope;
+  const float a = lrelu_max(lo16<F16>(w), slope), c = lrelu_max(hi16<F16>(w), slope);
   return pk2<F16>(a, c);
 }
 template <bool F16>

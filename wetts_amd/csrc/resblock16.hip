@@ -182,20 +182,8 @@ void resblock_pair16_kernel(const ResPairParams p) {
   // a conditional load makes the compiler's s_waitcnt insertion assume it may not be pending, and
   // the vmcnt it then emits also waits for the load just issued -- i.e. a full L2 round trip per
   // group.  Straight-line issue gives exact counts (vmcnt((NR-1)*KS*MB) ... ).
-  auto mma_group = [&](const uint4 (&av)[MB][KS], int tap, int chunk, int dil) {
-    const unsigned char* bb = bcol + (size_t)(tap * dil) * RS + chunk * (CKB * 2);
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          const uint4 bw = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
-#pragma unroll
-          for (int mi = 0; mi < MB; ++mi) acc[mi][j] = mfma16<F16>(av[mi][s], bw, acc[mi][j]);
-        }
-      }
-  };
-  // MB = 2: B fragments software-pipelined one k-step ahead (pinned by sched_barriers): the four ds_read_b128 of
-  // step s+1 are issued in front of the eight MFMAs of step s, across group boundaries too (`nxt` = the next
+  // B fragments software-pipelined one k-step ahead (pinned by sched_barriers): the four ds_read_b128 of
+  // step s+1 are issued in front of the MFMAs of step s, across group boundaries too (`nxt` = the next
   // group's tile position), so a wave hides its own LDS latency instead of relying on its SIMD neighbour
   uint4 bq[2][NB];
   auto b_load = [&](uint4 (&dst)[NB], const unsigned char* bb, int s) {
@@ -219,7 +207,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
     int chunk = 0, tap = 0, g = 0;
     auto bpos = [&](int tp, int ch) { return bcol + (size_t)(tp * dil) * RS + ch * (CKB * 2); };
     auto advance = [&](int& tp, int& ch) { if (++tp == p.ktaps) { tp = 0; ++ch; } };
-    if (MB == 2) b_load(bq[0], bpos(0, 0), 0);
+    b_load(bq[0], bpos(0, 0), 0);
     for (; g + NR <= G; g += NR) {
 #pragma unroll
       for (int par = 0; par < NR; ++par) {
@@ -231,13 +219,11 @@ void resblock_pair16_kernel(const ResPairParams p) {
           for (int s = 0; s < KS; ++s)
             aa[(par + NR - 1) % NR][mi][s] = abase[mi * mstride + ((int64_t)gn * KS + s) * 64];
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch at the top of its group
-        if (MB == 2) {
+        {
           int ntap = tap, nchunk = chunk;
           advance(ntap, nchunk);
           if (nchunk >= NCH) { ntap = tap; nchunk = chunk; }  // last group: a harmless re-read of its own tile
           mma_group2(aa[par], bpos(tap, chunk), bpos(ntap, nchunk));
-        } else {
-          mma_group(aa[par], tap, chunk, dil);
         }
         advance(tap, chunk);
       }
@@ -245,13 +231,11 @@ void resblock_pair16_kernel(const ResPairParams p) {
 #pragma unroll
     for (int par = 0; par < NR - 1; ++par) {  // tail: fewer than NR groups left, all in the ring
       if (g + par < G) {
-        if (MB == 2) {
+        {
           int ntap = tap, nchunk = chunk;
           advance(ntap, nchunk);
           if (nchunk >= NCH) { ntap = tap; nchunk = chunk; }
           mma_group2(aa[par], bpos(tap, chunk), bpos(ntap, nchunk));
-        } else {
-          mma_group(aa[par], tap, chunk, dil);
         }
         advance(tap, chunk);
       }
@@ -398,11 +382,11 @@ void resblock_pair16_kernel(const ResPairParams p) {
   }
 }
 
-static int g_pair16_mb = -1;  // WETTS_PAIR16_MB=1: the round-2 one-m-block wave tiles (A/B switch for the microbenchmarks)
+static int g_pair16_mb = -1;  // WETTS_PAIR16_MB=2: 64-row wave tiles at C >= 64 (measured slower: profiles/r03_pair16_mb2.txt)
 static int pair16_mb() {
   if (g_pair16_mb < 0) {
     const char* e = getenv("WETTS_PAIR16_MB");
-    g_pair16_mb = e ? atoi(e) : 2;
+    g_pair16_mb = e ? atoi(e) : 1;
   }
   return g_pair16_mb;
 }
