@@ -139,9 +139,8 @@ void free_packed(PackedConv* pc) {
 // offset + one lane offset + immediates: no vector address arithmetic), aligned 16-byte loads with one
 // in-range predicate per piece, leaky-relu as mul + max, ds_write_b128.  The staged window starts at
 // the 16-byte boundary at or below its first column; `sh` shifts the B-operand columns to match.
-template <int MB, int NB, int WM, int WN, int EPI = 0, bool MRF = false, bool FAST = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB * NB >= 4 && WN < 4) ? 3 : 1)))
-void conv_mfma_kernel(const ConvParams p) {
+template <int MB, int NB, int WM, int WN, int EPI, bool FAST>
+__device__ __forceinline__ void conv_mfma_body(const ConvParams& p, int bid) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int CK = kConvCK;
   constexpr int MT = 32 * MB * WM;
@@ -159,7 +158,6 @@ void conv_mfma_kernel(const ConvParams p) {
   // block -> (b, mtile, ntile); ntile fastest so neighbouring blocks share halos in L2
   const int ntiles = (p.N + NT - 1) / NT;
   const int mtiles = (p.M + MT - 1) / MT;
-  int bid = blockIdx.x;
   const int ntile = bid % ntiles;
   bid /= ntiles;
   const int mtile = bid % mtiles;
@@ -531,6 +529,36 @@ void conv_mfma_kernel(const ConvParams p) {
   }
 }
 
+template <int MB, int NB, int WM, int WN, int EPI = 0, bool MRF = false, bool FAST = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB * NB >= 4 && WN < 4) ? 3 : 1)))
+void conv_mfma_kernel(const ConvParams p) {
+  conv_mfma_body<MB, NB, WM, WN, EPI, FAST>(p, blockIdx.x);
+}
+
+// Several INDEPENDENT convs of one shape class in one launch (the c1 -- or the c2 -- convs of the k = 3 / 7 / 11
+// ResBlocks of a stage: same input length, same channel count, different weights, taps and dilation).  A launch of
+// the C = 256 stage is 1728 blocks on 1024 block slots -- 1.7 rounds, the second one 69 % full -- and the next
+// launch cannot start before it has drained; three of them in one grid (longest taps first) leave one such tail
+// per group instead of one per conv.  Each block runs conv_mfma_body on its own member: same code, same results.
+constexpr int kConvGroupMax = 3;
+struct ConvGroupParams {
+  ConvParams p[kConvGroupMax];
+  int first[kConvGroupMax + 1];  // first block of member j; first[n] = grid size
+  int n;
+};
+template <int MB, int NB, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB * NB >= 4 && WN < 4) ? 3 : 1)))
+void conv_mfma_group_kernel(const ConvGroupParams gp) {
+  const int bid = blockIdx.x;
+  int j = 0;
+  if (gp.n > 1 && bid >= gp.first[1]) j = 1;
+  if (gp.n > 2 && bid >= gp.first[2]) j = 2;
+  conv_mfma_body<MB, NB, WM, WN, EPI, true>(gp.p[j], bid - gp.first[j]);
+}
+
+
+
+static bool conv_fast_ok(const ConvParams& p);
 
 static int g_conv_variant = -1;  // -1: read WETTS_CONV_VARIANT once; 0 single-role, 1 wave-specialised
 
@@ -551,11 +579,7 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
   if (blocks <= 0) return WETTS_OK;
   WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
   // FAST staging (see the kernel): plain input, 16-byte aligned rows holding a multiple of 4 samples
-  const bool fast = p.in_mask == nullptr && p.in_rev_base < 0 && (p.Cin % kConvCK) == 0 &&
-                    (p.x_cs & 3) == 0 && (p.x_bs & 3) == 0 && (p.Tin & 3) == 0 && p.span <= 125 &&
-                    (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 &&
-                    ((int64_t)p.Cin * p.x_cs) < (1ll << 29) &&
-                    (p.lens == nullptr || (p.len_mul & 3) == 0);  // ragged: every utterance a multiple of 4 samples
+  const bool fast = conv_fast_ok(p);
   const size_t lds = (size_t)2 * kConvCK * (fast ? ((NT + p.span + 3 + 3) & ~3) : NT + p.span) * sizeof(float);
   const dim3 grid((unsigned)blocks), blk(256);
   // epilogue specialisation: residual / running sum are folded into the accumulator init
@@ -593,7 +617,8 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
   return WETTS_OK;
 }
 
-int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
+// fills the geometry fields of `p` from the packed descriptor (shared by launch_conv and launch_conv_group)
+static int32_t prepare_conv(const PackedConv& pc, ConvParams& p) {
   p.wpk = pc.wpk;
   p.bias = pc.bias;
   p.M = pc.M;
@@ -621,6 +646,70 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
   } else {
     p.N = p.Tout;
   }
+  return WETTS_OK;
+}
+
+static bool conv_fast_ok(const ConvParams& p) {
+  return p.in_mask == nullptr && p.in_rev_base < 0 && (p.Cin % kConvCK) == 0 && (p.x_cs & 3) == 0 &&
+         (p.x_bs & 3) == 0 && (p.Tin & 3) == 0 && p.span <= 125 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 &&
+         ((int64_t)p.Cin * p.x_cs) < (1ll << 29) && (p.lens == nullptr || (p.len_mul & 3) == 0);
+}
+
+template <int MB, int NB, int WM, int WN>
+static int32_t launch_group_cfg(ConvGroupParams& gp, int max_span, hipStream_t stream) {
+  constexpr int MT = 32 * MB * WM, NT = 32 * NB * WN;
+  int64_t total = 0;
+  for (int j = 0; j < gp.n; ++j) {
+    gp.first[j] = (int)total;
+    total += (int64_t)cdiv(gp.p[j].N, NT) * cdiv(gp.p[j].M, MT) * gp.p[j].B;
+  }
+  gp.first[gp.n] = (int)total;
+  WETTS_REQUIRE(total > 0 && total < (1ll << 31), "conv group grid size");
+  const size_t lds = (size_t)2 * kConvCK * ((NT + max_span + 3 + 3) & ~3) * sizeof(float);
+  hipLaunchKernelGGL((conv_mfma_group_kernel<MB, NB, WM, WN, 1>), dim3((unsigned)total), dim3(256), lds, stream, gp);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// The members must be plain MRF convs of one shape class (same M, N, B, Cin; FAST staging; residual / running sum
+// in the accumulator init; no mean division): the c1 or non-final c2 convs of a stage's ResBlocks.  Anything else
+// -- and a group of one -- runs as separate launches, which is always equivalent.
+int32_t launch_conv_group(const PackedConv* const* pcs, const ConvParams* ps, int n, hipStream_t stream) {
+  if (n <= 0) return WETTS_OK;
+  ConvGroupParams gp;
+  memset(&gp, 0, sizeof(gp));
+  bool ok = n >= 2 && n <= kConvGroupMax && conv_variant() == 0;
+  int order[kConvGroupMax] = {0, 1, 2};
+  if (ok) {  // longest reduction first: the short members fill the tail of the long ones
+    for (int a = 0; a < n; ++a)
+      for (int b = a + 1; b < n; ++b)
+        if (pcs[order[b]]->ktaps > pcs[order[a]]->ktaps) { int t = order[a]; order[a] = order[b]; order[b] = t; }
+  }
+  int max_span = 0;
+  for (int j = 0; j < n && ok; ++j) {
+    gp.p[j] = ps[order[j]];
+    WETTS_TRY(prepare_conv(*pcs[order[j]], gp.p[j]));
+    const ConvParams& q = gp.p[j];
+    ok = q.up == 0 && q.out_act == OUT_NONE && q.out_mask == nullptr && q.out_div == 1.f && q.tag && conv_fast_ok(q) &&
+         q.M == gp.p[0].M && q.N == gp.p[0].N && q.B == gp.p[0].B && q.Cin == gp.p[0].Cin && q.lens == gp.p[0].lens;
+    if (q.span > max_span) max_span = q.span;
+  }
+  gp.n = n;
+  if (ok) {
+    const ConvParams& q = gp.p[0];
+    const int64_t cols = (int64_t)q.N * q.B;
+    auto nblk = [&](int mt, int nt) { return (int64_t)cdiv(q.M, mt) * cdiv(q.N, nt) * q.B; };
+    // the tile choice of launch_conv for these shapes (big tiles only: small grids are not what this is for)
+    if (q.M >= 128 && cols >= 4096 && nblk(128, 128) >= 384) return launch_group_cfg<1, 4, 4, 1>(gp, max_span, stream);
+    if (q.M > 32 && q.M < 128 && cols >= 8192 && nblk(64, 256) >= 384)
+      return launch_group_cfg<1, 4, 2, 2>(gp, max_span, stream);
+  }
+  for (int j = 0; j < n; ++j) WETTS_TRY(launch_conv(*pcs[j], ps[j], stream));
+  return WETTS_OK;
+}
+
+int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
+  WETTS_TRY(prepare_conv(pc, p));
   // launches of at most ~one small tile per CU are latency-, not throughput-bound: own schedule
   if (conv_variant() == 0 && p.lens == nullptr) {
     bool taken = false;

@@ -163,8 +163,6 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float* __restrict__
           for (int c = 0; c < C; ++c) ring[d][c] = rowp[offc[c]];
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the refill where it is: RD rows ahead of its use
-        const int x_lo = max(0, t_x + y - t_y);
-        const unsigned band = (unsigned)(min(t_x, y + 1) - x_lo);  // x in band <=> (unsigned)(x - x_lo) < band
         // value[y-1][x-1] of the lane's first column: the left neighbour's last column of the previous row, one
         // DPP move; lane 0 has no neighbour and keeps `old` = the reference's boundary value for x == 0
         const float edge = (y == 0) ? 0.f : max_neg_val;
@@ -179,8 +177,10 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float* __restrict__
           const float pc = prev[c];                        // value[y-1][x]
           const bool diag = (x == y);
           const float v_cur = diag ? max_neg_val : pc;
-          const bool in_band = (unsigned)(x - x_lo) < band;
-          cur[c] = in_band ? raw[c] + vmax(pl, v_cur) : raw[c];
+          // every cell is updated, also outside the band max(0, t_x+y-t_y) <= x < min(t_x, y+1) (where the
+          // reference leaves the raw score): an in-band cell's two operands are in-band cells of the previous row
+          // (DESIGN 3.7), so what the others hold never reaches the path -- and the select costs 3 VALU per cell
+          cur[c] = raw[c] + vmax(pl, v_cur);
           rowbits |= (diag || (pc < pl)) ? (1u << c) : 0u;
         }
 #pragma unroll
