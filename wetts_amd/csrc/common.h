@@ -146,7 +146,9 @@ void free_packed(PackedConv* pc);
 // Launches the conv.  Fills geometry fields of `p` from `pc`; caller fills the I/O fields.
 int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream);
 // n independent convs of one shape class in ONE launch where that is possible (conv_mfma.hip), else n launches
-int32_t launch_conv_group(const PackedConv* const* pcs, const ConvParams* ps, int n, hipStream_t stream);
+// (*launches = how many kernels went out)
+int32_t launch_conv_group(const PackedConv* const* pcs, const ConvParams* ps, int n, hipStream_t stream,
+                          int* launches = nullptr);
 
 int conv_variant();
 void set_conv_variant(int v);

@@ -674,7 +674,9 @@ static int32_t launch_group_cfg(ConvGroupParams& gp, int max_span, hipStream_t s
 // The members must be plain MRF convs of one shape class (same M, N, B, Cin; FAST staging; residual / running sum
 // in the accumulator init; no mean division): the c1 or non-final c2 convs of a stage's ResBlocks.  Anything else
 // -- and a group of one -- runs as separate launches, which is always equivalent.
-int32_t launch_conv_group(const PackedConv* const* pcs, const ConvParams* ps, int n, hipStream_t stream) {
+int32_t launch_conv_group(const PackedConv* const* pcs, const ConvParams* ps, int n, hipStream_t stream,
+                          int* launches) {
+  if (launches) *launches = n;
   if (n <= 0) return WETTS_OK;
   ConvGroupParams gp;
   memset(&gp, 0, sizeof(gp));
@@ -700,9 +702,14 @@ int32_t launch_conv_group(const PackedConv* const* pcs, const ConvParams* ps, in
     const int64_t cols = (int64_t)q.N * q.B;
     auto nblk = [&](int mt, int nt) { return (int64_t)cdiv(q.M, mt) * cdiv(q.N, nt) * q.B; };
     // the tile choice of launch_conv for these shapes (big tiles only: small grids are not what this is for)
-    if (q.M >= 128 && cols >= 4096 && nblk(128, 128) >= 384) return launch_group_cfg<1, 4, 4, 1>(gp, max_span, stream);
-    if (q.M > 32 && q.M < 128 && cols >= 8192 && nblk(64, 256) >= 384)
+    if (q.M >= 128 && cols >= 4096 && nblk(128, 128) >= 384) {
+      if (launches) *launches = 1;
+      return launch_group_cfg<1, 4, 4, 1>(gp, max_span, stream);
+    }
+    if (q.M > 32 && q.M < 128 && cols >= 8192 && nblk(64, 256) >= 384) {
+      if (launches) *launches = 1;
       return launch_group_cfg<1, 4, 2, 2>(gp, max_span, stream);
+    }
   }
   for (int j = 0; j < n; ++j) WETTS_TRY(launch_conv(*pcs[j], ps[j], stream));
   return WETTS_OK;

@@ -436,6 +436,7 @@ struct wetts_model {
   // the model's own standard-normal stream (wetts_infer with eps == NULL)
   mutable uint64_t rng_seed = 0, rng_offset = 0;
   int mrf_streams = 1;
+  int conv_groups = 1;  // WETTS_TUNE conv_groups: independent single convs of a ResBlock1 step in one launch (0: one each)
   hipStream_t aux_stream[WETTS_MAX_RB_KERNELS] = {};
   hipEvent_t ev_fork = nullptr, ev_chain[WETTS_MAX_RB_KERNELS] = {};
 
@@ -877,6 +878,7 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
         {"fuse_min_blocks", &m->fuse_min_blocks}, {"chain_whole_pct", &m->chain_whole_waste_pct},
         {"chain_whole_maxc", &m->chain_whole_maxc}, {"chain_pair_maxc", &m->chain_pair_maxc},
         {"chain_pair_kmax", &m->chain_pair_kmax}, {"small_max_tiles", &m->small_max_tiles},
+        {"conv_groups", &m->conv_groups},
     };
     if (const char* env = getenv("WETTS_TUNE")) {
       std::string all(env);
@@ -1566,6 +1568,166 @@ static int pair_nto(int C, int ktaps) {
   return nto > 0 ? nto : 1;
 }
 
+// One stage's ResBlock1 sum  xsum = (sum_j ResBlock1_j(xu)) / nk  at f32 (decoders.py:157-170,72-77), dilation-major:
+// the k = 3 / 7 / 11 chains of a stage are independent until the final sum, so the convs that run as single launches
+// at step d of every chain go out TOGETHER (launch_conv_group: one grid, one tail instead of three -- at the C = 256
+// stage a launch is 1.7 rounds of blocks and 15 % of its time is the half-empty last round).  Per output element the
+// arithmetic and its order are those of the chain-by-chain loop in run_hifigan (the running sum is still added in
+// chain order j = 0, 1, 2 by the last launch of each chain), so the results are bit-identical to it.
+static int32_t run_stage_rb1_grouped(const wetts_model* m, int i, const float* xu, float* xsum,
+                                     float* (*chain_buf)[3], int ch, int len, int spf, int B, const int64_t* lens,
+                                     DecTiming* tm, hipStream_t s) {
+  const wetts_config_t* c = &m->cfg;
+  const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
+  const bool chain_addr_ok = (int64_t)ch * len * 4 < (int64_t)INT32_MAX;
+  auto count = [&](int n) {
+    if (tm && tm->on) tm->launches += n;
+    if (m->mrf_timing) m->mrf_launches += n;
+  };
+  // which chains run as ONE launch (the whole ResBlock1 on the chain kernel)
+  bool whole[WETTS_MAX_RB_KERNELS];
+  const float* rx[WETTS_MAX_RB_KERNELS];
+  for (int j = 0; j < nk; ++j) {
+    const RB& rb = m->rbs[i * nk + j];
+    rx[j] = xu;
+    whole[j] = false;
+    if (!m->dec_unfused && nd <= RESCHAIN32_MAX_PAIRS && ch <= m->chain_whole_maxc && m->chain_whole_waste_pct > 0 &&
+        len % 4 == 0 && chain_addr_ok &&
+        resblock_chain32_supported(rb.c1.data(), rb.c2.data(), nd, m->fuse32_lds / 2, m->chain_whole_waste_pct)) {
+      int dl[RESCHAIN32_MAX_PAIRS];
+      for (int d = 0; d < nd; ++d) dl[d] = rb.c1[d].dil;
+      whole[j] = cdiv(len, resblock_chain32_nto(ch, rb.c1[0].ktaps, dl, nd)) * B >= m->fuse_min_blocks;
+    }
+  }
+  enum Kind { K_CHAIN1, K_FUSE32, K_SINGLES };
+  for (int d = 0; d < nd; ++d) {
+    const bool last_d = d == nd - 1;
+    Kind kind[WETTS_MAX_RB_KERNELS];
+    float* outp[WETTS_MAX_RB_KERNELS];
+    const PackedConv* g1[WETTS_MAX_RB_KERNELS];
+    ConvParams p1s[WETTS_MAX_RB_KERNELS];
+    int n1 = 0;
+    for (int j = 0; j < nk; ++j) {
+      if (whole[j]) continue;
+      const RB& rb = m->rbs[i * nk + j];
+      float *fa = chain_buf[j][0], *fb = chain_buf[j][1], *ft = chain_buf[j][2];
+      outp[j] = last_d ? xsum : ((rx[j] == fa) ? fb : fa);
+      const int pair_tiles = cdiv(len, pair_nto(ch, rb.c1[d].ktaps)) * B;
+      const bool chain1 = !m->dec_unfused && len % 4 == 0 && chain_addr_ok &&
+                          (ch <= m->chain_pair_maxc || rb.c1[d].ktaps <= m->chain_pair_kmax) &&
+                          resblock_chain32_supported(&rb.c1[d], &rb.c2[d], 1, m->fuse32_lds / 2, 100) &&
+                          pair_tiles >= m->fuse_min_blocks;
+      const bool fuse32 = !chain1 && !m->dec_unfused && !lens &&
+                          resblock_pair32_supported(rb.c1[d], rb.c2[d], m->fuse32_lds) &&
+                          !(ch >= 128 && rb.c1[d].ktaps >= m->fuse32_kmax128) &&
+                          (ch <= m->fuse32_maxc || rb.c1[d].ktaps <= m->fuse32_kwide) &&
+                          rb.c1[d].ktaps <= m->fuse32_kmax && pair_tiles >= m->fuse_min_blocks;
+      kind[j] = chain1 ? K_CHAIN1 : fuse32 ? K_FUSE32 : K_SINGLES;
+      if (kind[j] == K_SINGLES) {  // xt = c1(lrelu(x)): every chain's c1 of this step in one launch
+        ConvParams p = conv_io(rx[j], ch, len, ft, ch, B);
+        p.in_act = IN_LRELU;
+        p.in_slope = 0.1f;
+        p.tag = 1;
+        p.lens = lens;
+        p.len_mul = spf;
+        g1[n1] = &rb.c1[d];
+        p1s[n1++] = p;
+      }
+    }
+    if (n1 > 0) {
+      if (m->dec_unfused) {  // the diagnostic form: every conv its own launch
+        for (int q = 0; q < n1; ++q) WETTS_TRY(launch_conv(*g1[q], p1s[q], s));
+        count(n1);
+      } else {
+        int nl = 0;
+        WETTS_TRY(launch_conv_group(g1, p1s, n1, s, &nl));
+        count(nl);
+      }
+    }
+    // the second half of the step.  Not the last dilation: the chains are still independent -- fused pairs go out as
+    // they are, the single c2 convs as one group.  Last dilation: every chain's last launch adds the running sum, so
+    // those run one after the other in chain order (whole-chain launches take their place in that order).
+    const PackedConv* g2[WETTS_MAX_RB_KERNELS];
+    ConvParams p2s[WETTS_MAX_RB_KERNELS];
+    int n2 = 0;
+    for (int j = 0; j < nk; ++j) {
+      const RB& rb = m->rbs[i * nk + j];
+      const int accum = (last_d && j > 0) ? 1 : 0;
+      const float odiv = (last_d && j == nk - 1) ? (float)nk : 1.f;  // x = xs / self.num_kernels
+      if (whole[j]) {
+        if (!last_d) continue;
+        ResChain32Params cp;
+        memset(&cp, 0, sizeof(cp));
+        cp.x = xu;
+        cp.out = xsum;
+        cp.T = len;
+        cp.B = B;
+        cp.accum = (j > 0) ? 1 : 0;
+        cp.out_div = odiv;
+        cp.slope = 0.1f;
+        cp.lens = lens;
+        cp.len_mul = spf;
+        WETTS_TRY(launch_resblock_chain32(rb.c1.data(), rb.c2.data(), nd, cp, s));
+        count(1);
+        continue;
+      }
+      if (kind[j] == K_CHAIN1) {
+        ResChain32Params cp;
+        memset(&cp, 0, sizeof(cp));
+        cp.x = rx[j];
+        cp.out = outp[j];
+        cp.T = len;
+        cp.B = B;
+        cp.accum = accum;
+        cp.out_div = odiv;
+        cp.slope = 0.1f;
+        cp.lens = lens;
+        cp.len_mul = spf;
+        WETTS_TRY(launch_resblock_chain32(&rb.c1[d], &rb.c2[d], 1, cp, s));
+        count(1);
+      } else if (kind[j] == K_FUSE32) {
+        ResPair32Params pp;
+        memset(&pp, 0, sizeof(pp));
+        pp.x = rx[j];
+        pp.out = outp[j];
+        pp.T = len;
+        pp.B = B;
+        pp.accum = accum;
+        pp.out_div = odiv;
+        pp.slope = 0.1f;
+        WETTS_TRY(launch_resblock_pair32(rb.c1[d], rb.c2[d], pp, s));
+        count(1);
+      } else {  // x = c2(lrelu(xt)) + x
+        ConvParams p2 = conv_io(chain_buf[j][2], ch, len, outp[j], ch, B);
+        p2.in_act = IN_LRELU;
+        p2.in_slope = 0.1f;
+        p2.res = rx[j];
+        p2.r_bs = (int64_t)ch * len;
+        p2.r_cs = len;
+        p2.accum = accum;
+        p2.out_div = odiv;
+        p2.tag = 1;
+        p2.lens = lens;
+        p2.len_mul = spf;
+        if (last_d || m->dec_unfused) {
+          WETTS_TRY(launch_conv(rb.c2[d], p2, s));
+          count(1);
+        } else {
+          g2[n2] = &rb.c2[d];
+          p2s[n2++] = p2;
+        }
+      }
+      rx[j] = outp[j];
+    }
+    if (n2 > 0) {
+      int nl = 0;
+      WETTS_TRY(launch_conv_group(g2, p2s, n2, s, &nl));
+      count(nl);
+    }
+  }
+  return WETTS_OK;
+}
+
 // lens != null: ragged batch (wetts_hifigan_ragged) -- utterance b is decoded over its own lens[b] frames, as if
 // it were alone in the call; ResBlock1 models at f32 only (the caller checks)
 static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, int64_t z_cs,
@@ -1643,7 +1805,9 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
     // the chain kernel addresses one utterance's [C][T] plane with 32-bit byte offsets and buffer descriptors: a
     // plane of 2 GiB or more (one utterance above ~16.7 M samples at C = 32) takes the conv-by-conv path instead
     const bool chain_addr_ok = (int64_t)ch * len * 4 < (int64_t)INT32_MAX;
-    for (int j = 0; j < nk; ++j) {
+    const bool grouped = c->resblock == 1 && !forked && m->conv_groups;
+    if (grouped) WETTS_TRY(run_stage_rb1_grouped(m, i, xu, xsum, chain_buf, ch, len, spf, B, lens, tm, s));
+    for (int j = 0; j < (grouped ? 0 : nk); ++j) {
       const RB& rb = m->rbs[i * nk + j];
       hipStream_t sj = (forked && j > 0 && j < m->mrf_streams) ? m->aux_stream[j] : s;
       if (sj != s) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_fork, 0));
