@@ -622,14 +622,16 @@ def main():
         return None, None
 
     if ddtype == "uint8":
-        traffic, traffic_src = None, None
+        # the dynamically quantised graph keeps f32 tensors between its nodes (DynamicQuantizeLinear in, Cast * scale
+        # + bias out), so the per-conv algorithmic bytes are the f32 figure; int8 MFMA makes every Conv node HBM-bound
         roofline = {
-            "kernel": "qconv_i8_kernel (v_mfma_i32_32x32x32_i8) + its quantisation passes; ConvTranspose1d stays f32",
-            "bound": "hbm", "achieved": mrf_gbs * 0.25 if mrf_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": (mrf_gbs * 0.25 / HBM_PEAK_GBS) if mrf_ms > 0 else None, "traffic": None,
-            "launches": int(mrf_launches), "avg_launch_ms": mrf_ms / nl_ if mrf_ms > 0 else None,
-            "note": "per-conv algorithmic bytes at one byte per activation (SURVEY 8d accounting / 4); null when "
-                    "the uint8 path recorded no MRF timing",
+            "kernel": "the quantised Conv nodes of the MRF ResBlocks: qminmax + qquantize + qconv_i8_kernel "
+                      "(v_mfma_i32_32x32x32_i8) per node; ConvTranspose1d stays f32 (conv_mfma_kernel)",
+            "bound": "hbm", "achieved": mrf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": mrf_gbs / HBM_PEAK_GBS, "traffic": None,
+            "launches": int(mrf_launches), "avg_launch_ms": mrf_ms / nl_,
+            "launches_note": "one 'launch' = one Conv node = three kernels (range, quantise, integer conv)",
+            "bytes_per_launch": mby * decoded_frames / nl_,
             "mrf_share_of_step": mrf_ms / (elapsed * 1e3),
         }
     elif ddtype != "f32":

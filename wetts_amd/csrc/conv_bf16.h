@@ -45,6 +45,7 @@ struct ConvBParams {
   float* wn_skip;         // [B][T][H] f32
   const float* wn_mask;   // [B][T]
   int wn_H, wn_last, wn_first;
+  int tag;    // 1: MRF ResBlock launch (own kernel symbol for profiles, no code difference)
   int basic;  // 1: always conv_bf16_kernel (the decoder's UNFUSED diagnostic mode: the form the newer kernels are held to)
 };
 
@@ -63,6 +64,7 @@ struct ResPairParams {
   float out_div;
   float slope;     // leaky-relu slope in front of both convs
   int ntiles, nblocks;
+  unsigned long long* prof;  // measurement aid (WETTS_PAIR16_PROF=1): per-block phase timestamps, null in production
 };
 bool resblock_pair16_supported(const PackedConvB& c1, const PackedConvB& c2);
 int32_t launch_resblock_pair16(const PackedConvB& c1, const PackedConvB& c2, ResPairParams p,

@@ -115,7 +115,9 @@ __device__ __forceinline__ float gate_fast(float a, float b) {
 }
 
 // EPIM: 0 = plain epilogue, 1 / 2 = the fused WaveNet epilogues of the 16-bit flow (ConvBParams::epi_mode)
-template <int NB, int WM, int WN, int CKB, bool F16, int EPIM = 0>
+// MRFTAG = name tag of the decoder's ResBlock launches (no code difference): rocprofv3 then separates the MRF class
+// from the upsamplers / flow convs that share the instantiation (as conv_mfma_kernel's MRF flag does at f32)
+template <int NB, int WM, int WN, int CKB, bool F16, int EPIM = 0, bool MRFTAG = false>
 // three waves per SIMD where the register allocation reaches it without heavy spilling (the compiler
 // otherwise spreads over VGPRs + AGPRs and settles at two)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CKB == 32 || WM == 4) ? 3 : 1)))
@@ -265,9 +267,11 @@ void conv_bf16_kernel(const ConvBParams p) {
     for (int par = 0; par < 2; ++par) {  // ping-pong A register sets, statically indexed
       const int gg = g + par;
       if (gg < G) {
-        if (gg + 1 < G) {
+        {  // unconditional (the last group re-reads itself): a prefetch under a branch makes the compiler wait for it
+           // with vmcnt(0) at the join -- a full L2 round trip per group ("a code-generation trap")
+          const int gnx = gg + 1 < G ? gg + 1 : gg;
 #pragma unroll
-          for (int s = 0; s < KS; ++s) aa[par ^ 1][s] = abase[((int64_t)(gg + 1) * KS + s) * 64];
+          for (int s = 0; s < KS; ++s) aa[par ^ 1][s] = abase[((int64_t)gnx * KS + s) * 64];
         }
         if (tap == 0 && chunk + 1 < p.nchunks) load_chunk(chunk + 1, st0);
         const unsigned char* cur = (chunk & 1) ? buf1 : buf0;
@@ -458,6 +462,14 @@ static int32_t launch_b(const ConvBParams& p, hipStream_t stream, bool f16) {
     }
   }
   WETTS_REQUIRE(p.epi_mode == 0, "fused epilogue requested for a tile shape it is not instantiated for");
+  if (p.tag) {
+    if (f16)
+      hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, 0, true>), grid, blk, lds, stream, p);
+    else
+      hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, 0, true>), grid, blk, lds, stream, p);
+    WETTS_LAUNCH_CHECK();
+    return WETTS_OK;
+  }
   if (f16)
     hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true>), grid, blk, lds, stream, p);
   else

@@ -2182,9 +2182,11 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
         } else if (c->resblock == 1) {
           ConvBParams p1 = convb_io(rx, ch, len, ft, ch, len, B);
           p1.basic = m->dec_unfused;
+          p1.tag = 1;
           WETTS_TRY(launch_conv_bf16(m->b_c1[n][d], p1, s));
           ConvBParams p2 = convb_io(ft, ch, len, outp, ch, len, B);
           p2.basic = m->dec_unfused;
+          p2.tag = 1;
           p2.res = rx;
           p2.r_bs = (int64_t)ch * len;
           p2.accum = accum;
@@ -2197,6 +2199,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           p1.r_bs = (int64_t)ch * len;
           p1.accum = accum;
           p1.out_div = odiv;
+          p1.tag = 1;
           WETTS_TRY(launch_conv_bf16(m->b_c1[n][d], p1, s));
           if (m->mrf_timing) m->mrf_launches += 1;
         }
@@ -2346,6 +2349,12 @@ static int32_t run_hifigan_u8(const wetts_model* m, const float* z, int64_t z_bs
     ch /= 2;
     len *= u;
     float* xsum = (x == bx) ? bs : bx;
+    hipEvent_t lv0 = nullptr, lv1 = nullptr;
+    if (m->mrf_timing) {  // the MRF ResBlock class of this mode: every quantised conv of the stage (3 kernels each)
+      WETTS_HIP_CHECK(hipEventCreate(&lv0));
+      WETTS_HIP_CHECK(hipEventCreate(&lv1));
+      WETTS_HIP_CHECK(hipEventRecord(lv0, s));
+    }
     for (int j = 0; j < nk; ++j) {
       const int n = i * nk + j;
       const float* rx = bt;
@@ -2353,6 +2362,7 @@ static int32_t run_hifigan_u8(const wetts_model* m, const float* z, int64_t z_bs
         const bool last_d = (d == nd - 1);
         float* outp = last_d ? xsum : ((rx == fa) ? fb : fa);
         const float* cin = rx;
+        if (m->mrf_timing) m->mrf_launches += (c->resblock == 1) ? 2 : 1;
         if (c->resblock == 1) {
           QConvIO i1 = qio(rx, ch, len, ft, ch, B);
           i1.in_act = 1;
@@ -2372,8 +2382,13 @@ static int32_t run_hifigan_u8(const wetts_model* m, const float* z, int64_t z_bs
         rx = outp;
       }
     }
+    if (m->mrf_timing) {
+      WETTS_HIP_CHECK(hipEventRecord(lv1, s));
+      m->mrf_events.emplace_back(lv0, lv1);
+    }
     x = xsum;
   }
+  if (m->mrf_timing) m->mrf_calls += 1;
   {  // leaky_relu (default slope 0.01) -> conv_post (no bias) -> tanh
     QConvIO io = qio(x, ch, len, audio, 1, B);
     io.in_act = 1;

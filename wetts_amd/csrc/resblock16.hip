@@ -21,6 +21,8 @@
 // (tests/test_gpu_parity.py::test_fused_resblock_pair_bit_identical).
 #include <stdlib.h>
 
+#include <vector>
+
 #include "common.h"
 #include "conv_bf16.h"
 #include "conv16_dev.h"
@@ -83,6 +85,11 @@ void resblock_pair16_kernel(const ResPairParams p) {
   const int tx0 = n0 - h2 - h1;  // time of LDS row 0 of the x tile
 
   const unsigned short* xb = p.x + (int64_t)b * p.T * C;
+  // phase timestamps of wave 0 (measurement aid; p.prof is null in production -- one uniform branch per stamp)
+  auto stamp = [&](int k) {
+    if (p.prof && tid == 0) p.prof[(int64_t)bid * 8 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
 
   // ---- A streams -----------------------------------------------------------------------------
   const int G = NCH * p.ktaps;
@@ -150,7 +157,9 @@ void resblock_pair16_kernel(const ResPairParams p) {
       }
     }
   }
+  stamp(1);
   __syncthreads();
+  stamp(2);
 
   f32x16 acc[MB][NB];
 #pragma unroll
@@ -244,6 +253,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
 
   // ---- 2. c1 ---------------------------------------------------------------------------------
   conv_loop(abase1, p.dil);
+  stamp(3);
 
   // c2's first A groups are requested now; they land during step 3.  (MB = 1 also requests the raw residual
   // here; with two m-blocks per wave its 64 registers on top of the 128 accumulators spill, so MB = 2 loads it
@@ -300,6 +310,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
     }
     __syncthreads();
   }
+  stamp(4);
 
   // ---- 4. c2, accumulator = residual (+ running sum) -------------------------------------------
   unsigned short* ob = p.out + (int64_t)b * p.T * C;
@@ -349,7 +360,9 @@ void resblock_pair16_kernel(const ResPairParams p) {
     }
     if (MB == 2) __builtin_amdgcn_sched_barrier(0);
   }
+  stamp(5);
   conv_loop(abase2, dil2);
+  stamp(6);
 
   // ---- 5. epilogue -----------------------------------------------------------------------------
   float bia[MB][16];
@@ -380,6 +393,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
         *reinterpret_cast<uint4*>(ob + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half) = o;
       }
   }
+  stamp(7);
 }
 
 static int g_pair16_mb = -1;  // WETTS_PAIR16_MB=2: 64-row wave tiles at C >= 64 (measured slower: profiles/r03_pair16_mb2.txt)
@@ -406,11 +420,36 @@ static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream
   p.nblocks = (int)nb;
   const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);
   const size_t lds = (size_t)(NTC + 2 * (h1 > h2 ? h1 : h2)) * RS;
+  static const bool prof_on = getenv("WETTS_PAIR16_PROF") != nullptr;  // micro-benchmark aid: phase timeline of a block
+  static unsigned long long* prof_buf = nullptr;
+  static int prof_left = 3;  // print the first three profiled launches of the process (the last one is warm)
+  p.prof = nullptr;
+  if (prof_on && prof_left > 0 && nb <= (1 << 20)) {
+    if (!prof_buf) WETTS_HIP_CHECK(hipMalloc((void**)&prof_buf, (size_t)(1 << 20) * 8 * sizeof(unsigned long long)));
+    p.prof = prof_buf;
+  }
   if (f16)
     hipLaunchKernelGGL((resblock_pair16_kernel<C, true, NR, OCC, RB2, MB>), dim3(grid), dim3(NTH), lds, stream, p);
   else
     hipLaunchKernelGGL((resblock_pair16_kernel<C, false, NR, OCC, RB2, MB>), dim3(grid), dim3(NTH), lds, stream, p);
   WETTS_LAUNCH_CHECK();
+  if (p.prof) {
+    --prof_left;
+    WETTS_HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<unsigned long long> h((size_t)nb * 8);
+    WETTS_HIP_CHECK(hipMemcpy(h.data(), prof_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_min = ~0ull, t_max = 0;
+    for (int64_t q = 0; q < nb; ++q) {
+      for (int k = 0; k < 7; ++k) sum[k] += (double)(h[q * 8 + k + 1] - h[q * 8 + k]);
+      if (h[q * 8] < t_min) t_min = h[q * 8];
+      if (h[q * 8 + 7] > t_max) t_max = h[q * 8 + 7];
+    }
+    fprintf(stderr, "[pair16 prof] C=%d k=%d d=%d MB=%d blocks=%lld  s_memtime ticks per block: stage %.0f | barrier %.0f | "
+            "c1 loop %.0f | ft epilogue %.0f | c2 init %.0f | c2 loop %.0f | store %.0f | whole launch %.0f\n",
+            C, p.ktaps, p.dil, MB, (long long)nb, sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[4] / nb, sum[5] / nb,
+            sum[6] / nb, (double)(t_max - t_min));
+  }
   return WETTS_OK;
 }
 
