@@ -267,11 +267,9 @@ void conv_bf16_kernel(const ConvBParams p) {
     for (int par = 0; par < 2; ++par) {  // ping-pong A register sets, statically indexed
       const int gg = g + par;
       if (gg < G) {
-        {  // unconditional (the last group re-reads itself): a prefetch under a branch makes the compiler wait for it
-           // with vmcnt(0) at the join -- a full L2 round trip per group ("a code-generation trap")
-          const int gnx = gg + 1 < G ? gg + 1 : gg;
+        if (gg + 1 < G) {
 #pragma unroll
-          for (int s = 0; s < KS; ++s) aa[par ^ 1][s] = abase[((int64_t)gnx * KS + s) * 64];
+          for (int s = 0; s < KS; ++s) aa[par ^ 1][s] = abase[((int64_t)(gg + 1) * KS + s) * 64];
         }
         if (tap == 0 && chunk + 1 < p.nchunks) load_chunk(chunk + 1, st0);
         const unsigned char* cur = (chunk & 1) ? buf1 : buf0;

@@ -416,7 +416,7 @@ struct wetts_model {
   int chain_whole_maxc = 64;      // WETTS_CHAIN_WHOLE_MAXC
   int chain_pair_maxc = 32;       // WETTS_CHAIN_PAIR_MAXC: widest stage whose pairs all run on the chain kernel
   int chain_pair_kmax = 3;        // WETTS_CHAIN_PAIR_KMAX: ... and pairs with at most this many taps at any width
-  int fuse2_waste_pct = 15;       // ResBlock2 chains: max % of tile columns lost to c2's halo at C = 32
+  int fuse2_waste_pct = 20;       // ResBlock2 chains: max % of tile columns lost to c2's halo at C = 32
                                   // (HBM-bound, +6..30 %); half of it at C >= 64 (profiles/r01_conv32_rb2_chain.txt)
   // 16-bit WaveNet layers of the flow (opt-in, wetts_set_flow_precision): weights packed by the setter
   mutable int flow_precision = 0;  // 0 = f32, 1 = bf16, 2 = f16
