@@ -7,6 +7,8 @@
 // Scores are kept TRANSPOSED in the workspace: S[b,h,j,i] with the query index i fastest, so in
 // all three kernels consecutive lanes touch consecutive addresses (q, S and the output are
 // stride-1 in i; k / v / E values are wave-uniform broadcasts).
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace wetts {
@@ -448,6 +450,118 @@ int64_t attn_score_elems(int window, int dk, int B, int n_heads, int T) {
   return (int64_t)B * n_heads * T * T;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Short sequences (T <= 128: a sentence's phonemes): the WHOLE windowed attention of one head for a strip of 32
+// queries in ONE launch -- scores (+ the banded relative-key term), mask, softmax, P.V (+ the banded relative-value
+// term) -- where the general path takes six (relk table, scores, softmax, v transpose, P.V, relv add: 53 us per
+// encoder layer at B = 1, T = 64, each launch a few microseconds of work on a handful of CUs,
+// profiles/r02_b1_anatomy.txt).  k, v and the query strip are staged in LDS once; lanes run along the query index,
+// so q / P reads are conflict-free and k / v / E reads are broadcasts.  Exact f32, the scalar kernels' formulas.
+// grid (ceil(T/32), B*H), 256 threads = 32 queries x 8 groups; LDS = ((2 T + 32) dk + (T + 16) 33 + 2 (2w+1) dk) floats
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_small_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ mask, const float* __restrict__ emb_rel_k, const float* __restrict__ emb_rel_v,
+    int window, int n_heads, int dk, int T, float qdiv, int64_t qbs, float* __restrict__ out) {
+  extern __shared__ float sm_a[];
+  constexpr int QT = 32, NG = 8;
+  const int nrel = 2 * window + 1;
+  float* qs = sm_a;                       // [dk][QT]   q / sqrt(dk)
+  float* kk = qs + (size_t)dk * QT;       // [dk][T]
+  float* vv = kk + (size_t)dk * T;        // [dk][T]
+  float* S = vv + (size_t)dk * T;         // [T][QT + 1]   scores, then P
+  float* red_m = S + (size_t)T * (QT + 1);  // [NG][QT + 1]
+  float* red_s = red_m + NG * (QT + 1);
+  float* ek = red_s + NG * (QT + 1);      // [nrel][dk]
+  float* ev = ek + (size_t)nrel * dk;     // [nrel][dk]
+  const int tid = threadIdx.x;
+  const int il = tid & (QT - 1), grp = tid >> 5;
+  const int i0 = blockIdx.x * QT, i = i0 + il;
+  const int bh = blockIdx.y, b = bh / n_heads, h = bh % n_heads;
+  const float* qb = q + (int64_t)b * qbs + (int64_t)h * dk * T;
+  const float* kb = k + (int64_t)b * qbs + (int64_t)h * dk * T;
+  const float* vb = v + (int64_t)b * qbs + (int64_t)h * dk * T;
+  const float* mb = mask + (int64_t)b * T;
+  // ---- stage ----------------------------------------------------------------------------------
+  for (int e = tid; e < dk * T; e += 256) {
+    kk[e] = kb[e];
+    vv[e] = vb[e];
+  }
+  for (int e = tid; e < dk * QT; e += 256) {
+    const int d = e / QT, c = e % QT;
+    qs[e] = (i0 + c < T) ? qb[(int64_t)d * T + i0 + c] / qdiv : 0.f;  // query / math.sqrt(k_channels)
+  }
+  for (int e = tid; e < nrel * dk; e += 256) {
+    ek[e] = emb_rel_k[e];
+    ev[e] = emb_rel_v[e];
+  }
+  __syncthreads();
+  // ---- scores S[j][il] ---------------------------------------------------------------------------
+  const float mi = i < T ? mb[i] : 0.f;
+  for (int j = grp; j < T; j += NG) {
+    float acc = 0.f;
+    for (int d = 0; d < dk; ++d) acc += qs[d * QT + il] * kk[d * T + j];
+    const int r = j - i;
+    if (r >= -window && r <= window) {
+      const float* er = ek + (size_t)(r + window) * dk;
+      float rel = 0.f;
+      for (int d = 0; d < dk; ++d) rel += qs[d * QT + il] * er[d];
+      acc += rel;
+    }
+    if (mi * mb[j] == 0.f) acc = -1e4f;  // masked_fill(mask == 0, -1e4)
+    S[j * (QT + 1) + il] = acc;
+  }
+  __syncthreads();
+  // ---- softmax over j (online max / sum per group, merged through LDS) ---------------------------------
+  {
+    float mx = -INFINITY, sum = 0.f;
+    for (int j = grp; j < T; j += NG) {
+      const float x = S[j * (QT + 1) + il];
+      if (x > mx) {
+        sum = sum * expf(mx - x);
+        mx = x;
+      }
+      sum += expf(x - mx);
+    }
+    red_m[grp * (QT + 1) + il] = mx;
+    red_s[grp * (QT + 1) + il] = sum;
+    __syncthreads();
+    float M = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) M = fmaxf(M, red_m[g * (QT + 1) + il]);
+    float Z = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float mg = red_m[g * (QT + 1) + il];
+      if (mg > -INFINITY) Z += red_s[g * (QT + 1) + il] * expf(mg - M);
+    }
+    for (int j = grp; j < T; j += NG) S[j * (QT + 1) + il] = expf(S[j * (QT + 1) + il] - M) / Z;
+  }
+  __syncthreads();
+  // ---- out[d][i] = sum_j P[j][i] v[d][j] + sum_r P[i+r][i] E_v[r+w][d] ------------------------------------
+  if (i < T) {
+    for (int d = grp; d < dk; d += NG) {
+      float acc = 0.f;
+      for (int j = 0; j < T; ++j) acc += S[j * (QT + 1) + il] * vv[d * T + j];
+      float rel = 0.f;
+      for (int r = -window; r <= window; ++r) {
+        const int j = i + r;
+        if (j >= 0 && j < T) rel += S[j * (QT + 1) + il] * ev[(size_t)(r + window) * dk + d];
+      }
+      out[((int64_t)bh * dk + d) * T + i] = acc + rel;
+    }
+  }
+}
+
+static int attn_small_max_t() {  // WETTS_ATTN_SMALL=0 keeps the multi-kernel paths (A/B switch)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("WETTS_ATTN_SMALL");
+    v = e ? atoi(e) : 128;
+  }
+  return v;
+}
+
 int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t qkv_batch_stride,
                         const float* mask, const float* emb_rel_k, const float* emb_rel_v,
                         int window, int B, int n_heads, int dk, int T, float* scores, float* out,
@@ -456,6 +570,20 @@ int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t 
   if (B * T == 0) return WETTS_OK;
   WETTS_REQUIRE(T <= 65535, "attention length %d too large", T);
   const float qdiv = (float)sqrt((double)dk);
+  if (window >= 0 && T <= attn_small_max_t()) {
+    const size_t lds = ((size_t)(2 * T + 32) * dk + (size_t)(T + 16) * 33 + (size_t)2 * (2 * window + 1) * dk) * sizeof(float);
+    if (lds <= 150 * 1024) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)attn_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(attn_small_kernel, dim3(cdiv(T, 32), B * n_heads), dim3(256), lds, s, q, k, v, mask,
+                         emb_rel_k, emb_rel_v, window, n_heads, dk, T, qdiv, qbs, out);
+      WETTS_LAUNCH_CHECK();
+      return WETTS_OK;
+    }
+  }
   if (window < 0 || T >= 64) {
     // Matrix-core path: window-less attention (VITS2 flow encoders) and every relative-position
     // attention long enough to fill 32x32 tiles.  The relative-key term is a [2w+1] x T table

@@ -436,6 +436,7 @@ struct wetts_model {
   // the model's own standard-normal stream (wetts_infer with eps == NULL)
   mutable uint64_t rng_seed = 0, rng_offset = 0;
   int mrf_streams = 1;
+  int small_fork = 0;   // WETTS_TUNE small_fork: the chains of a small (streaming-window) stage on their own streams
   int conv_groups = 1;  // WETTS_TUNE conv_groups: independent single convs of a ResBlock1 step in one launch (0: one each)
   hipStream_t aux_stream[WETTS_MAX_RB_KERNELS] = {};
   hipEvent_t ev_fork = nullptr, ev_chain[WETTS_MAX_RB_KERNELS] = {};
@@ -878,7 +879,7 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
         {"fuse_min_blocks", &m->fuse_min_blocks}, {"chain_whole_pct", &m->chain_whole_waste_pct},
         {"chain_whole_maxc", &m->chain_whole_maxc}, {"chain_pair_maxc", &m->chain_pair_maxc},
         {"chain_pair_kmax", &m->chain_pair_kmax}, {"small_max_tiles", &m->small_max_tiles},
-        {"conv_groups", &m->conv_groups},
+        {"conv_groups", &m->conv_groups},       {"small_fork", &m->small_fork},
     };
     if (const char* env = getenv("WETTS_TUNE")) {
       std::string all(env);
@@ -907,7 +908,7 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
     for (int j = 0; j < cfg->n_resblock_kernels; ++j) {
       (void)hipEventCreateWithFlags(&m->ev_chain[j], hipEventDisableTiming);
-      if (j > 0 && j < m->mrf_streams)
+      if (j > 0)  // one per ResBlock chain: mrf_streams (big launches, opt-in) and small_fork (streaming windows) use them
         (void)hipStreamCreateWithFlags(&m->aux_stream[j], hipStreamNonBlocking);
     }
   }
@@ -1800,7 +1801,12 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
       WETTS_HIP_CHECK(hipEventCreate(&lv1));
       WETTS_HIP_CHECK(hipEventRecord(lv0, s));
     }
-    const bool forked = m->mrf_streams > 1;
+    // streams for the k = 3 / 7 / 11 chains of this stage: mrf_streams (opt-in, any size), or -- small_fork -- all
+    // chains concurrently when the stage's convs are launches of a few blocks (a streaming window): three
+    // independent 10-25 us kernels then share the chip instead of queueing behind each other
+    const bool small_stage = !lens && (int64_t)cdiv(ch, 64) * cdiv(len, 64) * B <= m->small_max_tiles;
+    const int nstreams = (m->small_fork && small_stage && c->resblock == 1) ? nk : m->mrf_streams;
+    const bool forked = nstreams > 1;
     if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_fork, s));
     // the chain kernel addresses one utterance's [C][T] plane with 32-bit byte offsets and buffer descriptors: a
     // plane of 2 GiB or more (one utterance above ~16.7 M samples at C = 32) takes the conv-by-conv path instead
@@ -1809,7 +1815,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
     if (grouped) WETTS_TRY(run_stage_rb1_grouped(m, i, xu, xsum, chain_buf, ch, len, spf, B, lens, tm, s));
     for (int j = 0; j < (grouped ? 0 : nk); ++j) {
       const RB& rb = m->rbs[i * nk + j];
-      hipStream_t sj = (forked && j > 0 && j < m->mrf_streams) ? m->aux_stream[j] : s;
+      hipStream_t sj = (forked && j > 0 && j < nstreams) ? m->aux_stream[j] : s;
       if (sj != s) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_fork, 0));
       float* fa = chain_buf[j][0];
       float* fb = chain_buf[j][1];
