@@ -182,7 +182,7 @@ def stream_bench(args):
                     vo.decoder(W, cd, zt[:, :, w0[0]:w0[1]], g)
                 res.setdefault("cpu_baseline", {"kind": "port", "sample": "first decoder window, mean of 3"})[
                     f"first_window_ms_{thr}thr"] = (time.perf_counter() - t0) / 3 * 1e3
-    print(json.dumps(res), flush=True)
+    print(json.dumps(res), file=json_out(), flush=True)
 
 
 # BASELINE.json `configs`, by index: what each names, as flags of this script.  configs[0] is the
@@ -323,7 +323,8 @@ def mas_bench(args):
                       "cases": rows,
                       "cpu_baseline": {"kind": "port", "cores": 1,
                                        "what": "oracle/mas_oracle.c = maximum_path_jit restated in C, serial over "
-                                               "the batch like the reference (monotonic_align.py:11-19)"}}), flush=True)
+                                               "the batch like the reference (monotonic_align.py:11-19)"}}),
+          file=json_out(), flush=True)
 
 
 def spawn_ranks(args):
@@ -436,13 +437,30 @@ def blob_fingerprint(blob):
     return torch.stack([b.sum(), (b * w).sum()])
 
 
+_JSON_OUT = None
+
+
+def json_out():
+    """The stream the ONE JSON line goes to: the process's original stdout.  File descriptor 1 itself is pointed at
+    stderr for the rest of the run, because communication libraries print connection banners from C++ straight to
+    fd 1 (Gloo does: "[Gloo] Rank 0 is connected to 1 peer ranks"), which would break the one-line contract."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _JSON_OUT
+
+
 def main():
     args = parse_args()
     if args.stream or args.mas:
+        json_out()
         assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
         return stream_bench(args) if args.stream else mas_bench(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args))
+        sys.exit(spawn_ranks(args))  # the ranks inherit this process's stdout untouched
+    json_out()
     from wetts_amd import batching, checkpoint, config, sharding, synth
 
     rank, local_rank, world = sharding.env_world()
@@ -728,7 +746,7 @@ def main():
     if not args.no_cpu_baseline and (world == 1 or args.cpu_baseline_multi):
         out["cpu_baseline"] = cpu_baseline(cfg, sd, x, lens, sid, min(args.cpu_sample, total), sr, hop,
                                            args.length_scale)
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=json_out(), flush=True)
     if world > 1:
         dist.barrier()
 

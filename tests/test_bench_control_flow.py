@@ -32,6 +32,8 @@ def test_bench_two_ranks_control_flow_and_reductions():
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout  # exactly ONE JSON line, from rank 0
+    # ... and nothing else on stdout: the banners Gloo prints from C++ ("[Gloo] Rank 0 is connected ...") go to stderr
+    assert [l for l in p.stdout.splitlines() if l.strip()] == lines, p.stdout
     d = json.loads(lines[0])
     assert d["backend_label"].startswith("STUB")
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["blob_checksum_ok"] is True

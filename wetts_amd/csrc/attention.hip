@@ -496,20 +496,37 @@ __global__ __launch_bounds__(256) void attn_small_kernel(
     ev[e] = emb_rel_v[e];
   }
   __syncthreads();
-  // ---- scores S[j][il] ---------------------------------------------------------------------------
+  // ---- scores S[j][il]: four keys at a time (four independent accumulator chains per thread: the loop is bound by
+  // LDS latency, not by arithmetic) -----------------------------------------------------------------------------
   const float mi = i < T ? mb[i] : 0.f;
-  for (int j = grp; j < T; j += NG) {
-    float acc = 0.f;
-    for (int d = 0; d < dk; ++d) acc += qs[d * QT + il] * kk[d * T + j];
-    const int r = j - i;
-    if (r >= -window && r <= window) {
-      const float* er = ek + (size_t)(r + window) * dk;
-      float rel = 0.f;
-      for (int d = 0; d < dk; ++d) rel += qs[d * QT + il] * er[d];
-      acc += rel;
+  for (int jb = grp; jb < T; jb += 4 * NG) {
+    int jj[4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) jj[u] = min(jb + u * NG, T - 1);  // clamped: a tail entry recomputes the last key
+#pragma unroll 4
+    for (int d = 0; d < dk; ++d) {
+      const float qv = qs[d * QT + il];
+      const float* kr = kk + d * T;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] += qv * kr[jj[u]];
     }
-    if (mi * mb[j] == 0.f) acc = -1e4f;  // masked_fill(mask == 0, -1e4)
-    S[j * (QT + 1) + il] = acc;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = jb + u * NG;
+      if (j >= T) continue;
+      float a = acc[u];
+      const int r = j - i;
+      if (r >= -window && r <= window) {
+        const float* er = ek + (size_t)(r + window) * dk;
+        float rel = 0.f;
+#pragma unroll 4
+        for (int d = 0; d < dk; ++d) rel += qs[d * QT + il] * er[d];
+        a += rel;
+      }
+      if (mi * mb[j] == 0.f) a = -1e4f;  // masked_fill(mask == 0, -1e4)
+      S[j * (QT + 1) + il] = a;
+    }
   }
   __syncthreads();
   // ---- softmax over j (online max / sum per group, merged through LDS) ---------------------------------
@@ -538,17 +555,30 @@ __global__ __launch_bounds__(256) void attn_small_kernel(
     for (int j = grp; j < T; j += NG) S[j * (QT + 1) + il] = expf(S[j * (QT + 1) + il] - M) / Z;
   }
   __syncthreads();
-  // ---- out[d][i] = sum_j P[j][i] v[d][j] + sum_r P[i+r][i] E_v[r+w][d] ------------------------------------
+  // ---- out[d][i] = sum_j P[j][i] v[d][j] + sum_r P[i+r][i] E_v[r+w][d], four channels at a time ------------------
   if (i < T) {
-    for (int d = grp; d < dk; d += NG) {
-      float acc = 0.f;
-      for (int j = 0; j < T; ++j) acc += S[j * (QT + 1) + il] * vv[d * T + j];
-      float rel = 0.f;
-      for (int r = -window; r <= window; ++r) {
-        const int j = i + r;
-        if (j >= 0 && j < T) rel += S[j * (QT + 1) + il] * ev[(size_t)(r + window) * dk + d];
+    for (int db = grp; db < dk; db += 4 * NG) {
+      int dd[4];
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dd[u] = min(db + u * NG, dk - 1);
+#pragma unroll 4
+      for (int j = 0; j < T; ++j) {
+        const float pv = S[j * (QT + 1) + il];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += pv * vv[dd[u] * T + j];
       }
-      out[((int64_t)bh * dk + d) * T + i] = acc + rel;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int d = db + u * NG;
+        if (d >= dk) continue;
+        float rel = 0.f;
+        for (int r = -window; r <= window; ++r) {
+          const int j = i + r;
+          if (j >= 0 && j < T) rel += S[j * (QT + 1) + il] * ev[(size_t)(r + window) * dk + d];
+        }
+        out[((int64_t)bh * dk + d) * T + i] = acc[u] + rel;
+      }
     }
   }
 }

@@ -436,7 +436,7 @@ struct wetts_model {
   // the model's own standard-normal stream (wetts_infer with eps == NULL)
   mutable uint64_t rng_seed = 0, rng_offset = 0;
   int mrf_streams = 1;
-  int small_fork = 0;   // WETTS_TUNE small_fork: the chains of a small (streaming-window) stage on their own streams
+  int small_fork = 1;   // WETTS_TUNE small_fork: the chains of a small (streaming-window) stage on their own streams
   int conv_groups = 1;  // WETTS_TUNE conv_groups: independent single convs of a ResBlock1 step in one launch (0: one each)
   hipStream_t aux_stream[WETTS_MAX_RB_KERNELS] = {};
   hipEvent_t ev_fork = nullptr, ev_chain[WETTS_MAX_RB_KERNELS] = {};
