@@ -482,14 +482,56 @@ __global__ __launch_bounds__(256) void attn_small_kernel(
   const float* kb = k + (int64_t)b * qbs + (int64_t)h * dk * T;
   const float* vb = v + (int64_t)b * qbs + (int64_t)h * dk * T;
   const float* mb = mask + (int64_t)b * T;
-  // ---- stage ----------------------------------------------------------------------------------
-  for (int e = tid; e < dk * T; e += 256) {
-    kk[e] = kb[e];
-    vv[e] = vb[e];
+  // ---- stage: 16-byte loads, eight in flight per thread (a plain element loop waits for every load before the
+  // next: 24 memory round trips per block where one is needed) -----------------------------------------------
+  {
+    const int n = dk * T;
+    const bool vec = ((n & 3) == 0) && (((uintptr_t)kb | (uintptr_t)vb) & 15) == 0;
+    if (vec) {
+      const float4* k4 = reinterpret_cast<const float4*>(kb);
+      const float4* v4 = reinterpret_cast<const float4*>(vb);
+      float4* kd = reinterpret_cast<float4*>(kk);
+      float4* vd = reinterpret_cast<float4*>(vv);
+      const int n4 = n >> 2;
+      for (int e0 = tid; e0 < n4; e0 += 256 * 4) {
+        float4 a[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = min(e0 + 256 * u, n4 - 1);  // clamped: unconditional loads
+          a[u] = k4[e];
+          c[u] = v4[e];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + 256 * u;
+          if (e < n4) {
+            kd[e] = a[u];
+            vd[e] = c[u];
+          }
+        }
+      }
+    } else {
+      for (int e = tid; e < n; e += 256) {
+        kk[e] = kb[e];
+        vv[e] = vb[e];
+      }
+    }
   }
-  for (int e = tid; e < dk * QT; e += 256) {
-    const int d = e / QT, c = e % QT;
-    qs[e] = (i0 + c < T) ? qb[(int64_t)d * T + i0 + c] / qdiv : 0.f;  // query / math.sqrt(k_channels)
+  {
+    float qv[12];  // dk * QT / 256 <= 12 for dk <= 96; larger heads loop
+    for (int e0 = tid; e0 < dk * QT; e0 += 256 * 12) {
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int e = e0 + 256 * u;
+        const int d = min(e / QT, dk - 1), c = e % QT;
+        qv[u] = qb[(int64_t)d * T + min(i0 + c, T - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int e = e0 + 256 * u;
+        if (e < dk * QT) qs[e] = (i0 + e % QT < T) ? qv[u] / qdiv : 0.f;  // query / math.sqrt(k_channels)
+      }
+    }
   }
   for (int e = tid; e < nrel * dk; e += 256) {
     ek[e] = emb_rel_k[e];

@@ -798,7 +798,7 @@ static int64_t ws_decoder(const wetts_config_t* c, int B, int L) {
   for (int i = 0; i < c->n_upsamples; ++i) lenmax *= c->upsample_rates[i];
   const int64_t u8need = 6 * A256(dec_max_elems(c, B, L)) + A256((int64_t)B * c->upsample_initial_channel) +
                          align_up(dec_max_elems(c, B, L) + 32 * (int64_t)B * lenmax, 256) +
-                         align_up(4 * (int64_t)B * lenmax, 256) + 1024;
+                         align_up(4 * (int64_t)B * lenmax, 256) + 1024 + 16384;  // + the range slots
   return f32need > u8need ? f32need : u8need;
 }
 
@@ -2317,10 +2317,14 @@ static int32_t run_hifigan_u8(const wetts_model* m, const float* z, int64_t z_bs
   float* cond = ws.take<float>((int64_t)B * C0);
   const int64_t qbytes = align_up(mx + 32 * (int64_t)B * lenmax, 256) + align_up(4 * (int64_t)B * lenmax, 256) + 512;
   char* qs = ws.take<char>(qbytes);
+  // one range slot per tensor a quantised conv consumes (qconv_u8.h): the producing conv fills it in its epilogue
+  const int nslots = c->n_upsamples * (1 + c->n_resblock_kernels * c->n_resblock_dilations * 2) + 2;
+  QuantStats* slots = ws.take<QuantStats>(nslots);
   if (!ws.ok) {
     set_error("hifigan(uint8): workspace too small");
     return WETTS_E_WORKSPACE;
   }
+  WETTS_TRY(k_qstats_reset(slots, nslots, s));
   const bool use_g = has_g(c) && g;
   if (use_g) {  // cond(g): a Conv node like the others
     QConvIO io = qio(g, c->gin_channels, 1, cond, C0, B);
@@ -2356,25 +2360,39 @@ static int32_t run_hifigan_u8(const wetts_model* m, const float* z, int64_t z_bs
     len *= u;
     float* xsum = (x == bx) ? bs : bx;
     hipEvent_t lv0 = nullptr, lv1 = nullptr;
-    if (m->mrf_timing) {  // the MRF ResBlock class of this mode: every quantised conv of the stage (3 kernels each)
+    if (m->mrf_timing) {  // the MRF ResBlock class of this mode: every quantised conv of the stage (its kernels)
       WETTS_HIP_CHECK(hipEventCreate(&lv0));
       WETTS_HIP_CHECK(hipEventCreate(&lv1));
       WETTS_HIP_CHECK(hipEventRecord(lv0, s));
     }
+    // range slots of this stage: [0] the upsampled input (no quantised conv produced it: one pass here, shared by
+    // the first conv of every chain), then per (chain, dilation) the c1 output and the c2 output; the very last
+    // slot is the last stage's output, which conv_post reads
+    QuantStats* sl = slots + (size_t)i * (1 + nk * nd * 2);
+    QuantStats* sl_in = sl;
+    WETTS_TRY(k_qminmax(bt, B, ch, len, sl_in, s));
+    QuantStats* sl_stage_out = (i == c->n_upsamples - 1) ? slots + nslots - 1 : nullptr;
     for (int j = 0; j < nk; ++j) {
       const int n = i * nk + j;
       const float* rx = bt;
+      const QuantStats* rx_stats = sl_in;
       for (int d = 0; d < nd; ++d) {
         const bool last_d = (d == nd - 1);
         float* outp = last_d ? xsum : ((rx == fa) ? fb : fa);
         const float* cin = rx;
+        const QuantStats* cin_stats = rx_stats;
+        QuantStats* s_ft = sl + 1 + (size_t)(j * nd + d) * 2;
+        QuantStats* s_out = s_ft + 1;
         if (m->mrf_timing) m->mrf_launches += (c->resblock == 1) ? 2 : 1;
         if (c->resblock == 1) {
           QConvIO i1 = qio(rx, ch, len, ft, ch, B);
           i1.in_act = 1;
           i1.in_slope = 0.1f;
+          i1.in_stats = rx_stats;
+          i1.out_stats = s_ft;
           WETTS_TRY(launch_qconv(m->q_c1[n][d], i1, qs, qbytes, s));
           cin = ft;
+          cin_stats = s_ft;
         }
         QConvIO i2 = qio(cin, ch, len, outp, ch, B);
         i2.in_act = 1;
@@ -2384,8 +2402,12 @@ static int32_t run_hifigan_u8(const wetts_model* m, const float* z, int64_t z_bs
         i2.r_cs = len;
         i2.accum = (last_d && j > 0) ? 1 : 0;
         i2.out_div = (last_d && j == nk - 1) ? (float)nk : 1.f;
+        i2.in_stats = cin_stats;
+        // what this conv writes is read by the chain's next conv, or -- the last launch of the last stage -- by conv_post
+        i2.out_stats = !last_d ? s_out : (j == nk - 1 ? sl_stage_out : nullptr);
         WETTS_TRY(launch_qconv(c->resblock == 1 ? m->q_c2[n][d] : m->q_c1[n][d], i2, qs, qbytes, s));
         rx = outp;
+        rx_stats = s_out;
       }
     }
     if (m->mrf_timing) {
@@ -2399,6 +2421,7 @@ static int32_t run_hifigan_u8(const wetts_model* m, const float* z, int64_t z_bs
     QConvIO io = qio(x, ch, len, audio, 1, B);
     io.in_act = 1;
     io.in_slope = 0.01f;
+    io.in_stats = c->n_upsamples > 0 ? slots + nslots - 1 : nullptr;
     WETTS_TRY(launch_qconv(m->q_post, io, qs, qbytes, s));
     WETTS_TRY(k_tanh_inplace(audio, (int64_t)B * len, s));
   }

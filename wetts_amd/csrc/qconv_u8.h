@@ -37,6 +37,13 @@ struct QConvIO {
   int accum;               // add the previous contents of out
   float out_div;
   int B, T;
+  // range bookkeeping across convs (round 3): a tensor's (min, max) is what DynamicQuantizeLinear needs first, and
+  // reading the tensor once more for it was 30 % of the uint8 step.  The conv that PRODUCES a tensor can record the
+  // range of what it writes (out_stats: a slot the caller has reset), and the conv that consumes it takes the slot
+  // (in_stats) instead of launching the range pass; the activation in front of the quantiser is monotone, so it is
+  // applied to the two scalars.  Exact: the same two f32 values either way.
+  const QuantStats* in_stats;
+  QuantStats* out_stats;
 };
 
 struct QConvParams {       // kernel arguments (filled by launch_qconv)
@@ -56,6 +63,9 @@ struct QConvParams {       // kernel arguments (filled by launch_qconv)
   int64_t r_bs, r_cs;
   int accum;
   float out_div;
+  int in_act;              // activation the consumer applies in front of its quantiser (for `stats`)
+  float in_slope;
+  QuantStats* out_stats;   // or null
 };
 
 // Conv1d weights only (onnxruntime's dynamic quantisation leaves ConvTranspose in float)
@@ -63,6 +73,10 @@ int32_t pack_qconv_weight(const float* w_dev, const float* bias_dev, int Cout, i
                           int pad, hipStream_t s, PackedQConv* pc);
 void free_packed_qconv(PackedQConv* pc);
 int64_t qconv_scratch_bytes(int B, int Cin, int T);  // int8 image + per-frame channel sums + stats
+// resets n range slots (min = +inf, max = -inf in the ordered encoding)
+int32_t k_qstats_reset(QuantStats* slots, int n, hipStream_t s);
+// range of a plain [B][C][T] tensor into a (reset) slot -- for tensors no quantised conv produced
+int32_t k_qminmax(const float* x, int B, int C, int T, QuantStats* slot, hipStream_t s);
 int32_t launch_qconv(const PackedQConv& pc, QConvIO io, void* scratch, int64_t scratch_bytes,
                      hipStream_t s);
 // x = tanh(x) in place (the generator's last op, decoders.py:80)

@@ -44,8 +44,10 @@ __device__ __forceinline__ float q_act(float v, int act, float slope) {
 
 // DynamicQuantizeLinear parameters from the tensor's (min, max), ONNX operator spec:
 //   range adjusted to include 0; scale = (max - min) / 255; zp = saturate(round_half_even(-min / scale))
-__device__ __forceinline__ void dq_params(const QuantStats* st, float* scale, int* zp) {
-  float mn = fminf(ord2f(st->min_ord), 0.f), mx = fmaxf(ord2f(st->max_ord), 0.f);
+// `act` / `slope`: the stats hold the range of the RAW tensor, the quantiser sees act(tensor); act is monotone
+// non-decreasing, so the range of act(x) is (act(min x), act(max x)) -- the very same f32 values a pass over act(x) finds
+__device__ __forceinline__ void dq_params(const QuantStats* st, float* scale, int* zp, int act = 0, float slope = 0.f) {
+  float mn = fminf(q_act(ord2f(st->min_ord), act, slope), 0.f), mx = fmaxf(q_act(ord2f(st->max_ord), act, slope), 0.f);
   float s = (mx - mn) / 255.f;
   if (!(s > 0.f)) s = 1.f;  // an all-zero tensor
   float z = rintf((0.f - mn) / s);
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void qminmax_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void qquantize_kernel(const float* __restrict__ x, int64_t x_bs,
                                                         int64_t x_cs, const float* __restrict__ mask,
                                                         int64_t mask_stride, int B, int C, int Cp, int T,
-                                                        int act, float slope, const QuantStats* st,
+                                                        int act, float slope, const QuantStats* st, int stats_raw,
                                                         signed char* __restrict__ xs, int* __restrict__ colsum) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, c8, t), t fastest
   const int C8 = Cp / 8;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void qquantize_kernel(const float* __restrict_
   const int b = (int)(idx / ((int64_t)T * C8));
   float scale;
   int zp;
-  dq_params(st, &scale, &zp);
+  dq_params(st, &scale, &zp, stats_raw ? act : 0, slope);
   const float mk = mask ? mask[b * mask_stride + t] : 1.f;
   unsigned w[2] = {0u, 0u};
   int sum = 0;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
   const int khalf = lane >> 5, l31 = lane & 31;
   float sx;
   int zx;
-  dq_params(p.stats, &sx, &zx);
+  dq_params(p.stats, &sx, &zx, p.in_act, p.in_slope);
   const int padv = (zx - 128) & 0xff;
   const unsigned padw = (unsigned)padv * 0x01010101u;
   const int CG = p.Cp / 32;
@@ -215,26 +217,39 @@ __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0;
 
-  for (int tap = 0; tap < p.ktaps; ++tap) {
-    int tj[NB];
-    bool ok[NB];
+  // steps = (tap, channel group) pairs; the operands of step i + 1 are requested before the MFMAs of step i
+  // (every load unconditional: out-of-range frames read frame 0 and are replaced by the padding value afterwards)
+  const int nsteps = p.ktaps * CG;
+  auto load_step = [&](int step, uint4& av, uint4 (&bv)[NB], unsigned& okm) {
+    const int st = step < nsteps ? step : nsteps - 1;
+    const int tap = st / CG, cg = st - tap * CG;
+    av = ab[((int64_t)tap * CG + cg) * 64];
+    okm = 0u;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      tj[j] = n0 + 32 * j + l31 + tap * p.dil - p.pad;
-      ok[j] = tj[j] >= 0 && tj[j] < p.T;
+      const int tj = n0 + 32 * j + l31 + tap * p.dil - p.pad;
+      const bool ok = tj >= 0 && tj < p.T;
+      okm |= ok ? (1u << j) : 0u;
+      bv[j] = *reinterpret_cast<const uint4*>(xb + (int64_t)(ok ? tj : 0) * p.Cp + cg * 32 + 16 * khalf);
     }
-    for (int cg = 0; cg < CG; ++cg) {
-      const uint4 av = ab[((int64_t)tap * CG + cg) * 64];
-      const i32x4 a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+  };
+  uint4 a_cur, a_nxt, b_cur[NB], b_nxt[NB];
+  unsigned ok_cur, ok_nxt;
+  load_step(0, a_cur, b_cur, ok_cur);
+  for (int step = 0; step < nsteps; ++step) {
+    load_step(step + 1, a_nxt, b_nxt, ok_nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    const i32x4 a = {(int)a_cur.x, (int)a_cur.y, (int)a_cur.z, (int)a_cur.w};
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        uint4 bv = make_uint4(padw, padw, padw, padw);
-        if (ok[j])
-          bv = *reinterpret_cast<const uint4*>(xb + (int64_t)tj[j] * p.Cp + cg * 32 + 16 * khalf);
-        const i32x4 bq = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
-        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq, acc[j], 0, 0, 0);
-      }
+    for (int j = 0; j < NB; ++j) {
+      const uint4 bv = (ok_cur >> j) & 1u ? b_cur[j] : make_uint4(padw, padw, padw, padw);
+      const i32x4 bq = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+      acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq, acc[j], 0, 0, 0);
     }
+    a_cur = a_nxt;
+    ok_cur = ok_nxt;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) b_cur[j] = b_nxt[j];
   }
 
   // ---- epilogue: zero-point corrections, dequantise, bias / residual / running sum, f32 store ------
@@ -248,6 +263,7 @@ __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
   const float* rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
   const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
   const bool dodiv = p.out_div != 1.f;
+  float omn = INFINITY, omx = -INFINITY;  // range of what this wave writes (for the conv that consumes it)
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int t = n0 + 32 * j + l31;
@@ -271,6 +287,19 @@ __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
       if (p.accum) v += *dst;
       if (dodiv) v = v / p.out_div;
       *dst = v;
+      omn = fminf(omn, v);
+      omx = fmaxf(omx, v);
+    }
+  }
+  if (p.out_stats) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      omn = fminf(omn, __shfl_xor(omn, off, 64));
+      omx = fmaxf(omx, __shfl_xor(omx, off, 64));
+    }
+    if (lane == 0 && omn <= omx) {
+      atomicMin(&p.out_stats->min_ord, f2ord(omn));
+      atomicMax(&p.out_stats->max_ord, f2ord(omx));
     }
   }
 }
@@ -323,6 +352,31 @@ int64_t qconv_scratch_bytes(int B, int Cin, int T) {
   return align_up((int64_t)B * T * Cp, 256) + align_up((int64_t)B * T * 4, 256) + 256;
 }
 
+__global__ void qstats_reset_slots_kernel(QuantStats* st, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    st[i].min_ord = 0xffffffffu;
+    st[i].max_ord = 0u;
+  }
+}
+
+int32_t k_qstats_reset(QuantStats* slots, int n, hipStream_t s) {
+  if (n <= 0) return WETTS_OK;
+  hipLaunchKernelGGL(qstats_reset_slots_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, slots, n);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+int32_t k_qminmax(const float* x, int B, int C, int T, QuantStats* slot, hipStream_t s) {
+  const int64_t nx = (int64_t)B * C * T;
+  if (nx <= 0) return WETTS_OK;
+  const int gridm = (int)((nx + 255) / 256 < 4096 ? (nx + 255) / 256 : 4096);
+  hipLaunchKernelGGL(qminmax_kernel, dim3(gridm), dim3(256), 0, s, x, (int64_t)C * T, (int64_t)T,
+                     (const float*)nullptr, (int64_t)0, B, C, T, 0, 0.f, slot);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
 int32_t launch_qconv(const PackedQConv& pc, QConvIO io, void* scratch, int64_t scratch_bytes,
                      hipStream_t s) {
   WETTS_REQUIRE(pc.wpk != nullptr, "quantised conv weight not packed");
@@ -334,19 +388,24 @@ int32_t launch_qconv(const PackedQConv& pc, QConvIO io, void* scratch, int64_t s
   sp += align_up((int64_t)B * T * pc.Cp, 256);
   int* colsum = reinterpret_cast<int*>(sp);
   sp += align_up((int64_t)B * T * 4, 256);
-  QuantStats* st = reinterpret_cast<QuantStats*>(sp);
+  QuantStats* own = reinterpret_cast<QuantStats*>(sp);
   const int64_t ncs = (int64_t)B * T;
-  hipLaunchKernelGGL(qstats_reset_kernel, dim3((unsigned)((ncs + 255) / 256)), dim3(256), 0, s, st, colsum, ncs);
+  // resets the per-frame channel sums and this launch's own range slot (unused when the producer left the range)
+  hipLaunchKernelGGL(qstats_reset_kernel, dim3((unsigned)((ncs + 255) / 256)), dim3(256), 0, s, own, colsum, ncs);
   WETTS_LAUNCH_CHECK();
-  const int64_t nx = (int64_t)B * pc.Cin * T;
-  const int gridm = (int)((nx + 255) / 256 < 4096 ? (nx + 255) / 256 : 4096);
-  hipLaunchKernelGGL(qminmax_kernel, dim3(gridm), dim3(256), 0, s, io.x, io.x_bs, io.x_cs, io.mask,
-                     io.mask_stride, B, pc.Cin, T, io.in_act, io.in_slope, st);
-  WETTS_LAUNCH_CHECK();
+  const bool have_range = io.in_stats != nullptr && io.mask == nullptr;
+  const QuantStats* st = have_range ? io.in_stats : own;
+  if (!have_range) {  // one more pass over the tensor: range of act(x * mask)
+    const int64_t nx = (int64_t)B * pc.Cin * T;
+    const int gridm = (int)((nx + 255) / 256 < 4096 ? (nx + 255) / 256 : 4096);
+    hipLaunchKernelGGL(qminmax_kernel, dim3(gridm), dim3(256), 0, s, io.x, io.x_bs, io.x_cs, io.mask,
+                       io.mask_stride, B, pc.Cin, T, io.in_act, io.in_slope, own);
+    WETTS_LAUNCH_CHECK();
+  }
   const int64_t nq = (int64_t)B * (pc.Cp / 8) * T;
   hipLaunchKernelGGL(qquantize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, io.x, io.x_bs,
-                     io.x_cs, io.mask, io.mask_stride, B, pc.Cin, pc.Cp, T, io.in_act, io.in_slope, st, xs,
-                     colsum);
+                     io.x_cs, io.mask, io.mask_stride, B, pc.Cin, pc.Cp, T, io.in_act, io.in_slope, st,
+                     have_range ? 1 : 0, xs, colsum);
   WETTS_LAUNCH_CHECK();
   QConvParams p;
   memset(&p, 0, sizeof(p));
@@ -357,6 +416,9 @@ int32_t launch_qconv(const PackedQConv& pc, QConvIO io, void* scratch, int64_t s
   p.out = io.out; p.o_bs = io.o_bs; p.o_cs = io.o_cs;
   p.res = io.res; p.r_bs = io.r_bs; p.r_cs = io.r_cs;
   p.accum = io.accum; p.out_div = io.out_div;
+  p.in_act = have_range ? io.in_act : 0;  // the stats of the range pass already are those of act(x)
+  p.in_slope = io.in_slope;
+  p.out_stats = io.out_stats;
   constexpr int NB = 4;
   const int64_t blocks = (int64_t)cdiv(T, 32 * NB) * cdiv(pc.Cout, 128) * B;
   WETTS_REQUIRE(blocks < (1ll << 31), "qconv grid too large");
