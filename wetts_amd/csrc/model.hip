@@ -798,7 +798,8 @@ static int64_t ws_decoder(const wetts_config_t* c, int B, int L) {
   for (int i = 0; i < c->n_upsamples; ++i) lenmax *= c->upsample_rates[i];
   const int64_t u8need = 6 * A256(dec_max_elems(c, B, L)) + A256((int64_t)B * c->upsample_initial_channel) +
                          align_up(dec_max_elems(c, B, L) + 32 * (int64_t)B * lenmax, 256) +
-                         align_up(4 * (int64_t)B * lenmax, 256) + 1024 + 16384;  // + the range slots
+                         align_up(4 * (int64_t)B * lenmax, 256) + 2048 + 16384 +  // + the range slots
+                         align_up((int64_t)B * (lenmax / 128 + 1) * 64, 256);      // + the per-block range records
   return f32need > u8need ? f32need : u8need;
 }
 
@@ -2315,7 +2316,8 @@ static int32_t run_hifigan_u8(const wetts_model* m, const float* z, int64_t z_bs
   float* fb = ws.take<float>(mx);
   float* ft = ws.take<float>(mx);
   float* cond = ws.take<float>((int64_t)B * C0);
-  const int64_t qbytes = align_up(mx + 32 * (int64_t)B * lenmax, 256) + align_up(4 * (int64_t)B * lenmax, 256) + 512;
+  const int64_t qbytes = align_up(mx + 32 * (int64_t)B * lenmax, 256) + align_up(4 * (int64_t)B * lenmax, 256) + 1024 +
+                         align_up((int64_t)B * (lenmax / 128 + 1) * 64, 256);  // + the per-block range records
   char* qs = ws.take<char>(qbytes);
   // one range slot per tensor a quantised conv consumes (qconv_u8.h): the producing conv fills it in its epilogue
   const int nslots = c->n_upsamples * (1 + c->n_resblock_kernels * c->n_resblock_dilations * 2) + 2;

@@ -66,6 +66,7 @@ struct QConvParams {       // kernel arguments (filled by launch_qconv)
   int in_act;              // activation the consumer applies in front of its quantiser (for `stats`)
   float in_slope;
   QuantStats* out_stats;   // or null
+  float2* out_partial;     // [grid blocks] (min, max) of what each block wrote; reduced into out_stats by a tiny kernel
 };
 
 // Conv1d weights only (onnxruntime's dynamic quantisation leaves ConvTranspose in float)

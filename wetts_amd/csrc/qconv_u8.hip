@@ -95,30 +95,40 @@ __global__ __launch_bounds__(256) void qminmax_kernel(const float* __restrict__ 
 }
 
 // x [B][C][T] f32 -> xs [B][T][Cp] int8 (x_q - 128, channel-last, channels padded to Cp with a real
-// zero) and colsum[b][t] = sum_c xs (over the Cp channels)
+// zero) and colsum[b][t] = sum_c xs (over the Cp channels).  A thread takes one frame x 32 channels: 32 loads in
+// flight (each coalesced along t across the lanes), one 32-byte store, and the frame's channel sum without an
+// atomic when the tensor has no more than 32 channels (one atomic per 32-channel group otherwise; the first
+// version took 8 channels per thread and paid an atomic for every 8).
 __global__ __launch_bounds__(256) void qquantize_kernel(const float* __restrict__ x, int64_t x_bs,
                                                         int64_t x_cs, const float* __restrict__ mask,
                                                         int64_t mask_stride, int B, int C, int Cp, int T,
                                                         int act, float slope, const QuantStats* st, int stats_raw,
                                                         signed char* __restrict__ xs, int* __restrict__ colsum) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, c8, t), t fastest
-  const int C8 = Cp / 8;
-  if (idx >= (int64_t)B * C8 * T) return;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, c32, t), t fastest
+  const int C32 = Cp / 32;
+  if (idx >= (int64_t)B * C32 * T) return;
   const int t = (int)(idx % T);
-  const int c8 = (int)((idx / T) % C8);
-  const int b = (int)(idx / ((int64_t)T * C8));
+  const int c32 = (int)((idx / T) % C32);
+  const int b = (int)(idx / ((int64_t)T * C32));
   float scale;
   int zp;
   dq_params(st, &scale, &zp, stats_raw ? act : 0, slope);
   const float mk = mask ? mask[b * mask_stride + t] : 1.f;
-  unsigned w[2] = {0u, 0u};
+  const float* xp = x + b * x_bs + t;
+  float raw[32];
+#pragma unroll
+  for (int e = 0; e < 32; ++e) {
+    const int c = c32 * 32 + e;
+    raw[e] = xp[(int64_t)(c < C ? c : C - 1) * x_cs];  // unconditional (clamped channel), selected below
+  }
+  unsigned w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   int sum = 0;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = c8 * 8 + e;
+  for (int e = 0; e < 32; ++e) {
+    const int c = c32 * 32 + e;
     int q = zp;  // channel padding: (q - zp) = 0
     if (c < C) {
-      float v = x[b * x_bs + c * x_cs + t] * mk;
+      float v = raw[e] * mk;
       v = q_act(v, act, slope);
       float r = rintf(v / scale) + (float)zp;  // round half to even, then saturate
       r = fminf(fmaxf(r, 0.f), 255.f);
@@ -128,8 +138,11 @@ __global__ __launch_bounds__(256) void qquantize_kernel(const float* __restrict_
     sum += sv;
     w[e >> 2] |= (unsigned)(sv & 0xff) << (8 * (e & 3));
   }
-  *reinterpret_cast<uint2*>(xs + ((int64_t)b * T + t) * Cp + c8 * 8) = make_uint2(w[0], w[1]);
-  atomicAdd(&colsum[(int64_t)b * T + t], sum);
+  uint4* dst = reinterpret_cast<uint4*>(xs + ((int64_t)b * T + t) * Cp + c32 * 32);
+  dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  if (C32 == 1) colsum[(int64_t)b * T + t] = sum;
+  else atomicAdd(&colsum[(int64_t)b * T + t], sum);
 }
 
 // weight statistics -> (scale, zero point) per ORT's compute_scale_zp (range includes 0)
@@ -189,18 +202,23 @@ template <int NB>
 __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int NT = 32 * NB;  // columns per wave (= per block: the 4 waves take 4 m-blocks)
-  const int ntiles = (p.T + NT - 1) / NT;
-  const int mtiles = (p.M + 127) / 128;
+  constexpr int NT = 32 * NB;  // columns per wave
+  // the 4 waves of a block take mw m-blocks x (4 / mw) column groups: mw = 4 for M >= 128 (one column group),
+  // 2 for M = 64, 1 for M <= 32 (four column groups) -- no wave of a narrow conv sits idle
+  const int mw = p.M > 64 ? 4 : (p.M > 32 ? 2 : 1);
+  const int cgw = 4 / mw;
+  const int ntiles = (p.T + NT * cgw - 1) / (NT * cgw);
+  const int mtiles = (p.M + 32 * mw - 1) / (32 * mw);
   int bid = blockIdx.x;
   const int ntile = bid % ntiles;
   bid /= ntiles;
   const int mtile = bid % mtiles;
   const int b = bid / mtiles;
-  const int mt32 = mtile * 4 + wave;
+  const int mt32 = mtile * mw + wave % mw;
   const int row0 = mt32 * 32;
   if (row0 >= p.M) return;
-  const int n0 = ntile * NT;
+  const int n0 = (ntile * cgw + wave / mw) * NT;
+  if (n0 >= p.T) return;
   const int khalf = lane >> 5, l31 = lane & 31;
   float sx;
   int zx;
@@ -233,23 +251,29 @@ __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
       bv[j] = *reinterpret_cast<const uint4*>(xb + (int64_t)(ok ? tj : 0) * p.Cp + cg * 32 + 16 * khalf);
     }
   };
-  uint4 a_cur, a_nxt, b_cur[NB], b_nxt[NB];
-  unsigned ok_cur, ok_nxt;
-  load_step(0, a_cur, b_cur, ok_cur);
-  for (int step = 0; step < nsteps; ++step) {
-    load_step(step + 1, a_nxt, b_nxt, ok_nxt);
-    __builtin_amdgcn_sched_barrier(0);
-    const i32x4 a = {(int)a_cur.x, (int)a_cur.y, (int)a_cur.z, (int)a_cur.w};
+  // a ring three steps deep (two in flight behind the one being consumed): a step is four MFMAs, far less than an
+  // L2 round trip, so one step of prefetch distance left the loop waiting on memory.  Loads are unconditional
+  // (clamped step index), so the waits carry exact counts; only the MFMAs sit under the (uniform) tail test.
+  constexpr int RD = 3;
+  uint4 a_r[RD], b_r[RD][NB];
+  unsigned ok_r[RD];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const uint4 bv = (ok_cur >> j) & 1u ? b_cur[j] : make_uint4(padw, padw, padw, padw);
-      const i32x4 bq = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
-      acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq, acc[j], 0, 0, 0);
+  for (int u = 0; u < RD; ++u) load_step(u, a_r[u], b_r[u], ok_r[u]);
+  for (int step = 0; step < nsteps; step += RD) {
+#pragma unroll
+    for (int u = 0; u < RD; ++u) {
+      if (step + u < nsteps) {
+        const i32x4 a = {(int)a_r[u].x, (int)a_r[u].y, (int)a_r[u].z, (int)a_r[u].w};
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const uint4 bv = (ok_r[u] >> j) & 1u ? b_r[u][j] : make_uint4(padw, padw, padw, padw);
+          const i32x4 bq = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+          acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq, acc[j], 0, 0, 0);
+        }
+      }
+      load_step(step + u + RD, a_r[u], b_r[u], ok_r[u]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    a_cur = a_nxt;
-    ok_cur = ok_nxt;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) b_cur[j] = b_nxt[j];
   }
 
   // ---- epilogue: zero-point corrections, dequantise, bias / residual / running sum, f32 store ------
@@ -264,6 +288,17 @@ __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
   const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
   const bool dodiv = p.out_div != 1.f;
   float omn = INFINITY, omx = -INFINITY;  // range of what this wave writes (for the conv that consumes it)
+  // per-row constants of this lane's 16 rows: zero-point correction, bias (+ per-utterance bias)
+  int rcorr[16];
+  float rbias[16], rbb[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    const bool okr = row < p.M;
+    rcorr[r] = okr ? cx * p.rowsum[row] : 0;
+    rbias[r] = (okr && p.bias) ? p.bias[row] : 0.f;
+    rbb[r] = (okr && bb) ? bb[row] : 0.f;
+  }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int t = n0 + 32 * j + l31;
@@ -274,34 +309,87 @@ __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
       cs += (tt >= 0 && tt < p.T) ? csb[tt] : p.Cp * (zx - 128);
     }
     const int base = cw * cs + K * cx * cw;
+    // all of this column's residual / running-sum operands are requested BEFORE the first store: the stores go
+    // through a plain float* the loads might alias, so left to itself every load waits behind the previous store --
+    // 16 dependent memory round trips per column block instead of one
+    float rv[16], pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      const bool okr = row < p.M;
+      rv[r] = (rb && okr) ? rb[(int64_t)row * p.r_cs + t] : 0.f;
+      pv[r] = (p.accum && okr) ? ob[(int64_t)row * p.o_cs + t] : 0.f;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
       if (row >= p.M) continue;
-      const int a = acc[j][r] + base + cx * p.rowsum[row];
+      const int a = acc[j][r] + base + rcorr[r];
+      // (the empty asm pins the rounded product: HIP contracts a * b + c -- also through __fmul_rn / __fadd_rn --
+      // into v_fma_f32, one rounding instead of the graph's two)
       float v = (float)a * sprod;
-      if (p.bias) v += p.bias[row];
-      if (bb) v += bb[row];
-      if (rb) v += rb[(int64_t)row * p.r_cs + t];
-      float* dst = ob + (int64_t)row * p.o_cs + t;
-      if (p.accum) v += *dst;
+      asm volatile("" : "+v"(v));
+      v += rbias[r];
+      if (bb) v += rbb[r];  // the graph adds cond(g) to the finished conv_pre output
+      if (rb) v += rv[r];
+      if (p.accum) v += pv[r];
       if (dodiv) v = v / p.out_div;
-      *dst = v;
+      ob[(int64_t)row * p.o_cs + t] = v;
       omn = fminf(omn, v);
       omx = fmaxf(omx, v);
     }
   }
-  if (p.out_stats) {
+  if (p.out_partial) {
+    // one (min, max) record per BLOCK, no atomics: 25 k waves hitting one slot with atomicMin / atomicMax were most
+    // of this kernel's time (same-address atomics serialise at ~12 ns each); qrange_reduce_kernel folds the records
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       omn = fminf(omn, __shfl_xor(omn, off, 64));
       omx = fmaxf(omx, __shfl_xor(omx, off, 64));
     }
+    // (no __syncthreads: waves of a block may have returned early.)  Every wave folds its range into the BLOCK's own
+    // two words: at most four contenders per address, all on this CU
     if (lane == 0 && omn <= omx) {
-      atomicMin(&p.out_stats->min_ord, f2ord(omn));
-      atomicMax(&p.out_stats->max_ord, f2ord(omx));
+      atomicMin(reinterpret_cast<unsigned*>(&p.out_partial[blockIdx.x].x), f2ord(omn));
+      atomicMax(reinterpret_cast<unsigned*>(&p.out_partial[blockIdx.x].y), f2ord(omx));
     }
   }
+}
+
+// partial[i] = (min_ord, max_ord) of block i (ordered-uint encoding, reset to (0xffffffff, 0)) -> the slot
+__global__ __launch_bounds__(1024) void qrange_reduce_kernel(const float2* __restrict__ partial, int n,
+                                                             QuantStats* __restrict__ slot) {
+  __shared__ unsigned smn[16], smx[16];
+  unsigned mn = 0xffffffffu, mx = 0u;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const unsigned a = __float_as_uint(partial[i].x), b = __float_as_uint(partial[i].y);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned a = __shfl_xor(mn, off, 64), b = __shfl_xor(mx, off, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    smn[threadIdx.x >> 6] = mn;
+    smx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) {
+      mn = smn[w] < mn ? smn[w] : mn;
+      mx = smx[w] > mx ? smx[w] : mx;
+    }
+    slot->min_ord = mn;
+    slot->max_ord = mx;
+  }
+}
+
+__global__ void qpartial_reset_kernel(float2* partial, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) partial[i] = make_float2(__uint_as_float(0xffffffffu), __uint_as_float(0u));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -347,9 +435,13 @@ void free_packed_qconv(PackedQConv* pc) {
   pc->wstats = nullptr;
 }
 
+static int64_t qconv_partial_bytes(int B, int T) {  // upper bound: <= 8 blocks per 128 columns (Cout <= 1024)
+  return align_up((int64_t)B * (T / 128 + 1) * 8 * (int64_t)sizeof(float2), 256);
+}
+
 int64_t qconv_scratch_bytes(int B, int Cin, int T) {
   const int64_t Cp = (Cin + 31) / 32 * 32;
-  return align_up((int64_t)B * T * Cp, 256) + align_up((int64_t)B * T * 4, 256) + 256;
+  return align_up((int64_t)B * T * Cp, 256) + align_up((int64_t)B * T * 4, 256) + 256 + qconv_partial_bytes(B, T);
 }
 
 __global__ void qstats_reset_slots_kernel(QuantStats* st, int n) {
@@ -389,6 +481,8 @@ int32_t launch_qconv(const PackedQConv& pc, QConvIO io, void* scratch, int64_t s
   int* colsum = reinterpret_cast<int*>(sp);
   sp += align_up((int64_t)B * T * 4, 256);
   QuantStats* own = reinterpret_cast<QuantStats*>(sp);
+  sp += 256;
+  float2* partial = reinterpret_cast<float2*>(sp);
   const int64_t ncs = (int64_t)B * T;
   // resets the per-frame channel sums and this launch's own range slot (unused when the producer left the range)
   hipLaunchKernelGGL(qstats_reset_kernel, dim3((unsigned)((ncs + 255) / 256)), dim3(256), 0, s, own, colsum, ncs);
@@ -402,7 +496,7 @@ int32_t launch_qconv(const PackedQConv& pc, QConvIO io, void* scratch, int64_t s
                        io.mask_stride, B, pc.Cin, T, io.in_act, io.in_slope, own);
     WETTS_LAUNCH_CHECK();
   }
-  const int64_t nq = (int64_t)B * (pc.Cp / 8) * T;
+  const int64_t nq = (int64_t)B * (pc.Cp / 32) * T;
   hipLaunchKernelGGL(qquantize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, io.x, io.x_bs,
                      io.x_cs, io.mask, io.mask_stride, B, pc.Cin, pc.Cp, T, io.in_act, io.in_slope, st,
                      have_range ? 1 : 0, xs, colsum);
@@ -420,10 +514,22 @@ int32_t launch_qconv(const PackedQConv& pc, QConvIO io, void* scratch, int64_t s
   p.in_slope = io.in_slope;
   p.out_stats = io.out_stats;
   constexpr int NB = 4;
-  const int64_t blocks = (int64_t)cdiv(T, 32 * NB) * cdiv(pc.Cout, 128) * B;
+  const int mw = pc.Cout > 64 ? 4 : (pc.Cout > 32 ? 2 : 1);  // as in the kernel
+  const int64_t blocks = (int64_t)cdiv(T, 32 * NB * (4 / mw)) * cdiv(pc.Cout, 32 * mw) * B;
   WETTS_REQUIRE(blocks < (1ll << 31), "qconv grid too large");
+  p.out_partial = nullptr;
+  if (io.out_stats) {
+    WETTS_REQUIRE(blocks * (int64_t)sizeof(float2) <= qconv_partial_bytes(B, T), "qconv: more blocks than range records");
+    p.out_partial = partial;
+    hipLaunchKernelGGL(qpartial_reset_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, s, partial, (int)blocks);
+    WETTS_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL((qconv_i8_kernel<NB>), dim3((unsigned)blocks), dim3(256), 0, s, p);
   WETTS_LAUNCH_CHECK();
+  if (io.out_stats) {
+    hipLaunchKernelGGL(qrange_reduce_kernel, dim3(1), dim3(1024), 0, s, partial, (int)blocks, io.out_stats);
+    WETTS_LAUNCH_CHECK();
+  }
   return WETTS_OK;
 }
 
