@@ -22,7 +22,7 @@ import benchlib  # noqa: E402
 from wetts_amd import _lib  # noqa: E402
 
 lib = benchlib.load()
-B, Ty = 16, 864
+B, Ty = int(os.environ.get("WETTS_BENCH_B", "16")), 864
 variants = [int(v, 0) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,1").split(",")]
 shapes = []
 L = Ty
@@ -62,7 +62,8 @@ for (ch, k, d, L, fl) in shapes:
     ref = None
     for v in variants:
         ms, cs = C.c_double(), C.c_double()
-        rc = lib.wetts_bench_conv(ch, ch, k, d, B, L, fl | extra | (64 if rb2 else 0), v, 5,
+        rc = lib.wetts_bench_conv(ch, ch, k, d, B, L, fl | extra | (64 if rb2 else 0), v,
+                                  int(os.environ.get("WETTS_BENCH_ITERS", "5")),
                                   C.byref(ms), C.byref(cs))
         if rc != 0:
             row += f"  ERR {_lib.last_error()}"

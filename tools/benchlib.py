@@ -22,6 +22,8 @@ def load():
     lib.wetts_bench_mfma_loop.argtypes = [_I32, _I32, _I32, _I32, _D, _D]
     lib.wetts_bench_mfma_loop2.argtypes = [_I32, _I32, _I32, _I32, _D, _D]
     lib.wetts_bench_mfma_valu.argtypes = [_I32, _I32, _I32, _D, _D, _D]
+    lib.wetts_bench_mfma16_loop.argtypes = [_I32] * 5 + [_D, _D, _D]
+    lib.wetts_bench_mfma16_loop.restype = _I32
     return lib
 
 

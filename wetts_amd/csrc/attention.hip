@@ -450,6 +450,20 @@ int64_t attn_score_elems(int window, int dk, int B, int n_heads, int T) {
   return (int64_t)B * n_heads * T * T;
 }
 
+struct AttnSmallLayout {
+  int Tp, Tk, SS;   // keys padded to 4; + the relative columns padded to 4; row stride of S (4 x odd: conflict-free
+  size_t lds;       // 16-byte reads across the 32 query lanes)
+};
+__host__ __device__ static inline AttnSmallLayout attn_small_layout(int T, int dk, int window) {
+  AttnSmallLayout L;
+  const int nrel = 2 * window + 1;
+  L.Tp = (T + 3) & ~3;
+  L.Tk = L.Tp + ((nrel + 3) & ~3);
+  L.SS = L.Tk + (((L.Tk >> 2) & 1) ? 0 : 4);
+  L.lds = ((size_t)dk * 32 + (size_t)2 * dk * L.Tk + (size_t)32 * L.SS + (size_t)32 * 36) * sizeof(float);
+  return L;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Short sequences (T <= 128: a sentence's phonemes): the WHOLE windowed attention of one head for a strip of 32
 // queries in ONE launch -- scores (+ the banded relative-key term), mask, softmax, P.V (+ the banded relative-value
@@ -457,23 +471,23 @@ int64_t attn_score_elems(int window, int dk, int B, int n_heads, int T) {
 // encoder layer at B = 1, T = 64, each launch a few microseconds of work on a handful of CUs,
 // profiles/r02_b1_anatomy.txt).  k, v and the query strip are staged in LDS once; lanes run along the query index,
 // so q / P reads are conflict-free and k / v / E reads are broadcasts.  Exact f32, the scalar kernels' formulas.
-// grid (ceil(T/32), B*H), 256 threads = 32 queries x 8 groups; LDS = ((2 T + 32) dk + (T + 16) 33 + 2 (2w+1) dk) floats
+// grid (ceil(T/32), B*H), 1024 threads = 32 queries x 32 groups of four columns; LDS per attn_small_layout().
+// (256-thread blocks with 4-byte LDS reads took 48 us a launch at T = 64: 2000 dependent LDS reads per thread and
+// one wave per SIMD to hide them, profiles/r03_b1_anatomy.txt)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_small_kernel(
+__global__ __launch_bounds__(1024) void attn_small_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ mask, const float* __restrict__ emb_rel_k, const float* __restrict__ emb_rel_v,
     int window, int n_heads, int dk, int T, float qdiv, int64_t qbs, float* __restrict__ out) {
   extern __shared__ float sm_a[];
-  constexpr int QT = 32, NG = 8;
-  const int nrel = 2 * window + 1;
-  float* qs = sm_a;                       // [dk][QT]   q / sqrt(dk)
-  float* kk = qs + (size_t)dk * QT;       // [dk][T]
-  float* vv = kk + (size_t)dk * T;        // [dk][T]
-  float* S = vv + (size_t)dk * T;         // [T][QT + 1]   scores, then P
-  float* red_m = S + (size_t)T * (QT + 1);  // [NG][QT + 1]
-  float* red_s = red_m + NG * (QT + 1);
-  float* ek = red_s + NG * (QT + 1);      // [nrel][dk]
-  float* ev = ek + (size_t)nrel * dk;     // [nrel][dk]
+  constexpr int QT = 32, NG = 32, NTH = QT * NG, RS = NG + 4;
+  const AttnSmallLayout L = attn_small_layout(T, dk, window);
+  const int nrel = 2 * window + 1, Tp = L.Tp, Tk = L.Tk, SS = L.SS;
+  float* qs = sm_a;                        // [dk][QT]   q / sqrt(dk)
+  float* kk = qs + (size_t)dk * QT;        // [dk][Tk]   keys, then E_k as columns Tp.. (the relative-key logits are
+  float* vv = kk + (size_t)dk * Tk;        // [dk][Tk]   nrel more dot products of the same loop); values, then E_v
+  float* S = vv + (size_t)dk * Tk;         // [QT][SS]   rel logits, then P with the band of P in columns Tp..
+  float* red = S + (size_t)QT * SS;        // [QT][RS]   per-group max, then per-group sum
   const int tid = threadIdx.x;
   const int il = tid & (QT - 1), grp = tid >> 5;
   const int i0 = blockIdx.x * QT, i = i0 + il;
@@ -482,144 +496,167 @@ __global__ __launch_bounds__(256) void attn_small_kernel(
   const float* kb = k + (int64_t)b * qbs + (int64_t)h * dk * T;
   const float* vb = v + (int64_t)b * qbs + (int64_t)h * dk * T;
   const float* mb = mask + (int64_t)b * T;
-  // ---- stage: 16-byte loads, eight in flight per thread (a plain element loop waits for every load before the
-  // next: 24 memory round trips per block where one is needed) -----------------------------------------------
+  // ---- stage (all loads of a thread issued before its first LDS store: one memory round trip) --------------------
   {
-    const int n = dk * T;
-    const bool vec = ((n & 3) == 0) && (((uintptr_t)kb | (uintptr_t)vb) & 15) == 0;
+    const bool vec = ((T & 3) == 0) && (((uintptr_t)kb | (uintptr_t)vb) & 15) == 0;
     if (vec) {
       const float4* k4 = reinterpret_cast<const float4*>(kb);
       const float4* v4 = reinterpret_cast<const float4*>(vb);
-      float4* kd = reinterpret_cast<float4*>(kk);
-      float4* vd = reinterpret_cast<float4*>(vv);
-      const int n4 = n >> 2;
-      for (int e0 = tid; e0 < n4; e0 += 256 * 4) {
-        float4 a[4], c[4];
+      const int tq = T >> 2, n4 = dk * tq;
+      for (int e0 = tid; e0 < n4; e0 += NTH * 2) {
+        float4 a[2], c[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = min(e0 + 256 * u, n4 - 1);  // clamped: unconditional loads
+        for (int u = 0; u < 2; ++u) {
+          const int e = min(e0 + NTH * u, n4 - 1);  // clamped: unconditional loads
           a[u] = k4[e];
           c[u] = v4[e];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = e0 + 256 * u;
+        for (int u = 0; u < 2; ++u) {
+          const int e = e0 + NTH * u;
           if (e < n4) {
-            kd[e] = a[u];
-            vd[e] = c[u];
+            const int d = e / tq, jq = e - d * tq;
+            *reinterpret_cast<float4*>(kk + (size_t)d * Tk + 4 * jq) = a[u];
+            *reinterpret_cast<float4*>(vv + (size_t)d * Tk + 4 * jq) = c[u];
           }
         }
       }
     } else {
-      for (int e = tid; e < n; e += 256) {
-        kk[e] = kb[e];
-        vv[e] = vb[e];
+      for (int e = tid; e < dk * T; e += NTH) {
+        const int d = e / T, j = e - d * T;
+        kk[(size_t)d * Tk + j] = kb[e];
+        vv[(size_t)d * Tk + j] = vb[e];
       }
     }
-  }
-  {
-    float qv[12];  // dk * QT / 256 <= 12 for dk <= 96; larger heads loop
-    for (int e0 = tid; e0 < dk * QT; e0 += 256 * 12) {
-#pragma unroll
-      for (int u = 0; u < 12; ++u) {
-        const int e = e0 + 256 * u;
-        const int d = min(e / QT, dk - 1), c = e % QT;
-        qv[u] = qb[(int64_t)d * T + min(i0 + c, T - 1)];
-      }
-#pragma unroll
-      for (int u = 0; u < 12; ++u) {
-        const int e = e0 + 256 * u;
-        if (e < dk * QT) qs[e] = (i0 + e % QT < T) ? qv[u] / qdiv : 0.f;  // query / math.sqrt(k_channels)
-      }
+    // columns T..Tk-1: zero padding up to Tp, E_k / E_v (transposed) behind it, zero again up to Tk
+    const int nx = Tk - T;
+    for (int e = tid; e < dk * nx; e += NTH) {
+      const int d = e / nx, c = T + (e - d * nx), r = c - Tp;
+      const bool isrel = r >= 0 && r < nrel;
+      kk[(size_t)d * Tk + c] = isrel ? emb_rel_k[(size_t)r * dk + d] : 0.f;
+      vv[(size_t)d * Tk + c] = isrel ? emb_rel_v[(size_t)r * dk + d] : 0.f;
     }
-  }
-  for (int e = tid; e < nrel * dk; e += 256) {
-    ek[e] = emb_rel_k[e];
-    ev[e] = emb_rel_v[e];
+    for (int e = tid; e < dk * QT; e += NTH) {
+      const int d = e / QT, ii = i0 + (e & (QT - 1));
+      qs[e] = ii < T ? qb[(int64_t)d * T + ii] / qdiv : 0.f;
+    }
   }
   __syncthreads();
-  // ---- scores S[j][il]: four keys at a time (four independent accumulator chains per thread: the loop is bound by
-  // LDS latency, not by arithmetic) -----------------------------------------------------------------------------
-  const float mi = i < T ? mb[i] : 0.f;
-  for (int jb = grp; jb < T; jb += 4 * NG) {
-    int jj[4];
+  // ---- scores: a thread owns four consecutive columns (one 16-byte LDS read feeds four chains).  Key columns stay
+  // in registers for the softmax below; relative-key columns go to S for the threads whose band they fall in ------
+  float xq[4] = {0.f, 0.f, 0.f, 0.f};
+  const int nkq = Tp >> 2;  // <= NG: every key quad is some group's first unit
+  for (int unit = grp; unit < (Tk >> 2); unit += NG) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < 4; ++u) jj[u] = min(jb + u * NG, T - 1);  // clamped: a tail entry recomputes the last key
-#pragma unroll 4
+    const float* kr = kk + 4 * unit;
+#pragma unroll 8
     for (int d = 0; d < dk; ++d) {
       const float qv = qs[d * QT + il];
-      const float* kr = kk + d * T;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] += qv * kr[jj[u]];
+      const float4 k4 = *reinterpret_cast<const float4*>(kr + (size_t)d * Tk);
+      acc[0] += qv * k4.x;
+      acc[1] += qv * k4.y;
+      acc[2] += qv * k4.z;
+      acc[3] += qv * k4.w;
     }
+    if (unit < nkq) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xq[u] = acc[u];
+    } else {
+      *reinterpret_cast<float4*>(S + (size_t)il * SS + 4 * unit) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+  }
+  __syncthreads();
+  // ---- softmax over the keys: exp(x - max) / sum, groups merged through LDS ------------------------------
+  const bool own = grp < nkq;
+  const float mi = i < T ? mb[i] : 0.f;
+  float mx = -INFINITY;
+  if (own) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int j = jb + u * NG;
-      if (j >= T) continue;
-      float a = acc[u];
-      const int r = j - i;
-      if (r >= -window && r <= window) {
-        const float* er = ek + (size_t)(r + window) * dk;
-        float rel = 0.f;
-#pragma unroll 4
-        for (int d = 0; d < dk; ++d) rel += qs[d * QT + il] * er[d];
-        a += rel;
+      const int j = 4 * grp + u;
+      float a = xq[u];
+      if (j < T) {
+        const int r = j - i;
+        if (r >= -window && r <= window) a += S[(size_t)il * SS + Tp + r + window];
+        if (mi * mb[j] == 0.f) a = -1e4f;  // masked_fill(mask == 0, -1e4)
+      } else {
+        a = -INFINITY;
       }
-      if (mi * mb[j] == 0.f) a = -1e4f;  // masked_fill(mask == 0, -1e4)
-      S[j * (QT + 1) + il] = a;
+      xq[u] = a;
+      mx = fmaxf(mx, a);
     }
   }
+  red[il * RS + grp] = mx;
   __syncthreads();
-  // ---- softmax over j (online max / sum per group, merged through LDS) ---------------------------------
-  {
-    float mx = -INFINITY, sum = 0.f;
-    for (int j = grp; j < T; j += NG) {
-      const float x = S[j * (QT + 1) + il];
-      if (x > mx) {
-        sum = sum * expf(mx - x);
-        mx = x;
-      }
-      sum += expf(x - mx);
-    }
-    red_m[grp * (QT + 1) + il] = mx;
-    red_s[grp * (QT + 1) + il] = sum;
-    __syncthreads();
-    float M = -INFINITY;
+  float M = -INFINITY;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) M = fmaxf(M, red_m[g * (QT + 1) + il]);
-    float Z = 0.f;
+  for (int g = 0; g < NG; g += 4) {
+    const float4 m4 = *reinterpret_cast<const float4*>(red + il * RS + g);
+    M = fmaxf(fmaxf(fmaxf(M, m4.x), fmaxf(m4.y, m4.z)), m4.w);
+  }
+  float sum = 0.f;
+  if (own) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const float mg = red_m[g * (QT + 1) + il];
-      if (mg > -INFINITY) Z += red_s[g * (QT + 1) + il] * expf(mg - M);
+    for (int u = 0; u < 4; ++u) {
+      xq[u] = expf(xq[u] - M);  // exp(-inf) = 0 for the padding columns
+      sum += xq[u];
     }
-    for (int j = grp; j < T; j += NG) S[j * (QT + 1) + il] = expf(S[j * (QT + 1) + il] - M) / Z;
+  }
+  __syncthreads();  // every thread has read the maxima
+  red[il * RS + grp] = sum;
+  __syncthreads();
+  float Z = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; g += 4) {
+    const float4 s4 = *reinterpret_cast<const float4*>(red + il * RS + g);
+    Z += (s4.x + s4.y) + (s4.z + s4.w);
+  }
+  if (own)
+    *reinterpret_cast<float4*>(S + (size_t)il * SS + 4 * grp) =
+        make_float4(xq[0] / Z, xq[1] / Z, xq[2] / Z, xq[3] / Z);
+  __syncthreads();
+  // band of P behind the keys: column Tp + r + w holds P[i + r] (zero outside the sequence), so the relative-value
+  // term below is the same loop as P.V over the E_v columns
+  for (int c = grp; c < Tk - Tp; c += NG) {
+    const int j = i + c - window;
+    S[(size_t)il * SS + Tp + c] = (c < nrel && j >= 0 && j < T) ? S[(size_t)il * SS + j] : 0.f;
   }
   __syncthreads();
-  // ---- out[d][i] = sum_j P[j][i] v[d][j] + sum_r P[i+r][i] E_v[r+w][d], four channels at a time ------------------
+  // ---- out[d][i] = sum_j P[j][i] v[d][j] + sum_r P[i+r][i] E_v[r+w][d], four channels and four keys a step ----------
   if (i < T) {
+    const float* pr = S + (size_t)il * SS;
     for (int db = grp; db < dk; db += 4 * NG) {
-      int dd[4];
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* vr[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) dd[u] = min(db + u * NG, dk - 1);
-#pragma unroll 4
-      for (int j = 0; j < T; ++j) {
-        const float pv = S[j * (QT + 1) + il];
+      for (int u = 0; u < 4; ++u) vr[u] = vv + (size_t)min(db + u * NG, dk - 1) * Tk;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f}, rel[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int j = 0; j < Tp; j += 4) {
+        const float4 p4 = *reinterpret_cast<const float4*>(pr + j);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] += pv * vv[dd[u] * T + j];
+        for (int u = 0; u < 4; ++u) {
+          const float4 v4 = *reinterpret_cast<const float4*>(vr[u] + j);
+          acc[u] += p4.x * v4.x;
+          acc[u] += p4.y * v4.y;
+          acc[u] += p4.z * v4.z;
+          acc[u] += p4.w * v4.w;
+        }
+      }
+      for (int j = Tp; j < Tk; j += 4) {
+        const float4 p4 = *reinterpret_cast<const float4*>(pr + j);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float4 v4 = *reinterpret_cast<const float4*>(vr[u] + j);
+          rel[u] += p4.x * v4.x;
+          rel[u] += p4.y * v4.y;
+          rel[u] += p4.z * v4.z;
+          rel[u] += p4.w * v4.w;
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int d = db + u * NG;
-        if (d >= dk) continue;
-        float rel = 0.f;
-        for (int r = -window; r <= window; ++r) {
-          const int j = i + r;
-          if (j >= 0 && j < T) rel += S[j * (QT + 1) + il] * ev[(size_t)(r + window) * dk + d];
-        }
-        out[((int64_t)bh * dk + d) * T + i] = acc[u] + rel;
+        if (d < dk) out[((int64_t)bh * dk + d) * T + i] = acc[u] + rel[u];
       }
     }
   }
@@ -642,15 +679,15 @@ int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t 
   if (B * T == 0) return WETTS_OK;
   WETTS_REQUIRE(T <= 65535, "attention length %d too large", T);
   const float qdiv = (float)sqrt((double)dk);
-  if (window >= 0 && T <= attn_small_max_t()) {
-    const size_t lds = ((size_t)(2 * T + 32) * dk + (size_t)(T + 16) * 33 + (size_t)2 * (2 * window + 1) * dk) * sizeof(float);
+  if (window >= 0 && T <= min(attn_small_max_t(), 128)) {  // 32 groups x 4 keys
+    const size_t lds = attn_small_layout(T, dk, window).lds;
     if (lds <= 150 * 1024) {
       static bool attr_done = false;
       if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)attn_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
       }
-      hipLaunchKernelGGL(attn_small_kernel, dim3(cdiv(T, 32), B * n_heads), dim3(256), lds, s, q, k, v, mask,
+      hipLaunchKernelGGL(attn_small_kernel, dim3(cdiv(T, 32), B * n_heads), dim3(1024), lds, s, q, k, v, mask,
                          emb_rel_k, emb_rel_v, window, n_heads, dk, T, qdiv, qbs, out);
       WETTS_LAUNCH_CHECK();
       return WETTS_OK;

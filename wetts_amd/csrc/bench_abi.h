@@ -36,4 +36,8 @@ int32_t wetts_bench_mfma_loop2(int32_t cfg, int32_t lds_kb, int32_t groups, int3
                                double* tflops, double* ms);
 int32_t wetts_bench_mfma_valu(int32_t mode, int32_t nv, int32_t iters, double* tflops_mfma,
                               double* tflops_valu, double* ms);
+// The bf16 loop taken apart: cfg = MB*10000 + NB*1000 + BM*100 + AM*10 + SYNC (mfma16_loop_kernel); also returns the
+// clock the chip sustained (s_memtime cycles per 100 MHz tick).
+int32_t wetts_bench_mfma16_loop(int32_t cfg, int32_t blocks_per_cu, int32_t rs, int32_t groups, int32_t iters,
+                                double* tflops, double* ms, double* mhz);
 }

@@ -11,6 +11,7 @@
 #include "bench_abi.h"
 #include "common.h"
 #include "conv_bf16.h"
+#include "conv16_dev.h"
 #include "resblock32.h"
 #include "kernels.h"
 
@@ -644,9 +645,190 @@ __global__ __launch_bounds__(256) void mfma_loop2_kernel(const float4* __restric
       for (int r = 0; r < 16; ++r) s += acc[i][j][r];
   if (s == 12345.678f) out[tid] = s;
 }
+
+// The 16-bit conv inner loop taken apart (round 3): v_mfma_f32_32x32x16_bf16 with MB x NB accumulators per wave,
+// KS = 4 k-steps per (chunk, tap) group.  BM: 0 B fragments in registers, 1 ds_read_b128 per fragment from a
+// [column][rs bytes] image (the pair kernel's addresses: tap shift in rows, chunk / k-step in bytes), pipelined one
+// k-step ahead.  AM: 0 A in registers, 1 one global_load_dwordx4 per (m-block, k-step) from an L2-resident packed
+// stream, ring of two groups (the pair kernel's NR = 2).  SYNC: a block barrier every 22 groups (one conv of a
+// C = 128, k = 11 pair).  Operands are pseudo-random bf16 in +-[1, 2) (toggle rate of real data; the accumulators
+// random-walk).  clk[2 bid], clk[2 bid + 1]: shader cycles (s_memtime) and 100 MHz ticks of the block's loop.
+template <int MB, int NB, int BM, int AM, int SYNC>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(MB * NB >= 8 ? 2 : (MB * NB >= 4 ? 3 : 4), MB * NB >= 8 ? 2 : (MB * NB >= 4 ? 3 : 4))))
+void mfma16_loop_kernel(const uint4* __restrict__ A, float* out,
+                                                          unsigned long long* clk, int groups, int iters, int rs,
+                                                          int lds_words) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+  constexpr int KS = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned* smw = reinterpret_cast<unsigned*>(smb);
+  for (int i = tid; i < lds_words; i += 256) {
+    unsigned h = (unsigned)i * 2654435761u + 77u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    smw[i] = 0x3f803f80u | (h & 0x807f807fu);
+  }
+  __syncthreads();
+  const int half = lane >> 5, l31 = lane & 31;
+  const unsigned char* bcol = smb + (size_t)((wave & 1) * (32 * NB) + l31) * rs + half * 16;
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const uint4* ab = A + lane;
+  auto rnd4 = [&](unsigned k) {
+    unsigned h = (unsigned)(tid * 131 + k) * 2654435761u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const unsigned w = 0x3f803f80u | (h & 0x807f807fu);
+    return make_uint4(w, w ^ 0x00110022u, w ^ 0x80000033u, w ^ 0x00448000u);
+  };
+  auto loadA = [&](int g, int i, int s) -> uint4 {
+    if (AM == 1) return ab[((int64_t)(g * KS + s) * MB + i) * 64];
+    return rnd4(i * KS + s);
+  };
+  unsigned long long t0 = 0, w0 = 0;
+  if (tid == 0) { t0 = __builtin_amdgcn_s_memtime(); w0 = wall_clock64(); }
+  for (int it = 0; it < iters; ++it) {
+    uint4 aa[2][MB][KS];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) { aa[0][i][s2] = loadA(0, i, s2); aa[1][i][s2] = aa[0][i][s2]; }
+    uint4 bq[2][NB];
+    auto bpos = [&](int g) { return bcol + (size_t)(g % 3) * rs + ((g / 3) & 1) * 128; };
+    auto b_load = [&](uint4 (&dst)[NB], const unsigned char* bb, int s2) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (BM) dst[j] = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * rs + s2 * 32);
+        else dst[j] = rnd4(100 + j);
+      }
+    };
+    b_load(bq[0], bpos(0), 0);
+    auto group = [&](int par, int g) {
+      const int gn = g + 1 < groups ? g + 1 : groups - 1;  // clamped: unconditional prefetch
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) aa[par ^ 1][i][s2] = loadA(gn, i, s2);
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* cur = bpos(g);
+      const unsigned char* nxt = bpos(gn);
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        if (BM) {
+          if (s2 + 1 < KS) b_load(bq[(s2 + 1) & 1], cur, s2 + 1);
+          else b_load(bq[(s2 + 1) & 1], nxt, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int i = 0; i < MB; ++i)
+            acc[i][j] = mfma16<false>(aa[par][i][s2], bq[BM ? (s2 & 1) : 0][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    for (int g = 0; g < groups; g += 2) {
+      group(0, g);
+      group(1, g + 1);
+      if (SYNC && (g % 22) == 20) __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+    clk[2 * blockIdx.x + 1] = wall_clock64() - w0;
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+  if (sum == 12345.678f) out[tid] = sum;
+}
+__global__ void fill_bf16_words_kernel(unsigned* p, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned h = (unsigned)i * 2654435761u + 5u;
+  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+  p[i] = 0x3f803f80u | (h & 0x807f807fu);
+}
 }  // namespace wetts
 
 extern "C" {
+
+// cfg = MB*10000 + NB*1000 + BM*100 + AM*10 + SYNC (see mfma16_loop_kernel).  blocks_per_cu resident 4-wave blocks
+// (LDS-limited); rs = LDS row stride in bytes (272: C = 128, 144: C = 64).
+int32_t wetts_bench_mfma16_loop(int32_t cfg, int32_t blocks_per_cu, int32_t rs, int32_t groups, int32_t iters,
+                                double* tflops, double* ms_out, double* mhz) {
+  WETTS_REQUIRE(tflops && ms_out && mhz && groups > 0 && (groups & 1) == 0 && iters > 0, "bad argument");
+  WETTS_REQUIRE(blocks_per_cu >= 1 && blocks_per_cu <= 8 && (rs == 272 || rs == 144), "bad argument");
+  const int MBv = cfg / 10000, NBv = (cfg / 1000) % 10;
+  uint4* A = nullptr;
+  float* out = nullptr;
+  unsigned long long* clk = nullptr;
+  const size_t abytes = (size_t)(groups + 2) * 4 * MBv * 64 * sizeof(uint4);
+  WETTS_HIP_CHECK(hipMalloc((void**)&A, abytes));
+  hipLaunchKernelGGL(fill_bf16_words_kernel, dim3((unsigned)((abytes / 4 + 255) / 256)), dim3(256), 0, 0,
+                     reinterpret_cast<unsigned*>(A), (int64_t)(abytes / 4));
+  WETTS_HIP_CHECK(hipMalloc((void**)&out, 4096));
+  const int grid = 256 * blocks_per_cu;
+  WETTS_HIP_CHECK(hipMalloc((void**)&clk, (size_t)grid * 2 * sizeof(unsigned long long)));
+  const size_t need = (size_t)(2 * 32 * NBv + 4) * rs + 256;
+  size_t lds = (size_t)(160 * 1024 / blocks_per_cu) & ~(size_t)1023;   // exactly blocks_per_cu fit
+  if (blocks_per_cu < 8) {
+    const size_t lo = (size_t)(160 * 1024 / (blocks_per_cu + 1)) + 1024; // ... and not one more
+    if (lds < lo) lds = lo;
+  }
+  WETTS_REQUIRE(lds >= need, "tile of %zu bytes does not fit %d blocks per CU", need, blocks_per_cu);
+  bool ok = true;
+#define WETTS_L16(MB_, NB_, BM_, AM_, SY_)                                                                  \
+  if (cfg == MB_ * 10000 + NB_ * 1000 + BM_ * 100 + AM_ * 10 + SY_) {                                       \
+    (void)hipFuncSetAttribute((const void*)mfma16_loop_kernel<MB_, NB_, BM_, AM_, SY_>,                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                       \
+    hipLaunchKernelGGL((mfma16_loop_kernel<MB_, NB_, BM_, AM_, SY_>), dim3(grid), dim3(256), lds, 0, A, out, \
+                       clk, groups, iters, rs, (int)(need / 4));                                             \
+    return;                                                                                                  \
+  }
+  auto launch = [&]() {
+    WETTS_L16(1, 4, 0, 0, 0) WETTS_L16(1, 4, 1, 0, 0) WETTS_L16(1, 4, 0, 1, 0) WETTS_L16(1, 4, 1, 1, 0)
+    WETTS_L16(1, 4, 1, 1, 1) WETTS_L16(2, 4, 0, 0, 0) WETTS_L16(2, 4, 1, 0, 0) WETTS_L16(2, 4, 1, 1, 0)
+    WETTS_L16(2, 4, 1, 1, 1) WETTS_L16(2, 2, 0, 0, 0) WETTS_L16(2, 2, 1, 0, 0) WETTS_L16(2, 2, 1, 1, 0)
+    WETTS_L16(2, 2, 1, 1, 1) WETTS_L16(1, 2, 1, 1, 0) WETTS_L16(1, 8, 1, 1, 0) WETTS_L16(4, 1, 1, 1, 0)
+    WETTS_L16(2, 3, 1, 1, 0) WETTS_L16(4, 2, 1, 1, 0)
+    ok = false;
+  };
+  launch();
+  WETTS_REQUIRE(ok, "unknown mfma16 loop configuration %d", cfg);
+  WETTS_LAUNCH_CHECK();
+  WETTS_HIP_CHECK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, 0);
+  launch();
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h((size_t)grid * 2);
+  WETTS_HIP_CHECK(hipMemcpy(h.data(), clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  double cyc = 0, wall = 0;
+  for (int b = 0; b < grid; ++b) { cyc += (double)h[2 * b]; wall += (double)h[2 * b + 1]; }
+  *mhz = wall > 0 ? cyc / wall * 100.0 : 0.0;
+  *tflops = (double)grid * 4 * (double)iters * groups * 4 * MBv * NBv * 32768.0 / (ms * 1e-3) / 1e12;
+  *ms_out = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(A);
+  (void)hipFree(out);
+  (void)hipFree(clk);
+  return WETTS_OK;
+}
 
 // cfg = MB*1000 + NB*100 + BM*10 + AM
 int32_t wetts_bench_mfma_loop2(int32_t cfg, int32_t lds_kb, int32_t groups, int32_t iters,

@@ -74,6 +74,29 @@ bool resblock2_chain16_supported(const PackedConvB& c1, const PackedConvB& c2, i
 int32_t launch_resblock2_chain16(const PackedConvB& c1, const PackedConvB& c2, ResPairParams p,
                                  hipStream_t stream);
 
+// a whole ResBlock1 (up to three (c1, c2) pairs) in one launch at C <= 64 (resblock1_chain16.hip)
+constexpr int RESCHAIN16_MAX_PAIRS = 3;
+constexpr int RESCHAIN16_MAX_HALO = 25;  // widest single-conv halo (k-1)/2 * dilation the tile margins are sized for
+struct ResChain16Params {
+  const unsigned short* x;  // [B][T][C] channel-last
+  unsigned short* out;      // [B][T][C] (never aliases x)
+  const unsigned short *wpk1[RESCHAIN16_MAX_PAIRS], *wpk2[RESCHAIN16_MAX_PAIRS];
+  const float *bias1[RESCHAIN16_MAX_PAIRS], *bias2[RESCHAIN16_MAX_PAIRS];
+  int dil[RESCHAIN16_MAX_PAIRS];
+  int npairs, ktaps;
+  int halo, margin;  // sum of the convs' halos (valid columns shrink by it on each side); widest single halo
+  int T, B;
+  int accum;         // add the previous contents of out (running MRF sum)
+  float out_div;
+  float slope;
+  int ntiles, nblocks;
+};
+// valid output columns per block, or 0 when the kernel does not take the chain (shape, or 2 * halo above
+// max_waste_pct of the tile)
+int resblock1_chain16_nto(const PackedConvB* c1, const PackedConvB* c2, int npairs, int max_waste_pct);
+int32_t launch_resblock1_chain16(const PackedConvB* c1, const PackedConvB* c2, int npairs, ResChain16Params p,
+                                 hipStream_t stream);
+
 int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
                               int dil, int pad, int transposed, int up, int f16, hipStream_t stream,
                               PackedConvB* out, int gate_h = 0);

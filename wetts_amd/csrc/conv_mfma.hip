@@ -732,6 +732,7 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
     case 3: return launch_cfg<1, 4, 2, 2>(p, stream);
     case 4: return launch_cfg<1, 2, 2, 2>(p, stream);
     case 5: return launch_cfg<1, 1, 2, 2>(p, stream);
+    case 6: return launch_cfg<1, 4, 4, 1>(p, stream);
     default: break;
   }
   // ... but a grid of fewer than 1.5 big tiles per CU leaves CUs idle or unevenly loaded: the flow /

@@ -413,6 +413,9 @@ struct wetts_model {
   // C = 64: k = 3), single pairs at C = 32 (every k) and for k <= chain_pair_kmax at any width
   int small_max_tiles = 256;      // conv launches of at most this many 64x64 tiles use conv_small_kernel (0: off)
   int chain_whole_waste_pct = 15; // WETTS_CHAIN_WHOLE_PCT (0 disables whole-ResBlock launches)
+  // 16-bit decoder: whole ResBlock1 per launch at C <= 64 when 2 * halo <= this % of the tile.  Bit-identical to the
+  // pair launches and measured 1 % SLOWER on the MRF class at 10-15 %, 6 % at 30 % (profiles/r03_chain16_ab.txt): off
+  int chain16_waste_pct = 0;
   int chain_whole_maxc = 64;      // WETTS_CHAIN_WHOLE_MAXC
   int chain_pair_maxc = 32;       // WETTS_CHAIN_PAIR_MAXC: widest stage whose pairs all run on the chain kernel
   int chain_pair_kmax = 3;        // WETTS_CHAIN_PAIR_KMAX: ... and pairs with at most this many taps at any width
@@ -436,6 +439,9 @@ struct wetts_model {
   // the model's own standard-normal stream (wetts_infer with eps == NULL)
   mutable uint64_t rng_seed = 0, rng_offset = 0;
   int mrf_streams = 1;
+  // 16-bit decoder, > 1: the k = 3 / 7 / 11 chains of a stage on their own streams (run_hifigan_bf16).  Measured a
+  // wash -- the MRF class 2.7 % faster, the step not (profiles/r03_mrf_streams16.txt) -- so off by default
+  int mrf_streams16 = 1;
   int small_fork = 1;   // WETTS_TUNE small_fork: the chains of a small (streaming-window) stage on their own streams
   int conv_groups = 1;  // WETTS_TUNE conv_groups: independent single convs of a ResBlock1 step in one launch (0: one each)
   hipStream_t aux_stream[WETTS_MAX_RB_KERNELS] = {};
@@ -873,11 +879,11 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     // WETTS_TUNE="name=value,name=value", names as in the table below
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {
-        {"mrf_streams", &m->mrf_streams},         {"fuse32_lds", &m->fuse32_lds},
+        {"mrf_streams", &m->mrf_streams},         {"mrf_streams16", &m->mrf_streams16},         {"fuse32_lds", &m->fuse32_lds},
         {"fuse32_kmax128", &m->fuse32_kmax128},   {"fuse32_maxc", &m->fuse32_maxc},
         {"fuse32_kmax", &m->fuse32_kmax},         {"fuse32_kwide", &m->fuse32_kwide},
         {"fuse2_maxc", &m->fuse2_maxc},           {"fuse2_waste_pct", &m->fuse2_waste_pct},
-        {"fuse_min_blocks", &m->fuse_min_blocks}, {"chain_whole_pct", &m->chain_whole_waste_pct},
+        {"fuse_min_blocks", &m->fuse_min_blocks}, {"chain16_pct", &m->chain16_waste_pct}, {"chain_whole_pct", &m->chain_whole_waste_pct},
         {"chain_whole_maxc", &m->chain_whole_maxc}, {"chain_pair_maxc", &m->chain_pair_maxc},
         {"chain_pair_kmax", &m->chain_pair_kmax}, {"small_max_tiles", &m->small_max_tiles},
         {"conv_groups", &m->conv_groups},       {"small_fork", &m->small_fork},
@@ -2102,9 +2108,17 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
   unsigned short* bx = ws.take<unsigned short>(mx);
   unsigned short* bt = ws.take<unsigned short>(mx);
   unsigned short* bs = ws.take<unsigned short>(mx);
-  unsigned short* fa = ws.take<unsigned short>(mx);
-  unsigned short* fb = ws.take<unsigned short>(mx);
-  unsigned short* ft = ws.take<unsigned short>(mx);
+  const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
+  // ResBlock1 chains on their own streams: each needs its own ping-pong pair (and c1 output, for the unfused convs)
+  const bool fork_ok = c->resblock == 1 && m->mrf_streams16 > 1 && nk > 1 && nk <= WETTS_MAX_RB_KERNELS &&
+                       m->aux_stream[nk - 1] != nullptr;
+  unsigned short *fas[WETTS_MAX_RB_KERNELS], *fbs[WETTS_MAX_RB_KERNELS], *fts[WETTS_MAX_RB_KERNELS];
+  for (int j = 0; j < (fork_ok ? nk : 1); ++j) {
+    fas[j] = ws.take<unsigned short>(mx);
+    fbs[j] = ws.take<unsigned short>(mx);
+    fts[j] = ws.take<unsigned short>(mx);
+  }
+  for (int j = 1; j < nk && !fork_ok && j < WETTS_MAX_RB_KERNELS; ++j) { fas[j] = fas[0]; fbs[j] = fbs[0]; fts[j] = fts[0]; }
   float* cond = ws.take<float>((int64_t)B * C0);
   if (!ws.ok) {
     set_error("hifigan(bf16): workspace too small");
@@ -2128,7 +2142,6 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
   }
   int ch = C0, len = L;
   unsigned short* x = bx;
-  const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
   for (int i = 0; i < c->n_upsamples; ++i) {
     const int u = c->upsample_rates[i];
     {
@@ -2144,9 +2157,38 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
       WETTS_HIP_CHECK(hipEventCreate(&lv1));
       WETTS_HIP_CHECK(hipEventRecord(lv0, s));
     }
+    // Fork: the chains of a stage are independent up to their last launch, which adds into the running sum -- those
+    // are ordered chain j-1 -> chain j by events, so the sum is formed in the sequential order (bit-identical).
+    // Three launches in flight fill each other's ramp and tail (2.7 of 3 resident blocks per CU on average for one
+    // pair launch, profiles/r03_pair16_phase_clock.txt).  Launches of a few blocks (streaming windows) fork too.
+    const bool forked = fork_ok;
+    if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_fork, s));
     for (int j = 0; j < nk; ++j) {
       const int n = i * nk + j;
+      hipStream_t sj = (forked && j > 0) ? m->aux_stream[j] : s;
+      if (sj != s) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_fork, 0));
+      unsigned short *fa = fas[j], *fb = fbs[j], *ft = fts[j];
       const unsigned short* rx = bt;
+      // a whole ResBlock1 in one launch (resblock1_chain16.hip): x read once, the MRF sum written once
+      if (c->resblock == 1 && !m->dec_unfused && m->chain16_waste_pct > 0 && nd <= RESCHAIN16_MAX_PAIRS) {
+        const int nto = resblock1_chain16_nto(m->b_c1[n].data(), m->b_c2[n].data(), nd, m->chain16_waste_pct);
+        if (nto > 0 && cdiv(len, nto) * B >= m->fuse_min_blocks) {
+          ResChain16Params cp;
+          memset(&cp, 0, sizeof(cp));
+          cp.x = rx;
+          cp.out = xsum;
+          cp.T = len;
+          cp.B = B;
+          cp.accum = (j > 0) ? 1 : 0;
+          cp.out_div = (j == nk - 1) ? (float)nk : 1.f;  // x = xs / self.num_kernels
+          cp.slope = 0.1f;
+          if (forked && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
+          WETTS_TRY(launch_resblock1_chain16(m->b_c1[n].data(), m->b_c2[n].data(), nd, cp, sj));
+          if (m->mrf_timing) m->mrf_launches += 1;
+          if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_chain[j], sj));
+          continue;
+        }
+      }
       for (int d = 0; d < nd; ++d) {
         const bool last_d = (d == nd - 1);
         unsigned short* outp = last_d ? xsum : ((rx == fa) ? fb : fa);
@@ -2184,13 +2226,15 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           pp.accum = accum;
           pp.out_div = odiv;
           pp.slope = 0.1f;
-          WETTS_TRY(launch_resblock_pair16(m->b_c1[n][d], m->b_c2[n][d], pp, s));
+          if (forked && last_d && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
+          WETTS_TRY(launch_resblock_pair16(m->b_c1[n][d], m->b_c2[n][d], pp, sj));
           if (m->mrf_timing) m->mrf_launches += 1;
         } else if (c->resblock == 1) {
           ConvBParams p1 = convb_io(rx, ch, len, ft, ch, len, B);
           p1.basic = m->dec_unfused;
           p1.tag = 1;
-          WETTS_TRY(launch_conv_bf16(m->b_c1[n][d], p1, s));
+          WETTS_TRY(launch_conv_bf16(m->b_c1[n][d], p1, sj));
+          if (forked && last_d && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
           ConvBParams p2 = convb_io(ft, ch, len, outp, ch, len, B);
           p2.basic = m->dec_unfused;
           p2.tag = 1;
@@ -2198,7 +2242,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           p2.r_bs = (int64_t)ch * len;
           p2.accum = accum;
           p2.out_div = odiv;
-          WETTS_TRY(launch_conv_bf16(m->b_c2[n][d], p2, s));
+          WETTS_TRY(launch_conv_bf16(m->b_c2[n][d], p2, sj));
           if (m->mrf_timing) m->mrf_launches += 2;
         } else {
           ConvBParams p1 = convb_io(rx, ch, len, outp, ch, len, B);
@@ -2212,7 +2256,9 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
         }
         rx = outp;
       }
+      if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_chain[j], sj));
     }
+    if (forked) WETTS_HIP_CHECK(hipStreamWaitEvent(s, m->ev_chain[nk - 1], 0));
     if (m->mrf_timing) {
       WETTS_HIP_CHECK(hipEventRecord(lv1, s));
       m->mrf_events.emplace_back(lv0, lv1);

@@ -86,8 +86,13 @@ void resblock_pair16_kernel(const ResPairParams p) {
 
   const unsigned short* xb = p.x + (int64_t)b * p.T * C;
   // phase timestamps of wave 0 (measurement aid; p.prof is null in production -- one uniform branch per stamp)
+  // (slots 0..7: s_memtime = shader cycles; behind them, per block, the constant 100 MHz counter at entry and exit:
+  // the ratio is the clock the chip actually sustained under this kernel's power draw)
   auto stamp = [&](int k) {
-    if (p.prof && tid == 0) p.prof[(int64_t)bid * 8 + k] = __builtin_amdgcn_s_memtime();
+    if (p.prof && tid == 0) {
+      p.prof[(int64_t)bid * 8 + k] = __builtin_amdgcn_s_memtime();
+      if (k == 0 || k == 7) p.prof[(int64_t)p.nblocks * 8 + (int64_t)bid * 2 + (k == 7)] = wall_clock64();
+    }
   };
   stamp(0);
 
@@ -422,9 +427,9 @@ static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream
   const size_t lds = (size_t)(NTC + 2 * (h1 > h2 ? h1 : h2)) * RS;
   static const bool prof_on = getenv("WETTS_PAIR16_PROF") != nullptr;  // micro-benchmark aid: phase timeline of a block
   static unsigned long long* prof_buf = nullptr;
-  static int prof_left = 3;  // print the first three profiled launches of the process (the last one is warm)
+  static int prof_left = getenv("WETTS_PAIR16_PROF_N") ? atoi(getenv("WETTS_PAIR16_PROF_N")) : 3;  // launches to print (later ones are warm)
   p.prof = nullptr;
-  if (prof_on && prof_left > 0 && nb <= (1 << 20)) {
+  if (prof_on && prof_left > 0 && nb * 10 <= ((int64_t)8 << 20)) {
     if (!prof_buf) WETTS_HIP_CHECK(hipMalloc((void**)&prof_buf, (size_t)(1 << 20) * 8 * sizeof(unsigned long long)));
     p.prof = prof_buf;
   }
@@ -436,19 +441,24 @@ static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream
   if (p.prof) {
     --prof_left;
     WETTS_HIP_CHECK(hipStreamSynchronize(stream));
-    std::vector<unsigned long long> h((size_t)nb * 8);
+    std::vector<unsigned long long> h((size_t)nb * 10);
     WETTS_HIP_CHECK(hipMemcpy(h.data(), prof_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double sum[7] = {0, 0, 0, 0, 0, 0, 0};
-    unsigned long long t_min = ~0ull, t_max = 0;
+    double sum[7] = {0, 0, 0, 0, 0, 0, 0}, cyc = 0, wall = 0;
+    unsigned long long w_min = ~0ull, w_max = 0;
     for (int64_t q = 0; q < nb; ++q) {
       for (int k = 0; k < 7; ++k) sum[k] += (double)(h[q * 8 + k + 1] - h[q * 8 + k]);
-      if (h[q * 8] < t_min) t_min = h[q * 8];
-      if (h[q * 8 + 7] > t_max) t_max = h[q * 8 + 7];
+      const unsigned long long w0 = h[nb * 8 + q * 2], w1 = h[nb * 8 + q * 2 + 1];
+      cyc += (double)(h[q * 8 + 7] - h[q * 8]);
+      wall += (double)(w1 - w0);
+      if (w0 < w_min) w_min = w0;
+      if (w1 > w_max) w_max = w1;
     }
     fprintf(stderr, "[pair16 prof] C=%d k=%d d=%d MB=%d blocks=%lld  s_memtime ticks per block: stage %.0f | barrier %.0f | "
-            "c1 loop %.0f | ft epilogue %.0f | c2 init %.0f | c2 loop %.0f | store %.0f | whole launch %.0f\n",
+            "c1 loop %.0f | ft epilogue %.0f | c2 init %.0f | c2 loop %.0f | store %.0f | block life %.1f us, launch %.1f us, "
+            "%.2f blocks resident per CU on average, sustained clock %.0f MHz\n",
             C, p.ktaps, p.dil, MB, (long long)nb, sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[4] / nb, sum[5] / nb,
-            sum[6] / nb, (double)(t_max - t_min));
+            sum[6] / nb, wall / nb / 100.0, (double)(w_max - w_min) / 100.0, wall / (double)(w_max - w_min) / 256.0,
+            wall > 0 ? cyc / wall * 100.0 : 0.0);
   }
   return WETTS_OK;
 }
