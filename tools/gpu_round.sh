@@ -37,7 +37,9 @@ python bench.py --model vits2_vocos_v1 --steps 10 --warmup 3 --no-cpu-baseline >
 WETTS_TUNE=conv_groups=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_ungrouped.json 2>/dev/null
 python bench.py --stream --model v1 > gpurun_out/stream_v1.json 2>/dev/null
 python bench.py --stream --model vits2_vocos_v1 --stream-cpu > gpurun_out/stream_vits2_vocos.json 2>/dev/null
+python bench.py --stream --model v1 --decoder-dtype bf16 > gpurun_out/stream_v1_bf16.json 2>/dev/null
 python bench.py --mas > gpurun_out/mas.json 2>/dev/null
+(export TMPDIR=/tmp; timeout 300 rocprofv3 --kernel-trace -d /tmp/b1 -o b1 --output-format csv -- python tools/trace_b1.py --reps 5 > gpurun_out/b1_run.txt 2>&1; python tools/trace_b1.py --summarize /tmp/b1 > gpurun_out/b1_summary.txt 2>&1)
 python tools/bench_conv.py 0 > gpurun_out/conv_microbench.txt 2>&1
 WETTS_PAIR=1 WETTS_CONV_FLAGS=16 python tools/bench_conv.py 32,16 > gpurun_out/conv16_fused_pair.txt 2>&1
 for f in gpurun_out/bench_*.json; do echo $f; python -c "

@@ -25,7 +25,8 @@ for a, b in [("prof_stats_baker/r_kernel_stats.csv", "kernel_stats.csv"), ("benc
              ("bench_cfg2_multilingual_bf16.json",) * 2, ("bench_cfg2_multilingual_f32.json",) * 2,
              ("bench_cfg3_aishell3.json",) * 2, ("bench_cfg3_aishell3_padded.json",) * 2,
              ("bench_cfg4_stress48k_f16.json",) * 2,
-             ("bench_gpus2_refused.err",) * 2, ("bench_2rank_dryrun.json",) * 2, ("pytest_gpu.log",) * 2]:
+             ("bench_gpus2_refused.err",) * 2, ("bench_2rank_dryrun.json",) * 2, ("pytest_gpu.log",) * 2,
+             ("b1_summary.txt", "b1_anatomy.txt"), ("stream_v1_bf16.json",) * 2]:
     if os.path.exists(f"{src}/{a}"):
         shutil.copy(f"{src}/{a}", f"profiles/{tag}_{b}")
 
@@ -48,7 +49,7 @@ def is_mrf(k):
         return True
     if "conv_mfma_group_kernel" in k or "resblock_pair32_kernel" in k or "resblock_chain32_kernel" in k:
         return True
-    if "resblock_pair16_kernel" in k or "conv16_mb2_kernel" in k:
+    if "resblock_pair16_kernel" in k or "conv16_mb2_kernel" in k or "resblock1_chain16_kernel" in k:
         return True
     mm = re.search(r"conv_bf16_kernel<\d+, \d+, \d+, \d+, (true|false), \d+, (true|false)", k)
     return bool(mm and mm.group(2) == "true")
