@@ -267,6 +267,34 @@ def test_fused_resblock_pair_bit_identical(dtype, L, cname):
     assert np.array_equal(a, b), f"max |diff| {np.abs(a - b).max()}"
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("name", ["tiny_sdp_b3", "v1_b4x128", "aishell3_b4x128"])
+def test_dds_fused_kernel_matches_the_layerwise_path(name, mode):
+    """dds_fused.hip (a whole DDSConv of the stochastic duration predictor in one launch: 48 launches -> 4 per
+    utterance; mode 1 = the 32-column tiles small launches take by default, mode 2 = the 64-column tiles) against
+    the conv-by-conv path: per column the same arithmetic except the
+    summation order of the 1x1 convs (the small-launch kernel splits K over its waves), so logw agrees to 1e-5 and
+    the durations -- ceil(exp(logw) * length_scale) -- do not move.  Ragged lengths and tile seams (Tx = 128 is 22 tiles
+    of 6 valid columns / 4 of 38, 13-column halos) are in the cases."""
+    case = util.load_case(name)
+    outs = []
+    for fused in (mode, "0"):
+        os.environ["WETTS_TUNE"] = "dds_fused=" + fused
+        try:
+            net, cfg, W = _model(case)
+        finally:
+            del os.environ["WETTS_TUNE"]
+        ns, ls, nsw = [float(v) for v in case["scales"]]
+        net.infer(util.t(case["x"]).cuda(), util.t(case["x_lengths"]).cuda(), sid=util.t(case["sid"]).cuda(),
+                  noise_scale=ns, length_scale=ls, noise_scale_w=nsw, eps_w=util.t(case["eps_w"]).cuda(),
+                  eps_z=util.t(case["eps_z"]).cuda())
+        outs.append((net._last["logw"].cpu().numpy(), net._last["w_ceil"].cpu().numpy()))
+    d = float(np.abs(outs[0][0] - outs[1][0]).max())
+    print(name, "fused vs layerwise logw max |diff|", d)
+    assert np.isfinite(outs[0][0]).all() and d < 1e-5
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("L", [3, 50, 200])
 def test_small_launch_conv_schedule_matches_the_big_tile_kernel(L):
     """conv_small_kernel (32x32 tiles, K split over the block's waves; B = 1 streaming windows and short

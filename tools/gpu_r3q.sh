@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 3, pass Q: a whole DDSConv of the stochastic duration predictor in one launch (dds_fused.hip)
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests -m gpu -q --timeout 900 -rf -k "dds_fused or reference_golden or random_small or ragged or session or native or stream or b16x128 or boundary" 2>&1 | tail -15 > gpurun_out/pytest_gpu_q.log
+tail -6 gpurun_out/pytest_gpu_q.log
+for e in "WETTS_TUNE=dds_fused=0" "WETTS_TUNE=dds_fused=1" "WETTS_TUNE=dds_fused=0" "WETTS_TUNE=dds_fused=1"; do env $e python bench.py --stream --model v1 > gpurun_out/tmp.json 2>/dev/null; python -c "
+import json; d=json.load(open('gpurun_out/tmp.json')); print('stream v1 [$e] enc', round(d['encoder_ms'],3), 'win', round(d['first_window_ms_plain'],3), 'first chunk', round(d['first_chunk_latency_ms_plain'],3), 'graph', round(d['first_chunk_latency_ms_graph'],3), 'total', round(d['stream_total_ms_plain'],2))"; done 2>&1 | tee gpurun_out/dds_fused_ab.txt
+for e in "WETTS_TUNE=dds_fused=0" "WETTS_TUNE=dds_fused=1"; do env $e python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/tmp.json 2>/dev/null; python -c "
+import json; d=json.load(open('gpurun_out/tmp.json')); r=d['roofline']; print('headline [$e] ->', round(d['value']/1e6,2), 'M/s', round(d['ms_per_step'],2), 'ms frac', round(r['frac'],4))"; done 2>&1 | tee -a gpurun_out/dds_fused_ab.txt
+export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace -d /tmp/b1 -o b1 --output-format csv -- python tools/trace_b1.py --reps 5 > gpurun_out/b1_run.txt 2>&1
+python tools/trace_b1.py --summarize /tmp/b1 > gpurun_out/b1_summary.txt 2>&1
+grep "dds\|call 5\|call 6" gpurun_out/b1_summary.txt | head

@@ -18,6 +18,18 @@ int32_t k_layernorm(const float* a, const float* add, const float* gamma, const 
                     hipStream_t s);
 
 // DDSConv depthwise dilated conv on (x*mask)  (duration_predictors.py:49-50)
+// a whole DDSConv (three dwconv / LN / GELU / 1x1 / LN / GELU / residual layers) in one launch (dds_fused.hip)
+struct DdsFusedParams {
+  const float* x;     // [B][C][T]
+  float* out;         // [B][C][T], never aliases x (blocks read their neighbours' columns of x)
+  const float* mask;  // [B][T]
+  const float *sep_w[3], *sep_b[3], *n1g[3], *n1b[3], *n2g[3], *n2b[3];
+  const float* wpk[3];   // the 1x1 convs, conv_mfma's packed layout
+  const float* bias[3];
+  int B, C, T, G;        // G = 2 * (C / 16): groups of eight input channels
+};
+bool dds_fused_supported(int mode, int C, int Cw, int nchunks, int B, int T);
+int32_t k_dds_fused(DdsFusedParams p, hipStream_t s);
 int32_t k_dwconv(const float* x, const float* mask, const float* w, const float* bias, int k,
                  int dil, int B, int C, int T, float* out, hipStream_t s);
 

@@ -442,6 +442,10 @@ struct wetts_model {
   // 16-bit decoder, > 1: the k = 3 / 7 / 11 chains of a stage on their own streams (run_hifigan_bf16).  Measured a
   // wash -- the MRF class 2.7 % faster, the step not (profiles/r03_mrf_streams16.txt) -- so off by default
   int mrf_streams16 = 1;
+  // WETTS_TUNE dds_fused: a DDSConv of the duration predictor in one launch (dds_fused.hip).  1: for small launches
+  // (B * ceil(Tx / 6) <= 128 blocks of 32 columns, 6 of them valid: encoder call 1.70 -> 1.63 ms at B = 1, Tx = 64);
+  // 2: always (64-column tiles; no faster than the 12 launches it replaces, profiles/r03_dds_fused_ab.txt); 0: never
+  int dds_fused = 1;
   int small_fork = 1;   // WETTS_TUNE small_fork: the chains of a small (streaming-window) stage on their own streams
   int conv_groups = 1;  // WETTS_TUNE conv_groups: independent single convs of a ResBlock1 step in one launch (0: one each)
   hipStream_t aux_stream[WETTS_MAX_RB_KERNELS] = {};
@@ -879,7 +883,7 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     // WETTS_TUNE="name=value,name=value", names as in the table below
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {
-        {"mrf_streams", &m->mrf_streams},         {"mrf_streams16", &m->mrf_streams16},         {"fuse32_lds", &m->fuse32_lds},
+        {"dds_fused", &m->dds_fused}, {"mrf_streams", &m->mrf_streams},         {"mrf_streams16", &m->mrf_streams16},         {"fuse32_lds", &m->fuse32_lds},
         {"fuse32_kmax128", &m->fuse32_kmax128},   {"fuse32_maxc", &m->fuse32_maxc},
         {"fuse32_kmax", &m->fuse32_kmax},         {"fuse32_kwide", &m->fuse32_kwide},
         {"fuse2_maxc", &m->fuse2_maxc},           {"fuse2_waste_pct", &m->fuse2_waste_pct},
@@ -1084,9 +1088,29 @@ int32_t wetts_text_encoder(const wetts_model_t* m, const int64_t* x, const int64
 
 // ---------------------------------------------------------------------------------------------
 namespace wetts {
-// DDSConv.forward (duration_predictors.py:45-57); x is updated in place; `x + g` is the caller's.
-static int32_t run_dds(const DDS& d, float* x, const float* mask, int B, int C, int T, float* t1,
-                       float* t2, hipStream_t s) {
+// DDSConv.forward (duration_predictors.py:45-57); `x + g` is the caller's.  *xout = where the result is: x itself
+// (updated in place, layer by layer) or t1 (the one-launch kernel of dds_fused.hip, which cannot write in place).
+static int32_t run_dds(const wetts_model* m, const DDS& d, float* x, const float* mask, int B, int C, int T, float* t1,
+                       float* t2, hipStream_t s, float** xout) {
+  *xout = x;
+  if (m->dds_fused && dds_fused_supported(m->dds_fused, C, d.c1x1[0].M, d.c1x1[0].nchunks, B, T)) {
+    DdsFusedParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x;
+    p.out = t1;
+    p.mask = mask;
+    for (int i = 0; i < 3; ++i) {
+      p.sep_w[i] = d.sep_w[i]; p.sep_b[i] = d.sep_b[i];
+      p.n1g[i] = d.n1g[i]; p.n1b[i] = d.n1b[i];
+      p.n2g[i] = d.n2g[i]; p.n2b[i] = d.n2b[i];
+      p.wpk[i] = d.c1x1[i].wpk; p.bias[i] = d.c1x1[i].bias;
+    }
+    p.B = B; p.C = C; p.T = T;
+    p.G = 2 * d.c1x1[0].nchunks;
+    WETTS_TRY(k_dds_fused(p, s));
+    *xout = t1;
+    return WETTS_OK;
+  }
   int dil = 1;
   for (int i = 0; i < 3; ++i) {
     WETTS_TRY(k_dwconv(x, mask, d.sep_w[i], d.sep_b[i], 3, dil, B, C, T, t1, s));
@@ -1136,9 +1160,10 @@ int32_t wetts_duration_sdp(const wetts_model_t* m, const float* x_enc, const flo
     }
     WETTS_TRY(launch_conv(m->sdp_pre, p, s));
   }
-  WETTS_TRY(run_dds(m->sdp_dds, xd, x_mask, B, H, Tx, t1, t2, s));
+  float* xdo = xd;
+  WETTS_TRY(run_dds(m, m->sdp_dds, xd, x_mask, B, H, Tx, t1, t2, s, &xdo));
   {
-    ConvParams p = conv_io(xd, H, Tx, xg, H, B);  // x = proj(x) * x_mask
+    ConvParams p = conv_io(xdo, H, Tx, xg, H, B);  // x = proj(x) * x_mask
     p.out_mask = x_mask;
     p.out_mask_stride = Tx;
     WETTS_TRY(launch_conv(m->sdp_proj, p, s));
@@ -1153,9 +1178,10 @@ int32_t wetts_duration_sdp(const wetts_model_t* m, const float* x_enc, const flo
     const int ch0 = 0 ^ swapped, ch1 = 1 ^ swapped;
     // h = pre(x0); DDSConv(h, mask, g=x): h = h + g first
     WETTS_TRY(k_convflow_pre(z, ch0, cf.pre_w, cf.pre_b, xg, B, H, Tx, hh, s));
-    WETTS_TRY(run_dds(cf.dds, hh, x_mask, B, H, Tx, t1, t2, s));
+    float* hho = hh;
+    WETTS_TRY(run_dds(m, cf.dds, hh, x_mask, B, H, Tx, t1, t2, s, &hho));
     {
-      ConvParams p = conv_io(hh, H, Tx, hp, 29, B);  // h = proj(h) * x_mask
+      ConvParams p = conv_io(hho, H, Tx, hp, 29, B);  // h = proj(h) * x_mask
       p.out_mask = x_mask;
       p.out_mask_stride = Tx;
       WETTS_TRY(launch_conv(cf.proj, p, s));
