@@ -267,6 +267,30 @@ def test_fused_resblock_pair_bit_identical(dtype, L, cname):
     assert np.array_equal(a, b), f"max |diff| {np.abs(a - b).max()}"
 
 
+@pytest.mark.parametrize("name", ["tiny_sdp_b3", "v1_b2", "v1_b4x128"])
+def test_wn_update_in_the_conv_epilogue_is_bit_identical(name):
+    """The f32 flow's residual / skip update (modules.py:79-86) runs in the epilogue of the res_skip conv
+    (ConvParams.wn_*; conv_small_kernel for short calls, conv_mfma_kernel's generic epilogue for B = 4 x 128) instead
+    of wn_update_kernel: the same additions on the same values, so z and the audio must be EQUAL."""
+    case = util.load_case(name)
+    outs = []
+    for fuse in ("2", "0"):  # 2 = at every size (1, the default, fuses only the small launches)
+        os.environ["WETTS_TUNE"] = "wn_fuse=" + fuse
+        try:
+            net, cfg, W = _model(case)
+        finally:
+            del os.environ["WETTS_TUNE"]
+        ns, ls, nsw = [float(v) for v in case["scales"]]
+        o, _, _, (z, *_r) = net.infer(util.t(case["x"]).cuda(), util.t(case["x_lengths"]).cuda(),
+                                      sid=util.t(case["sid"]).cuda(), noise_scale=ns, length_scale=ls,
+                                      noise_scale_w=nsw, eps_w=util.t(case["eps_w"]).cuda(),
+                                      eps_z=util.t(case["eps_z"]).cuda())
+        outs.append((z.cpu().numpy(), o.cpu().numpy()))
+    assert np.isfinite(outs[0][0]).all()
+    assert np.array_equal(outs[0][0], outs[1][0]), f"z: max |diff| {np.abs(outs[0][0] - outs[1][0]).max()}"
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("name", ["tiny_sdp_b3", "v1_b4x128", "aishell3_b4x128"])
 def test_dds_fused_kernel_matches_the_layerwise_path(name, mode):

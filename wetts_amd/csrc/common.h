@@ -100,6 +100,14 @@ struct ConvParams {
   // geometry of the tensors; blocks whose tile starts behind an utterance's end exit at once.  null = dense.
   const int64_t* lens;
   int len_mul;
+  // WaveNet residual / skip update in the epilogue of the res_skip conv (modules.py:79-86; wn_update_kernel's
+  // arithmetic): rows < wn_H -> h = (h + v) * mask, rows >= wn_H -> skip (+)= v; last layer: every row is skip.
+  // h, skip: contiguous [B][wn_H][Tout].  `out` is not written.  null wn_skip = off.
+  float* wn_h;
+  float* wn_skip;
+  const float* wn_mask;
+  int64_t wn_mask_stride;
+  int wn_H, wn_last, wn_first;
 };
 
 // default-initialised ConvParams for a plain contiguous [B,C,T] -> [B,Cout,T] conv

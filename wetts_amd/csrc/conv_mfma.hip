@@ -514,6 +514,17 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, int bid) {
         float v = acc[i][j][r];
         if (p.bias) v += p.bias[co];
         if (bb) v += bb[co];
+        if (p.wn_skip) {  // WaveNet residual / skip update instead of a store (common.h)
+          const int64_t hb = (int64_t)b * p.wn_H * p.Tout + t;  // (dense row geometry)
+          if (!p.wn_last && row < p.wn_H) {
+            float* hp = p.wn_h + hb + (int64_t)row * p.Tout;
+            *hp = (*hp + v) * p.wn_mask[(int64_t)b * p.wn_mask_stride + t];
+          } else {
+            float* sp = p.wn_skip + hb + (int64_t)(p.wn_last ? row : row - p.wn_H) * p.Tout;
+            *sp = p.wn_first ? v : *sp + v;
+          }
+          continue;
+        }
         if (p.out_act == OUT_RELU) v = v > 0.f ? v : 0.f;
         if (p.out_act == OUT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
         if (omask) v *= omask[t];
@@ -584,7 +595,7 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
   const dim3 grid((unsigned)blocks), blk(256);
   // epilogue specialisation: residual / running sum are folded into the accumulator init
   // whenever there is no output activation or mask, which leaves "acc + bias [/ div]"
-  const bool plain = p.up == 0 && p.out_act == OUT_NONE && p.out_mask == nullptr;
+  const bool plain = p.up == 0 && p.out_act == OUT_NONE && p.out_mask == nullptr && p.wn_skip == nullptr;
   if (p.up > 0 && p.up_shift >= 0 && p.out_act == OUT_NONE && !p.out_mask && !p.res && !p.accum &&
       !p.bias_b && p.out_div == 1.f) {
     if (fast)

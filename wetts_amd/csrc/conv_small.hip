@@ -197,6 +197,17 @@ __global__ __launch_bounds__(64 * KG) void conv_small_kernel(const ConvParams p)
     float v = fin[q];
     if (p.bias) v += p.bias[co];
     if (bb) v += bb[co];
+    if (p.wn_skip) {  // WaveNet residual / skip update instead of a store (common.h)
+      const int64_t hb = (int64_t)b * p.wn_H * p.Tout + t;
+      if (!p.wn_last && row < p.wn_H) {
+        float* hp = p.wn_h + hb + (int64_t)row * p.Tout;
+        *hp = (*hp + v) * p.wn_mask[(int64_t)b * p.wn_mask_stride + t];
+      } else {
+        float* sp = p.wn_skip + hb + (int64_t)(p.wn_last ? row : row - p.wn_H) * p.Tout;
+        *sp = p.wn_first ? v : *sp + v;
+      }
+      continue;
+    }
     if (p.out_act == OUT_RELU) v = v > 0.f ? v : 0.f;
     if (p.out_act == OUT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     if (omask) v *= omask[t];

@@ -446,6 +446,7 @@ struct wetts_model {
   // (B * ceil(Tx / 6) <= 128 blocks of 32 columns, 6 of them valid: encoder call 1.70 -> 1.63 ms at B = 1, Tx = 64);
   // 2: always (64-column tiles; no faster than the 12 launches it replaces, profiles/r03_dds_fused_ab.txt); 0: never
   int dds_fused = 1;
+  int wn_fuse = 1;      // WETTS_TUNE wn_fuse: the f32 flow's residual / skip update in the res_skip conv's epilogue (1: small launches, 2: always, 0: wn_update_kernel)
   int small_fork = 1;   // WETTS_TUNE small_fork: the chains of a small (streaming-window) stage on their own streams
   int conv_groups = 1;  // WETTS_TUNE conv_groups: independent single convs of a ResBlock1 step in one launch (0: one each)
   hipStream_t aux_stream[WETTS_MAX_RB_KERNELS] = {};
@@ -883,7 +884,7 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     // WETTS_TUNE="name=value,name=value", names as in the table below
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {
-        {"dds_fused", &m->dds_fused}, {"mrf_streams", &m->mrf_streams},         {"mrf_streams16", &m->mrf_streams16},         {"fuse32_lds", &m->fuse32_lds},
+        {"dds_fused", &m->dds_fused}, {"wn_fuse", &m->wn_fuse}, {"mrf_streams", &m->mrf_streams},         {"mrf_streams16", &m->mrf_streams16},         {"fuse32_lds", &m->fuse32_lds},
         {"fuse32_kmax128", &m->fuse32_kmax128},   {"fuse32_maxc", &m->fuse32_maxc},
         {"fuse32_kmax", &m->fuse32_kmax},         {"fuse32_kwide", &m->fuse32_kwide},
         {"fuse2_maxc", &m->fuse2_maxc},           {"fuse2_waste_pct", &m->fuse2_waste_pct},
@@ -1499,8 +1500,23 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
       }
       WETTS_TRY(k_gate(xin, B, H, Ty, acts, s));
       const bool last = (i == NL - 1);
-      WETTS_TRY(launch_conv(fw.res_skip[i], conv_io(acts, H, Ty, rs, last ? H : 2 * H, B), s));
-      WETTS_TRY(k_wn_update(rs, h, skip, y_mask, last ? 1 : 0, i == 0 ? 1 : 0, B, H, Ty, s));
+      ConvParams p2 = conv_io(acts, H, Ty, rs, last ? H : 2 * H, B);
+      // residual / skip update in the conv's epilogue (rs never exists, one launch less per layer) where launches are
+      // the cost: the calls the small-launch conv kernel takes.  Big batches keep the specialised conv epilogue and
+      // the separate update -- the generic epilogue costs them 0.2 % of the headline step (profiles/r03_wn_fuse_ab.txt)
+      const bool fuse_upd = m->wn_fuse == 2 ||
+                            (m->wn_fuse == 1 && (int64_t)cdiv(last ? H : 2 * H, 64) * cdiv(Ty, 64) * B <= m->small_max_tiles);
+      if (fuse_upd) {
+        p2.wn_h = h;
+        p2.wn_skip = skip;
+        p2.wn_mask = y_mask;
+        p2.wn_mask_stride = Ty;
+        p2.wn_H = H;
+        p2.wn_last = last ? 1 : 0;
+        p2.wn_first = i == 0 ? 1 : 0;
+      }
+      WETTS_TRY(launch_conv(fw.res_skip[i], p2, s));
+      if (!fuse_upd) WETTS_TRY(k_wn_update(rs, h, skip, y_mask, last ? 1 : 0, i == 0 ? 1 : 0, B, H, Ty, s));
     }
     {
       ConvParams p = conv_io(skip, H, Ty, mm, I / 2, B);  // m = post(output*mask) * mask
