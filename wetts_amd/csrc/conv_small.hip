@@ -23,6 +23,8 @@
 //    ring slots, loop structure and therefore the s_waitcnt counts are static; every load is
 //    unconditional (indices clamped, past-the-end stages multiply the weights' zero tail with a zeroed
 //    tile) for the same reason ("code-generation trap").
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace wetts {
@@ -253,12 +255,13 @@ static int32_t launch_small_kg(const ConvParams& p, hipStream_t stream) {
 // reductions get 8 or 16 waves (2 / 4 per SIMD) as long as the blocks do not fill the chip anyway and
 // LDS / registers allow (MAXKG: 8 for k >= 7).
 template <int KT, int SCH, int MAXKG>
-static int32_t launch_small_cfg(const ConvParams& p, hipStream_t stream) {
+static int32_t launch_small_cfg(const ConvParams& p, hipStream_t stream, int force_kg = 0) {
   const int64_t blocks = (int64_t)cdiv(p.M, 32) * cdiv(p.N, 32) * p.B;
   const int NS = p.nchunks / SCH;
   int kg = 4;
   if (NS >= 16 && blocks * 2 <= 512) kg = 8;
   if (NS >= 32 && blocks * 4 <= 512) kg = 16;
+  if (force_kg) kg = force_kg;
   if (kg > MAXKG) kg = MAXKG;
   while (kg > 4 && small_lds_bytes(SCH, p.span, kg) > 128 * 1024) kg >>= 1;
   if constexpr (MAXKG >= 16)
@@ -267,6 +270,8 @@ static int32_t launch_small_cfg(const ConvParams& p, hipStream_t stream) {
     if (kg == 8) return launch_small_kg<KT, SCH, 8>(p, stream);
   return launch_small_kg<KT, SCH, 4>(p, stream);
 }
+
+static int64_t blocks_of(const ConvParams& p) { return (int64_t)cdiv(p.M, 32) * cdiv(p.N, 32) * p.B; }
 
 // p: geometry filled by launch_conv.  *taken = false when the shape is not one this kernel handles
 // (the caller then runs conv_mfma_kernel).
@@ -279,7 +284,16 @@ int32_t launch_conv_small(const ConvParams& p, hipStream_t stream, bool* taken) 
   if (small_lds_bytes(sch4 ? 4 : 1, p.span, 4) > 160 * 1024) return WETTS_OK;
   *taken = true;
   switch (p.ktaps) {
-    case 1: return sch4 ? launch_small_cfg<1, 4, 8>(p, stream) : launch_small_cfg<1, 1, 16>(p, stream);
+    case 1: {
+      // 1x1 convs of launches with at most 256 blocks: one-chunk stages over 8 waves instead of four-chunk stages
+      // over 4 (of which one idles at 12 chunks): a wave's chain is 1-2 short stages instead of one long one --
+      // B = 1 encoder call 1.64 -> 1.51 ms (profiles/r03_small_1x1_ab.txt).  WETTS_SMALL_1X1: 0 = the four-chunk
+      // form, 1 / 2 / 3 = one-chunk stages over 4 / 8 / 16 waves.
+      static const int mode = getenv("WETTS_SMALL_1X1") ? atoi(getenv("WETTS_SMALL_1X1")) : 2;
+      if (mode > 0 && blocks_of(p) * 4 <= 1024)
+        return launch_small_cfg<1, 1, 16>(p, stream, mode == 1 ? 4 : mode == 2 ? 8 : 16);
+      return sch4 ? launch_small_cfg<1, 4, 8>(p, stream) : launch_small_cfg<1, 1, 16>(p, stream);
+    }
     case 2: return launch_small_cfg<2, 1, 16>(p, stream);
     case 3: return launch_small_cfg<3, 1, 16>(p, stream);
     case 5: return launch_small_cfg<5, 1, 16>(p, stream);
