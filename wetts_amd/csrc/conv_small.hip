@@ -258,9 +258,12 @@ template <int KT, int SCH, int MAXKG>
 static int32_t launch_small_cfg(const ConvParams& p, hipStream_t stream, int force_kg = 0) {
   const int64_t blocks = (int64_t)cdiv(p.M, 32) * cdiv(p.N, 32) * p.B;
   const int NS = p.nchunks / SCH;
+  // WETTS_SMALL_KG8_NS / WETTS_SMALL_KG16_NS (experiment): stages from which 8 / 16 waves are used
+  static const int ns8 = getenv("WETTS_SMALL_KG8_NS") ? atoi(getenv("WETTS_SMALL_KG8_NS")) : 16;
+  static const int ns16 = getenv("WETTS_SMALL_KG16_NS") ? atoi(getenv("WETTS_SMALL_KG16_NS")) : 32;
   int kg = 4;
-  if (NS >= 16 && blocks * 2 <= 512) kg = 8;
-  if (NS >= 32 && blocks * 4 <= 512) kg = 16;
+  if (NS >= ns8 && blocks * 2 <= 512) kg = 8;
+  if (NS >= ns16 && blocks * 4 <= 512) kg = 16;
   if (force_kg) kg = force_kg;
   if (kg > MAXKG) kg = MAXKG;
   while (kg > 4 && small_lds_bytes(SCH, p.span, kg) > 128 * 1024) kg >>= 1;
