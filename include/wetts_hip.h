@@ -96,7 +96,12 @@ typedef struct wetts_config {
   /* VITS2 flows (models.py:73-79, flows.py:340-360): 0 = ResidualCouplingLayer, 1 = "pre_conv"
    * (ResidualCouplingTransformersLayer, flows.py:95-177: 2-layer window-less Encoder on x0),
    * 2 = "pre_conv2" (ResidualCouplingTransformersLayer2, flows.py:16-92: 1-layer Encoder on
-   * pre(x0) with the flow's kernel size and the default relative window) */
+   * pre(x0) with the flow's kernel size and the default relative window),
+   * 3 = "mono_layer_inter_residual", 4 = "mono_layer_post_residual" (the default when a config sets
+   * use_transformer_flows without a type, models.py:74-75): [ResidualCouplingLayer, Flip,
+   * MonoTransformerFlowLayer] per flow (flows.py:391-425); the mono layer (flows.py:242-324) is a
+   * coupling on I/2 channels whose statistics come from the same 2-layer window-less Encoder + a 1x1 post,
+   * 4 with residual_connection=True (reverse: x0 / 2, (x1 - m) / (1 + exp(-logs))) */
   int32_t transformer_flows;
   /* speaker-conditioned text encoder (models.py:87-101, attentions.py:39-48,74-78): at layer 2
    * x = (x + spk_emb_linear(g)) * x_mask */

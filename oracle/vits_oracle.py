@@ -322,16 +322,41 @@ def wn_16bit_sim(W, pre, x, x_mask, g, hidden, n_layers, k, dtype):
     return out * x_mask
 
 
+def mono_flow_reverse(W, pre, x, y_mask, residual_connection):
+    """MonoTransformerFlowLayer.forward(reverse=True) with mean_only=True (flows.py:242-324): a coupling on
+    the natural channel halves whose mean comes from a 2-layer, 2-head, window-less Encoder on x0 and a 1x1
+    `post`.  residual_connection=True (type "mono_layer_post_residual", :287-300): x0 is halved first and
+    kept halved, x1 <- (x1 - m) / (1 + exp(-logs)) with logs = 0; False (":302-324"): the Encoder output gets
+    the x0 residual and x1 <- (x1 - m) * exp(-0)."""
+    half = x.shape[1] // 2
+    x0, x1 = x[:, :half], x[:, half:]
+    if residual_connection:
+        x0 = x0 / 2
+        h = encoder_stack(W, pre + ".pre_transformer", x0, y_mask, 2, 2, None, 3)  # masks its input itself
+        m = conv1d(W, pre + ".post", h) * y_mask
+        x1 = ((x1 - m) / (1 + torch.exp(-torch.zeros_like(m)))) * y_mask
+    else:
+        h = encoder_stack(W, pre + ".pre_transformer", x0 * y_mask, y_mask, 2, 2, None, 3) + x0
+        m = conv1d(W, pre + ".post", h) * y_mask
+        x1 = (x1 - m) * y_mask
+    return torch.cat([x0, x1], 1)
+
+
 def flow_reverse(W, cfg, z_p, y_mask, g, wn_dtype=None):
-    """ResidualCouplingTransformersBlock.forward(reverse=True): reversed [(RCL, Flip) x n]
-    (flows.py:442-449); RCL reverse with mean_only (flows.py:494-513).  wn_dtype (torch.bfloat16 /
+    """ResidualCouplingTransformersBlock.forward(reverse=True): reversed [(RCL, Flip) x n], or
+    [(RCL, Flip, Mono) x n] for the mono_layer types (flows.py:442-449); RCL reverse with mean_only (flows.py:494-513).  wn_dtype (torch.bfloat16 /
     torch.float16): the 16-bit WaveNet numerics spec instead of the f32 graph."""
     H, I = cfg["hidden_channels"], cfg["inter_channels"]
     half = I // 2
     x = z_p
+    tf = cfg.get("transformer_flows", 0)
     for f in range(cfg["flow_n_flows"] - 1, -1, -1):
+        if tf >= 3:
+            # "mono_layer_*": flows = [RCL, Flip, MonoTransformerFlowLayer] x n (flows.py:391-425), so the
+            # reversed list applies the mono layer of flow f first
+            x = mono_flow_reverse(W, f"flow.flows.{3 * f + 2}", x, y_mask, residual_connection=(tf == 4))
         x = torch.flip(x, [1])
-        pre = f"flow.flows.{2 * f}"
+        pre = f"flow.flows.{(3 if tf >= 3 else 2) * f}"
         x0, x1 = x[:, :half], x[:, half:]
         if cfg.get("transformer_flows", 0) == 1:
             # "pre_conv" = ResidualCouplingTransformersLayer (flows.py:95-177): a 2-layer,

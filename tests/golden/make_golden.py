@@ -42,6 +42,12 @@ CASES = {
     "vits2_vocos_b2": ("vits2_vocos_v1", 64, 1, 2, 8, [8, 6], 24, 204, (0.667, 1.0, 0.8)),
     # the two options no checked-in recipe enables: "pre_conv2" flows + speaker-conditioned encoder
     "tiny_preconv2_spk_b3": ("tiny_preconv2_spk", 40, 3, 3, 11, [11, 5, 8], 17, 107, (0.667, 1.0, 0.8)),
+    # the mono-layer flow types (flows.py:242-324,391-425); "tiny_mono_post" carries no transformer_flow_type key,
+    # i.e. it is the reference's DEFAULT type (models.py:74-75)
+    "tiny_mono_post_b2": ("tiny_mono_post", 40, 2, 2, 10, [10, 6], 18, 108, (0.667, 1.0, 0.8)),
+    "tiny_mono_inter_b3": ("tiny_mono_inter", 40, 3, 3, 12, [12, 5, 9], 19, 109, (0.667, 1.0, 0.8)),
+    # B = 1, noise-free: the call shape of the native C++ host (vits_model.cc:37-87 feeds one utterance)
+    "tiny_sdp_b1_nonoise": ("tiny", 40, 3, 1, 14, [14], 20, 110, (0.0, 1.0, 0.0)),
 }
 # Full-size cases (BASELINE.json configs[1]/[2] phoneme counts): these switch on the kernels the tiny
 # cases never reach -- MFMA text-encoder attention (Tx >= 64), the flash attention of the VITS2 flows,
@@ -57,6 +63,8 @@ BIG_CASES = {
     # BASELINE.json configs[3] as benched: AISHELL-3 v1 with the 218-row speaker table (the row count is
     # data derived, task.py:229-232), ragged lengths, speaker ids at both ends of the table
     "aishell3_b4x128": ("v1", 256, 218, 4, 128, [128, 57, 100, 33], 35, 305, (0.667, 1.0, 0.8), [0, 57, 217, 3]),
+    # mono-layer flows at 64 phonemes (~380 frames): the flash attention kernel inside the flow's Encoder
+    "tiny_mono_post_b2x64": ("tiny_mono_post", 64, 2, 2, 64, [64, 41], 36, 326, (0.667, 1.0, 0.8)),
 }
 ONLY = os.environ.get("WETTS_GOLDEN_ONLY")  # comma-separated case names (default: all)
 

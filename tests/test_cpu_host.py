@@ -146,10 +146,16 @@ def test_config_validation_and_unsupported_options():
     assert config.make_config(dict(config.MODEL_CONFIGS["v1"], use_spk_conditioned_encoder=True),
                               10, 0).use_spk_conditioned_encoder == 0
     # a config that omits transformer_flow_type gets the reference's default,
-    # "mono_layer_post_residual" (models.py:74-75) -- not implemented here, so it must raise rather
-    # than silently build pre_conv flows
-    with pytest.raises(NotImplementedError):
-        config.make_config(dict(config.MODEL_CONFIGS["v1"], use_transformer_flows=True), 10, 1)
+    # "mono_layer_post_residual" (models.py:74-75), never pre_conv
+    mp = config.make_config(dict(config.MODEL_CONFIGS["v1"], use_transformer_flows=True), 10, 1)
+    mi = config.make_config(dict(config.MODEL_CONFIGS["v1"], use_transformer_flows=True,
+                                 transformer_flow_type="mono_layer_inter_residual"), 10, 1)
+    assert (mp.transformer_flows, mi.transformer_flows) == (4, 3)
+    # [RCL, Flip, Mono] x 4 (flows.py:391-425): coupling layers at flow.flows.{0,3,6,9}, mono layers at {2,5,8,11}
+    names = {n for n, *_ in checkpoint.blob_layout(mp)}
+    assert "flow.flows.9.enc.in_layers.3.weight" in names and "flow.flows.11.post.weight" in names
+    assert "flow.flows.11.pre_transformer.attn_layers.1.conv_o.weight" in names
+    assert not any(n.startswith("flow.flows.2.enc") or n.startswith("flow.flows.1.") for n in names)
     with pytest.raises(NotImplementedError):
         config.make_config(dict(config.MODEL_CONFIGS["v1"], vocoder_type="bigvgan"), 10, 1)
     vc = config.make_config(dict(config.MODEL_CONFIGS["v1"], vocoder_type="vocos"), 10, 1)

@@ -11,11 +11,15 @@ INFER_CASES = ["tiny_sdp_b3", "tiny_dp_b2", "tiny_sdp_nonoise", "tiny_sdp_single
                "tiny_vocos_b2", "vocos_b2",  # VocosGenerator (decoders.py:251-308)
                "tiny_vits2_vocos_b2", "vits2_vocos_b2",  # + VITS2 pre_conv flows (flows.py:95-177)
                "tiny_preconv2_spk_b3",  # pre_conv2 flows (flows.py:16-92) + speaker-conditioned encoder
+               # mono-layer flows (flows.py:242-324,391-425): post-residual = the reference's default type, inter
+               "tiny_mono_post_b2", "tiny_mono_inter_b3",
+               "tiny_sdp_b1_nonoise",  # B = 1, noise-free: the native C++ host's call shape
                # BASELINE-size phoneme counts (make_golden.py BIG_CASES): MFMA / flash attention, the
                # 128x128 and 64x256 conv tiles and fused ResBlock launches with >= 128 time tiles
                "v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64",
-               "aishell3_b4x128"]  # configs[3]: 218-row speaker table, ragged, sids at both ends
-BIG_CASES = ["v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64", "aishell3_b4x128"]
+               "aishell3_b4x128",  # configs[3]: 218-row speaker table, ragged, sids at both ends
+               "tiny_mono_post_b2x64"]  # mono-layer flows with the flash attention kernel (~400 frames)
+BIG_CASES = ["v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64", "aishell3_b4x128", "tiny_mono_post_b2x64"]
 
 
 def big_case_noise(seed, shape, which):

@@ -35,6 +35,15 @@ def _digest():
     return h.hexdigest()
 
 
+def _obj_digest(src):
+    h = hashlib.sha256()
+    for f in [src] + [x for x in HEADERS if x.endswith(".h")]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=True):
     """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
     os.makedirs(LIBDIR, exist_ok=True)
@@ -48,19 +57,29 @@ def build(force=False, verbose=True):
     procs = []
     for src in SOURCES + BENCH_SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        # per-object stamp: the source, every header and the flags (an edit to one .hip recompiles one object)
+        odig = _obj_digest(src)
+        ostamp = obj + ".sha256"
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == odig:
+            continue
+        if os.path.exists(ostamp):
+            os.remove(ostamp)
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[wetts_amd.build]", " ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
+        procs.append((src, ostamp, odig, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     failed = False
-    for src, p in procs:
+    for src, ostamp, odig, p in procs:
         out, _ = p.communicate()
         if out and verbose:
             sys.stdout.write(out.decode(errors="replace"))
         if p.returncode != 0:
             failed = True
             sys.stderr.write(out.decode(errors="replace") if not verbose else "")
+        else:
+            with open(ostamp, "w") as f:
+                f.write(odig)
     if failed:
         raise RuntimeError("hipcc failed")
     bench_objs = objs[len(SOURCES):]

@@ -121,8 +121,17 @@ MODEL_CONFIGS["tiny_preconv2_spk"] = dict(
 MODEL_CONFIGS["tiny_vits2_vocos"] = dict(
     MODEL_CONFIGS["tiny_vocos"], use_transformer_flows=True, transformer_flow_type="pre_conv",
     use_sdp=True)
-SAMPLING_RATES = {"tiny_preconv2_spk": 22050, "vits2_v1": 22050, "vits2_vocos_v1": 24000, "tiny_vits2_vocos": 24000, "v1": 22050, "v2": 22050, "v3": 16000, "stress48k": 48000, "tiny": 22050,
+# the mono-layer flow types (flows.py:242-324,391-425); "tiny_mono_post" leaves the type key out on purpose:
+# models.py:74-75 then selects mono_layer_post_residual
+MODEL_CONFIGS["tiny_mono_post"] = dict(MODEL_CONFIGS["tiny"], use_transformer_flows=True)
+MODEL_CONFIGS["tiny_mono_inter"] = dict(MODEL_CONFIGS["tiny_dp"], use_transformer_flows=True,
+                                        transformer_flow_type="mono_layer_inter_residual")
+SAMPLING_RATES = {"tiny_mono_post": 22050, "tiny_mono_inter": 16000, "tiny_preconv2_spk": 22050, "vits2_v1": 22050, "vits2_vocos_v1": 24000, "tiny_vits2_vocos": 24000, "v1": 22050, "v2": 22050, "v3": 16000, "stress48k": 48000, "tiny": 22050,
                   "tiny_dp": 16000, "vocos": 16000, "tiny_vocos": 16000}
+
+
+# transformer_flow_type (flows.py:7-13) -> wetts_config_t.transformer_flows
+FLOW_TYPES = {"pre_conv": 1, "pre_conv2": 2, "mono_layer_inter_residual": 3, "mono_layer_post_residual": 4}
 
 
 def _get(model, key, default=None):
@@ -151,13 +160,16 @@ def make_config(model, n_vocab, n_speakers):
     c = _lib.Config()
     if _get(model, "use_transformer_flows", False):
         # models.py:74-75: kwargs.get("transformer_flow_type", "mono_layer_post_residual") -- a config
-        # that omits the key selects the mono-layer flows, which are not implemented here => raise
+        # that omits the key selects the post-residual mono-layer flows
         ft = _get(model, "transformer_flow_type", "mono_layer_post_residual")
-        if ft not in ("pre_conv", "pre_conv2"):
+        if ft not in FLOW_TYPES:
+            # "fft" (flows.py:180-239) cannot be constructed in the reference either: attentions.FFT.__init__
+            # calls an un-imported `weight_norm` (NameError, checked against the live reference) -- there is
+            # no behaviour to match
             raise NotImplementedError(
-                f"transformer_flow_type={ft!r}: 'pre_conv' (flows.py:95-177, the type the "
-                "reference's vits2 configs use) and 'pre_conv2' (flows.py:16-92) are implemented")
-        c.transformer_flows = 1 if ft == "pre_conv" else 2
+                f"transformer_flow_type={ft!r}: implemented types are {sorted(FLOW_TYPES)} "
+                "(flows.py:16-177,242-324); 'fft' is not constructible in the reference")
+        c.transformer_flows = FLOW_TYPES[ft]
     if _get(model, "use_spk_conditioned_encoder", False) and int(_get(model, "gin_channels", 0)) > 0 \
             and n_speakers > 0:
         if int(_get(model, "n_layers")) <= 2:

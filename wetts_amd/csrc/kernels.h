@@ -118,6 +118,12 @@ int32_t k_scale_rows(const float* a, const float* scale, int rows, int cols, flo
 // in natural order, raw (x0) and masked (x0m = x0 * mask)
 int32_t k_flip_half(const float* x, const float* mask, int B, int C, int T, float* x0, float* x0m,
                     hipStream_t s);
+// VITS2 "mono_layer_*" flows, MonoTransformerFlowLayer reverse (flows.py:287-300,302-324): the input split
+// (x0 = x[:, :C/2] * sc raw and masked) and the coupling out = [x0 * sc, (x1 - m) * sc * mask]
+int32_t k_mono_split(const float* x, const float* mask, int B, int C, int T, float sc, float* x0, float* x0m,
+                     hipStream_t s);
+int32_t k_mono_coupling(const float* x, const float* m, const float* mask, int B, int C, int T, float sc, float* out,
+                        hipStream_t s);
 // out = a + b (out may alias a)
 int32_t k_add(const float* a, const float* b, int64_t n, float* out, hipStream_t s);
 

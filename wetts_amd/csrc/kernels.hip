@@ -983,6 +983,56 @@ int32_t k_flip_half(const float* x, const float* mask, int B, int C, int T, floa
   return WETTS_OK;
 }
 
+// MonoTransformerFlowLayer reverse, input side (flows.py:287-290,303-304): x0 = x[:, :C/2] * sc copied out, raw and masked
+__global__ void mono_split_kernel(const float* __restrict__ x, const float* __restrict__ mask, int B, int C, int T,
+                                  float sc, float* __restrict__ x0, float* __restrict__ x0m) {
+  const int half = C / 2;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * half * T) return;
+  const int t = (int)(idx % T);
+  const int c = (int)((idx / T) % half);
+  const int b = (int)(idx / ((int64_t)T * half));
+  const float v = x[((int64_t)b * C + c) * T + t] * sc;
+  x0[idx] = v;
+  x0m[idx] = v * mask[(int64_t)b * T + t];
+}
+
+int32_t k_mono_split(const float* x, const float* mask, int B, int C, int T, float sc, float* x0, float* x0m,
+                     hipStream_t s) {
+  int64_t n = (int64_t)B * (C / 2) * T;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(mono_split_kernel, grid1d(n, 256), dim3(256), 0, s, x, mask, B, C, T, sc, x0, x0m);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// MonoTransformerFlowLayer reverse, output side (flows.py:297-299,320-322 with mean_only => logs = 0):
+//   out[c] = c < half ? x[c] * sc : (x[c] - m[c - half]) * sc * mask;  sc = 1 (inter) or 1/2 (post: x0 / 2 and
+//   1 / (1 + exp(-0)), both exact as a multiply by 0.5)
+__global__ void mono_coupling_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                     const float* __restrict__ mask, int B, int C, int T, float sc,
+                                     float* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * C * T) return;
+  const int t = (int)(idx % T);
+  const int c = (int)((idx / T) % C);
+  const int b = (int)(idx / ((int64_t)T * C));
+  const int half = C / 2;
+  float v = x[idx];
+  if (c >= half) v = ((v - m[((int64_t)b * half + (c - half)) * T + t]) * sc) * mask[(int64_t)b * T + t];
+  else v = v * sc;
+  out[idx] = v;
+}
+
+int32_t k_mono_coupling(const float* x, const float* m, const float* mask, int B, int C, int T, float sc, float* out,
+                        hipStream_t s) {
+  int64_t n = (int64_t)B * C * T;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(mono_coupling_kernel, grid1d(n, 256), dim3(256), 0, s, x, m, mask, B, C, T, sc, out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
                            float* __restrict__ out) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

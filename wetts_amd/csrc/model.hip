@@ -89,10 +89,11 @@ static int validate_config(const wetts_config_t* c) {
                 "bad flow config");
   WETTS_REQUIRE(c->sdp_n_flows >= 2, "bad sdp_n_flows");
   WETTS_REQUIRE(c->vocoder_type == 0 || c->vocoder_type == 1, "vocoder_type must be 0 (hifigan) or 1 (vocos)");
-  WETTS_REQUIRE(c->transformer_flows >= 0 && c->transformer_flows <= 2,
-                "transformer_flows must be 0, 1 (pre_conv) or 2 (pre_conv2)");
-  WETTS_REQUIRE(c->transformer_flows != 1 || (c->inter_channels / 2) % 2 == 0,
-                "pre_conv flows need inter_channels/2 divisible by their 2 heads");
+  WETTS_REQUIRE(c->transformer_flows >= 0 && c->transformer_flows <= 4,
+                "transformer_flows must be 0, 1 (pre_conv), 2 (pre_conv2), 3 (mono_layer_inter_residual) or "
+                "4 (mono_layer_post_residual)");
+  WETTS_REQUIRE(c->transformer_flows == 0 || c->transformer_flows == 2 || (c->inter_channels / 2) % 2 == 0,
+                "pre_conv / mono_layer flows need inter_channels/2 divisible by their 2 heads");
   WETTS_REQUIRE(c->transformer_flows != 2 || c->hidden_channels % 2 == 0,
                 "pre_conv2 flows need hidden_channels divisible by their 2 heads");
   WETTS_REQUIRE(c->use_spk_conditioned_encoder == 0 ||
@@ -110,6 +111,31 @@ static int validate_config(const wetts_config_t* c) {
 }
 
 static bool has_g(const wetts_config_t* c) { return c->n_speakers > 0 && c->gin_channels > 0; }
+// "mono_layer_*" flow types (flows.py:391-425): [ResidualCouplingLayer, Flip, MonoTransformerFlowLayer] per flow, so
+// coupling layer f sits at flow.flows.{3f} and its mono layer at flow.flows.{3f+2}; every other type is [layer, Flip]
+static bool mono_flows(const wetts_config_t* c) { return c->transformer_flows >= 3; }
+static int flow_key_stride(const wetts_config_t* c) { return mono_flows(c) ? 3 : 2; }
+// the flow types whose Encoder runs on the I/2 channels of x0 (2 layers, 2 heads, window_size=None, FFN kernel 3)
+static bool half_enc_flows(const wetts_config_t* c) { return c->transformer_flows == 1 || mono_flows(c); }
+// that Encoder's tensors under `p`.pre_transformer (flows.py:111-119 and :256-264 build the same module)
+static void add_half_encoder(Layout& L, const std::string& p, int Hh) {
+  for (int l = 0; l < 2; ++l) {
+    std::string a = p + S(".pre_transformer.attn_layers.%d", l);
+    for (const char* n : {"conv_q", "conv_k", "conv_v", "conv_o"}) {
+      L.add(a + "." + n + ".weight", Hh, Hh, 1);
+      L.add(a + "." + n + ".bias", Hh);
+    }
+    L.add(p + S(".pre_transformer.norm_layers_1.%d.gamma", l), Hh);
+    L.add(p + S(".pre_transformer.norm_layers_1.%d.beta", l), Hh);
+    std::string ff = p + S(".pre_transformer.ffn_layers.%d", l);
+    L.add(ff + ".conv_1.weight", Hh, Hh, 3);
+    L.add(ff + ".conv_1.bias", Hh);
+    L.add(ff + ".conv_2.weight", Hh, Hh, 3);
+    L.add(ff + ".conv_2.bias", Hh);
+    L.add(p + S(".pre_transformer.norm_layers_2.%d.gamma", l), Hh);
+    L.add(p + S(".pre_transformer.norm_layers_2.%d.beta", l), Hh);
+  }
+}
 
 static void add_dds(Layout& L, const std::string& p, int C, int k, int n) {
   for (int i = 0; i < n; ++i) {
@@ -197,27 +223,9 @@ static void build_layout(const wetts_config_t* c, Layout& L) {
   }
 
   for (int f = 0; f < c->flow_n_flows; ++f) {
-    std::string p = S("flow.flows.%d", 2 * f);
-    if (c->transformer_flows == 1) {
-      // Encoder(half, half, n_heads=2, n_layers=2, kernel_size=3, window_size=None), flows.py:111-119
-      const int Hh = I / 2;
-      for (int l = 0; l < 2; ++l) {
-        std::string a = p + S(".pre_transformer.attn_layers.%d", l);
-        for (const char* n : {"conv_q", "conv_k", "conv_v", "conv_o"}) {
-          L.add(a + "." + n + ".weight", Hh, Hh, 1);
-          L.add(a + "." + n + ".bias", Hh);
-        }
-        L.add(p + S(".pre_transformer.norm_layers_1.%d.gamma", l), Hh);
-        L.add(p + S(".pre_transformer.norm_layers_1.%d.beta", l), Hh);
-        std::string ff = p + S(".pre_transformer.ffn_layers.%d", l);
-        L.add(ff + ".conv_1.weight", Hh, Hh, 3);
-        L.add(ff + ".conv_1.bias", Hh);
-        L.add(ff + ".conv_2.weight", Hh, Hh, 3);
-        L.add(ff + ".conv_2.bias", Hh);
-        L.add(p + S(".pre_transformer.norm_layers_2.%d.gamma", l), Hh);
-        L.add(p + S(".pre_transformer.norm_layers_2.%d.beta", l), Hh);
-      }
-    }
+    std::string p = S("flow.flows.%d", flow_key_stride(c) * f);
+    // Encoder(half, half, n_heads=2, n_layers=2, kernel_size=3, window_size=None), flows.py:111-119
+    if (c->transformer_flows == 1) add_half_encoder(L, p, I / 2);
     if (c->transformer_flows == 2) {
       // Encoder(hidden, hidden, n_heads=2, n_layers=1, kernel_size=flow kernel, window 4), flows.py:40-48
       const int dkf = H / 2, Wf = 2 * 4 + 1, fk2 = c->flow_kernel_size;
@@ -252,6 +260,14 @@ static void build_layout(const wetts_config_t* c, Layout& L) {
     }
     L.add(p + ".post.weight", I / 2, H, 1);
     L.add(p + ".post.bias", I / 2);
+    if (mono_flows(c)) {
+      // MonoTransformerFlowLayer(channels, hidden, mean_only=True): pre_transformer + post 1x1 on I/2 channels
+      // (flows.py:242-269)
+      std::string q = S("flow.flows.%d", 3 * f + 2);
+      add_half_encoder(L, q, I / 2);
+      L.add(q + ".post.weight", I / 2, I / 2, 1);
+      L.add(q + ".post.bias", I / 2);
+    }
   }
 
   if (c->vocoder_type == 1) {  // VocosGenerator (decoders.py:251-284)
@@ -337,6 +353,9 @@ struct FlowW {
   std::vector<PackedConv> in_layers, res_skip;
   const float *cond_w = nullptr, *cond_b = nullptr;
   std::vector<EncLayer> pre_tr;  // VITS2 "pre_conv": Encoder on x0 (flows.py:111-119), else empty
+  // "mono_layer_*": the MonoTransformerFlowLayer that follows this coupling layer (flows.py:242-324)
+  std::vector<EncLayer> mono_tr;
+  PackedConv mono_post;
 };
 
 struct RB {
@@ -636,7 +655,7 @@ static int32_t build_model(wetts_model* m, hipStream_t s) {
   m->flows.resize(c->flow_n_flows);
   for (int f = 0; f < c->flow_n_flows; ++f) {
     FlowW& fw = m->flows[f];
-    std::string p = S("flow.flows.%d", 2 * f);
+    std::string p = S("flow.flows.%d", flow_key_stride(c) * f);
     // plain coupling layers read x0 = Flip(x)[:I/2] = x[I-1 .. I/2]: the Flip is folded into `pre` by packing
     // its input channels in reverse, so the conv reads channels I/2 .. I-1 in place (no index arithmetic
     // while staging); the pre_conv transformer flow materialises x0 and keeps the natural order
@@ -673,11 +692,17 @@ static int32_t build_model(wetts_model* m, hipStream_t s) {
       WETTS_TRY(pack(m, ff + ".conv_1.weight", ff + ".conv_1.bias", H, H, fk, 1, (fk - 1) / 2, 0, 0, s, &e.f1));
       WETTS_TRY(pack(m, ff + ".conv_2.weight", ff + ".conv_2.bias", H, H, fk, 1, (fk - 1) / 2, 0, 0, s, &e.f2));
     }
-    if (c->transformer_flows == 1) {
+    if (mono_flows(c)) {
+      const std::string q = S("flow.flows.%d", 3 * f + 2);
+      WETTS_TRY(pack(m, q + ".post.weight", q + ".post.bias", I / 2, I / 2, 1, 1, 0, 0, 0, s, &fw.mono_post));
+    }
+    if (half_enc_flows(c)) {
       const int Hh = I / 2;
-      fw.pre_tr.resize(2);
+      std::vector<EncLayer>& tr = mono_flows(c) ? fw.mono_tr : fw.pre_tr;
+      if (mono_flows(c)) p = S("flow.flows.%d", 3 * f + 2);
+      tr.resize(2);
       for (int l = 0; l < 2; ++l) {
-        EncLayer& e = fw.pre_tr[l];
+        EncLayer& e = tr[l];
         std::string a = p + S(".pre_transformer.attn_layers.%d", l);
         e.rel_k = e.rel_v = nullptr;  // window_size=None
         WETTS_TRY(pack_qkv(m, a, Hh, s, &e.qkv));
@@ -773,11 +798,11 @@ static int64_t ws_flow(const wetts_config_t* c, int B, int Ty) {
   // the skip sum at f32 channel-last
   n += 2 * align_up(B * H * Ty * 2, 256) + 2 * align_up(B * 2 * H * Ty * 2, 256) + A256(B * H * Ty);
   if (c->transformer_flows != 0) {
-    const int64_t He = c->transformer_flows == 1 ? I / 2 : H;
+    const int64_t He = half_enc_flows(c) ? I / 2 : H;
     // the T*T score region only exists on the three-kernel attention path; the flash kernel (every
     // reference config: window-less, dk = 48) needs the transposed v and nothing else
     n += 9 * A256(B * He * Ty) +
-         A256(attn_score_elems(c->transformer_flows == 1 ? -1 : 4, (int)(He / 2), B, 2, Ty) + B * He * Ty +
+         A256(attn_score_elems(half_enc_flows(c) ? -1 : 4, (int)(He / 2), B, 2, Ty) + B * He * Ty +
               (int64_t)B * 2 * 9 * Ty);
   }
   return n;
@@ -1322,7 +1347,7 @@ static int32_t pack_flow_bf16_layers(const wetts_model* m, int f16, hipStream_t 
   m->b_wn_in.assign(c->flow_n_flows, std::vector<PackedConvB>(NL));
   m->b_wn_rs.assign(c->flow_n_flows, std::vector<PackedConvB>(NL));
   for (int f = 0; f < c->flow_n_flows; ++f) {
-    const std::string p = S("flow.flows.%d", 2 * f);
+    const std::string p = S("flow.flows.%d", flow_key_stride(c) * f);
     for (int i = 0; i < NL; ++i) {
       WETTS_TRY(pack_conv_weight_bf16(m->T(p + S(".enc.in_layers.%d.weight", i)),
                                       m->T(p + S(".enc.in_layers.%d.bias", i)), 2 * H, H, fk, 1,
@@ -1395,12 +1420,12 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
         *tatt = nullptr, *ty = nullptr, *thid = nullptr, *txb = nullptr, *tsc = nullptr;
   if (c->transformer_flows != 0) {
     // encoder width: x0 (I/2 channels) for pre_conv, the hidden h for pre_conv2
-    const int64_t nh2 = (int64_t)B * (c->transformer_flows == 1 ? I / 2 : H) * Ty;
+    const int64_t nh2 = (int64_t)B * (half_enc_flows(c) ? I / 2 : H) * Ty;
     tx0 = ws.take<float>(nh2); txm = ws.take<float>(nh2); tq = ws.take<float>(nh2);
     tk = ws.take<float>(nh2); tv = ws.take<float>(nh2); tatt = ws.take<float>(nh2);
     ty = ws.take<float>(nh2); thid = ws.take<float>(nh2); txb = ws.take<float>(nh2);
-    const int He = c->transformer_flows == 1 ? I / 2 : H;
-    tsc = ws.take<float>(attn_score_elems(c->transformer_flows == 1 ? -1 : 4, He / 2, B, 2, Ty) + nh2 +
+    const int He = half_enc_flows(c) ? I / 2 : H;
+    tsc = ws.take<float>(attn_score_elems(half_enc_flows(c) ? -1 : 4, He / 2, B, 2, Ty) + nh2 +
                          (int64_t)B * 2 * 9 * Ty);  // scores (three-kernel path only) + vT + rel table
   }
   if (!ws.ok) {
@@ -1410,6 +1435,26 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
   const float* cur = z_p;
   for (int f = c->flow_n_flows - 1; f >= 0; --f) {
     const FlowW& fw = m->flows[f];
+    if (mono_flows(c)) {
+      // MonoTransformerFlowLayer.forward(reverse=True) ahead of this flow's Flip + coupling layer (reversed
+      // [RCL, Flip, Mono] list, flows.py:391-425,444-446), channels in natural order: x0 = cur[:, :I/2].
+      //   inter (3, flows.py:302-324): h = pre_transformer(x0 * mask, mask) + x0;  m = post(h) * mask;
+      //                                out = [x0, (x1 - m) * mask]
+      //   post  (4, flows.py:287-300): x0 = x0 / 2;  m = post(pre_transformer(x0, mask)) * mask  (the Encoder masks its
+      //                                input itself, attentions.py:72);  out = [x0, (x1 - m) / (1 + exp(-0)) * mask]
+      const int Hh = I / 2;
+      const float sc = c->transformer_flows == 4 ? 0.5f : 1.f;
+      float* mdst = (cur == xa) ? xb : xa;
+      WETTS_TRY(k_mono_split(cur, y_mask, B, I, Ty, sc, tx0, txm, s));  // x0 * sc, and x0 * sc * mask
+      WETTS_TRY(run_enc_layers(fw.mono_tr, txm, y_mask, B, Hh, Hh, 2, -1, Ty, tq, tk, tv, tatt, ty, thid, tsc, txb, s));
+      if (c->transformer_flows == 3) WETTS_TRY(k_add(txm, tx0, (int64_t)B * Hh * Ty, txm, s));
+      ConvParams p = conv_io(txm, Hh, Ty, mm, Hh, B);
+      p.out_mask = y_mask;
+      p.out_mask_stride = Ty;
+      WETTS_TRY(launch_conv(fw.mono_post, p, s));
+      WETTS_TRY(k_mono_coupling(cur, mm, y_mask, B, I, Ty, sc, mdst, s));
+      cur = mdst;
+    }
     float* dst = (f == 0) ? z_out : ((cur == xa) ? xb : xa);
     // Flip then ResidualCouplingLayer(reverse): x0 = flipped[:I/2] = cur[I-1 .. I/2]
     if (c->transformer_flows == 1) {
