@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define WETTS_ABI_VERSION 6
+#define WETTS_ABI_VERSION 7
 
 #define WETTS_OK 0
 #define WETTS_E_INVALID (-1)   /* bad argument / unsupported configuration */
@@ -152,6 +152,11 @@ int32_t wetts_set_seed(const wetts_model_t* m, uint64_t seed);
 
 /* total upsampling factor (prod upsample_rates) == hop length of the checkpoint. */
 int32_t wetts_hop_length(const wetts_model_t* m);
+
+/* Copies the model's folded float32 weights (the blob wetts_create() was given, in
+ * wetts_blob_tensor_info() order) into out_dev[numel], stream-ordered.  Backs the drop-in module's
+ * state_dict() (the reference saves checkpoints from it, utils/task.py:59-76). */
+int32_t wetts_get_blob(const wetts_model_t* m, float* out_dev, int64_t numel, void* stream);
 
 /* Scratch needed by any of the stage calls below for a batch of B utterances, Tx phonemes
  * (padded) and Ty frames (padded).  Pass Ty = 0 for the pre-length-regulation stages only. */

@@ -261,6 +261,7 @@ def main():
                         y_lengths=ylen.numpy(), attn=attn.numpy())
     print("generate_path_kat: ok")
     chunk_kat()
+    chunk_kat_triton()
 
 
 def chunk_kat():
@@ -294,6 +295,48 @@ def chunk_kat():
                 rows.append((L, block, pad, hop, len(chunks), i, a, b, lo, hi))
     np.savez_compressed(os.path.join(OUT, "chunk_kat.npz"), rows=np.array(rows, np.int64))
     print("chunk_kat:", len(rows), "windows")
+
+
+def chunk_kat_triton():
+    """Known answers of the Triton streaming twin's get_chunks / depadding
+    (runtime/cpu_triton_stream/model_repo/stream_tts/1/model.py:58-111, MIN_CHUNK = 65 and the reflect padding of
+    a short last window), lifted out of the file's AST and executed as they are (the module imports
+    triton_python_backend_utils / pypinyin / tn, all absent).  One row per window:
+    (L, block, pad, hop, n_chunks, i, win_start, win_len_with_padding, pad_end or -1, index_checksum, lo, hi,
+    raised) -- `index_checksum` = sum((pos + 1) * frame_index) over the window incl. its reflected frames, `raised`
+    = 1 where the reference's depadding raises TypeError (`-None`, model.py:105)."""
+    import ast
+    path = os.path.join(ref_import.REF_VITS, "..", "..", "runtime", "cpu_triton_stream", "model_repo", "stream_tts",
+                        "1", "model.py")
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body
+            if (isinstance(n, ast.FunctionDef) and n.name in ("get_chunks", "depadding"))
+            or (isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") in
+                ("MIN_CHUNK", "VOC_BLOCK_SIZE", "VOC_PAD_SIZE", "UPSAMPLE_SIZE"))]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "stream_tts/1/model.py", "exec"), ns)
+    assert (ns["MIN_CHUNK"], ns["VOC_BLOCK_SIZE"], ns["VOC_PAD_SIZE"], ns["UPSAMPLE_SIZE"]) == (65, 70, 10, 256)
+    rows = []
+    for L in (2, 30, 64, 65, 66, 69, 70, 71, 80, 124, 125, 139, 140, 141, 150, 200, 210, 333):
+        for block, pad in ((70, 10), (40, 10), (16, 4), (100, 20)):
+            hop = 256 if block != 16 else 64
+            mel = np.arange(L, dtype=np.int64).reshape(1, 1, L)  # (B, freq, Frame): the Triton twin's z layout
+            chunks, pad_end = ns["get_chunks"](mel, block, pad)
+            for i, ch in enumerate(chunks):
+                idx = ch[0, 0]
+                n = idx.shape[0] * hop
+                audio = np.arange(n, dtype=np.int64).reshape(1, n)
+                raised, lo, hi = 0, 0, 0
+                try:
+                    kept = ns["depadding"](audio, len(chunks), i, block, pad, hop, pad_end)
+                    lo, hi = (int(kept[0, 0]), int(kept[0, -1]) + 1) if kept.shape[1] else (0, 0)
+                except TypeError:
+                    raised = 1
+                cks = int(((np.arange(idx.shape[0]) + 1) * idx).sum())
+                rows.append((L, block, pad, hop, len(chunks), i, int(idx[0]), idx.shape[0],
+                             -1 if pad_end is None else int(pad_end), cks, lo, hi, raised))
+    np.savez_compressed(os.path.join(OUT, "chunk_kat_triton.npz"), rows=np.array(rows, np.int64))
+    print("chunk_kat_triton:", len(rows), "windows,", sum(r[-1] for r in rows), "where the reference raises")
 
 
 if __name__ == "__main__":

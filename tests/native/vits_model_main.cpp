@@ -1,9 +1,13 @@
 // Native-host check of include/wetts_vits_model.hpp (the C++ twin of the reference's
 // runtime/core/model/vits_model.h).  Reads a case written by tests/test_gpu_native.py:
 //   case.bin = [wetts_config_t][int64 n_blob][float blob...][int64 n_ph][int64 ph...][int64 sid]
-//              [int64 n_audio][float expected_audio...]   (expected from the Python path,
-//              noise scales 0 so both sides are deterministic)
-// Prints "OK rms=<..> stream_ok=<0/1>" and exits 0 on success.
+//              [int64 n_audio][float expected_audio...]   (expected = the REFERENCE's golden audio for
+//              this utterance, tests/golden/tiny_sdp_b1_nonoise.npz; noise scales 0 so the run is deterministic)
+//   argv: case.bin chunk pad rf   (rf = the generator's receptive field in frames, one side)
+// Gates: Forward() vs the golden (RMS < 1e-4); the streamed concatenation has the one-shot's length; every
+// streamed sample whose window reaches rf frames to both sides (or ends at the utterance's own edge) equals the
+// one-shot decode and the golden to 1e-4 -- the overlap-discard protocol of vits_model.cc:96-153.
+// Prints "OK ..." and exits 0 on success.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -35,8 +39,10 @@ int main(int argc, char** argv) {
   rd(f, &n, 1);
   std::vector<float> expect(n);
   rd(f, expect.data(), n);
+  const int chunk = argc > 2 ? std::atoi(argv[2]) : 16, pad = argc > 3 ? std::atoi(argv[3]) : 12;
+  const int rf = argc > 4 ? std::atoi(argv[4]) : 20;
   try {
-    wetts_hip::VitsModel model(cfg, blob, /*chunk*/ 16, /*pad*/ 12);
+    wetts_hip::VitsModel model(cfg, blob, chunk, pad);
     model.set_scales(0.f, 1.f, 0.f);
     std::vector<float> audio;
     model.Forward(ph, (int)sid, &audio);
@@ -50,22 +56,40 @@ int main(int argc, char** argv) {
       se += d * d;
     }
     const double rms = std::sqrt(se / audio.size());
-    // streaming: concatenation has the same length; interior samples agree with the one-shot
+    // streaming: SetInput once, StreamDecode until done (vits_model.cc:128-153)
     model.SetInput(ph, (int)sid);
     std::vector<float> cat, piece;
     bool done = false;
     int calls = 0;
     while (!done && calls < 1000) { done = model.StreamDecode(&piece); cat.insert(cat.end(), piece.begin(), piece.end()); ++calls; }
-    bool stream_ok = cat.size() == audio.size();
-    double worst = 0;
+    const bool stream_ok = cat.size() == audio.size();
+    const int frames = model.frames(), hop = model.hop_length();
+    const int nchunks = (frames + chunk - 1) / chunk;
+    double worst_in = 0, worst_in_gold = 0, worst_all = 0;
+    long n_in = 0;
     if (stream_ok) {
-      std::vector<double> diffs;
-      for (size_t i = 0; i < cat.size(); ++i) worst = std::max(worst, std::fabs((double)cat[i] - audio[i]) / 32767.0);
+      for (int t = 0; t < frames; ++t) {
+        const int c = t / chunk;  // the chunk that emits frame t
+        const int ws = std::max(0, c * chunk - pad), we = std::min((c + 1) * chunk + pad, frames);
+        const bool interior = (ws == 0 || t - ws >= rf) && (we == frames || we - 1 - t >= rf);
+        for (int k = 0; k < hop; ++k) {
+          const size_t i = (size_t)t * hop + k;
+          const double d = std::fabs((double)cat[i] - audio[i]) / 32767.0;
+          worst_all = std::max(worst_all, d);
+          if (interior) {
+            worst_in = std::max(worst_in, d);
+            worst_in_gold = std::max(worst_in_gold, std::fabs((double)cat[i] / 32767.0 - expect[i]));
+            ++n_in;
+          }
+        }
+      }
     }
-    std::printf("%s rms=%.3e frames=%d stream_calls=%d stream_ok=%d stream_worst=%.3e\n",
-                (rms < 1e-4 && stream_ok) ? "OK" : "FAIL", rms, model.frames(), calls,
-                (int)stream_ok, worst);
-    return (rms < 1e-4 && stream_ok) ? 0 : 1;
+    const bool ok = rms < 1e-4 && stream_ok && calls == nchunks && n_in > 0 && worst_in < 1e-4 && worst_in_gold < 1e-3;
+    std::printf("%s rms_vs_reference=%.3e frames=%d stream_calls=%d stream_ok=%d interior_samples=%ld of %zu "
+                "interior_worst=%.3e interior_worst_vs_reference=%.3e all_worst=%.3e\n",
+                ok ? "OK" : "FAIL", rms, frames, calls, (int)stream_ok, n_in, cat.size(), worst_in, worst_in_gold,
+                worst_all);
+    return ok ? 0 : 1;
   } catch (const std::exception& e) {
     std::printf("FAIL exception: %s\n", e.what());
     return 1;

@@ -135,6 +135,83 @@ def test_chunk_helpers_match_the_references_own_functions():
         assert g == (lo, hi), (L, block, pad, i, g, (lo, hi))
 
 
+def test_triton_min_chunk_helpers_match_the_references_own_functions():
+    """tests/golden/chunk_kat_triton.npz: get_chunks / depadding of the Triton streaming twin
+    (stream_tts/1/model.py:58-111, MIN_CHUNK 65, reflect-padded short last window) lifted from the reference by
+    AST (make_golden.py:chunk_kat_triton).  Windows, pad_end, the reflected frame indices and the kept sample
+    ranges are equal wherever the reference returns a result; the two documented deviations are exactly the
+    reference's crash (`-None`) and its single-window over-read."""
+    from wetts_amd.session import depad_bounds_min, get_chunks_min
+    rows = np.load(os.path.join(util.GOLDEN, "chunk_kat_triton.npz"))["rows"].tolist()
+    seen_pad = seen_raise = seen_single = 0
+    for (L, block, pad, hop, n, i, a, wlen, pad_end, cks, lo, hi, raised) in rows:
+        wins, pe = get_chunks_min(L, block, pad, 65)
+        assert len(wins) == n and (pe if pe is not None else -1) == pad_end, (L, block, pad)
+        ws, we = wins[i]
+        last_pad = pe if (pe and i == n - 1) else 0
+        idx = np.arange(ws, we, dtype=np.int64)
+        if last_pad:  # the reflected frames, through the same numpy call stream_decode makes
+            idx = np.pad(idx.reshape(1, -1, 1), ((0, 0), (0, last_pad), (0, 0)), mode="reflect").reshape(-1)
+            seen_pad += 1
+        assert ws == a and idx.shape[0] == wlen, (L, block, pad, i)
+        assert int(((np.arange(idx.shape[0]) + 1) * idx).sum()) == cks, (L, block, pad, i)
+        g = depad_bounds_min(n, i, block, pad, hop, wlen * hop, last_pad or None)
+        g = (g[0], g[1]) if g[1] > g[0] else (0, 0)
+        if raised:  # reference: TypeError; here the un-padded tail is kept
+            seen_raise += 1
+            assert i == n - 1 and n > 1 and pad_end == -1 and g == (min(i * block, pad) * hop, wlen * hop)
+        elif n == 1 and pad_end > 0:  # reference keeps audio of reflected frames; here clipped to real frames
+            seen_single += 1
+            assert (lo, hi) == (0, min(block, wlen) * hop) and g == (0, L * hop)
+        else:
+            assert g == (lo, hi), (L, block, pad, i, g, (lo, hi))
+    assert seen_pad > 10 and seen_raise > 0 and seen_single > 0
+    # the pieces always tile [0, L*hop) exactly
+    for L in (30, 65, 139, 141, 333):
+        wins, pe = get_chunks_min(L, 70, 10, 65)
+        total = 0
+        for i, (ws, we) in enumerate(wins):
+            lp = pe if (pe and i == len(wins) - 1) else None
+            a, b = depad_bounds_min(len(wins), i, 70, 10, 256, (we - ws + (lp or 0)) * 256, lp)
+            total += b - a
+        assert total == L * 256
+
+
+def test_state_dict_round_trip_and_reference_keys():
+    """SynthesizerTrn.state_dict(): folded tensors under the reference's keys; loading it into a second model
+    reproduces the blob bit for bit; with the live reference present, the dict loads into the reference module
+    after its own remove_weight_norm() and every tensor lands (CPU tier: read from the host blob; the device
+    read-back through wetts_get_blob is the GPU tier's)."""
+    from wetts_amd import SynthesizerTrn
+    for mname, n_spk in (("tiny", 3), ("tiny_mono_post", 2), ("tiny_vocos", 2)):
+        cfg = config.make_config(config.MODEL_CONFIGS[mname], 40, n_spk)
+        sd = synth.make_state_dict(cfg, 5)
+        net = SynthesizerTrn(40, 513, 32, n_speakers=n_spk, **config.MODEL_CONFIGS[mname]).load_state_dict(sd)
+        out = net.state_dict()
+        W = checkpoint.fold_weight_norm(sd)
+        assert list(out) == [n for n, *_ in checkpoint.blob_layout(cfg)]
+        for k, v in out.items():
+            assert tuple(v.shape) == tuple(W[k].shape) and torch.equal(v, W[k].to(torch.float32)), k
+        net2 = SynthesizerTrn(40, 513, 32, n_speakers=n_spk, **config.MODEL_CONFIGS[mname]).load_state_dict(out)
+        assert torch.equal(net2._blob, net._blob)
+    from oracle import ref_import
+    if not ref_import.available():
+        return
+    import contextlib
+    import io
+    Ref, *_ = ref_import.import_reference()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = Ref(40, 513, 32, n_speakers=3, **config.MODEL_CONFIGS["tiny"]).eval()
+    ref.dec.remove_weight_norm()
+    ref.flow.remove_weight_norm()
+    cfg = config.make_config(config.MODEL_CONFIGS["tiny"], 40, 3)
+    net = SynthesizerTrn(40, 513, 32, n_speakers=3, **config.MODEL_CONFIGS["tiny"]).load_state_dict(
+        synth.make_state_dict(cfg, 5))
+    missing, unexpected = ref.load_state_dict(net.state_dict(), strict=False)
+    assert not unexpected
+    assert all(k.startswith(("enc_q.", "dp.post_", "dp.flows.1.")) for k in missing), missing
+
+
 def test_config_validation_and_unsupported_options():
     with pytest.raises(NotImplementedError):
         config.make_config(dict(config.MODEL_CONFIGS["v1"], use_transformer_flows=True,

@@ -104,7 +104,7 @@ def test_native_wetts_infer_matches_python_composition():
     assert rc == -3 and frames.value == Ty
 
 
-def test_cli_writes_reference_format_wavs(tmp_path):
+def test_cli_writes_reference_format_wavs(tmp_path, capsys):
     from scipy.io import wavfile
     from wetts_amd import config, inference, synth
     mname, n_vocab, n_spk = "tiny", 12, 2
@@ -126,6 +126,18 @@ def test_cli_writes_reference_format_wavs(tmp_path):
                     str(out), "--phone_table", str(tmp_path / "phones.txt"), "--speaker_table",
                     str(tmp_path / "speaker.txt"), "--test_file", str(tmp_path / "test.txt"),
                     "--gpu", "0", "--batch", "2", "--seed", "1"])
+    printed = [l for l in capsys.readouterr().out.splitlines() if l.endswith(".wav")]
+    assert printed == ["a/utt1.wav", "b/utt2.wav"]  # test-file order, whatever the bucket order was
+    ragged = {n: wavfile.read(out / n)[1] for n in ("utt1.wav", "utt2.wav")}
+    # --decode padded: the shorter utterance is decoded inside the padded batch (infer()'s semantics); same seed,
+    # same frame counts, the longest utterance's audio is the same either way
+    inference.main(["--checkpoint", str(ckpt), "--cfg", str(tmp_path / "cfg.json"), "--outdir",
+                    str(out), "--phone_table", str(tmp_path / "phones.txt"), "--speaker_table",
+                    str(tmp_path / "speaker.txt"), "--test_file", str(tmp_path / "test.txt"),
+                    "--gpu", "0", "--batch", "2", "--seed", "1", "--decode", "padded", "--max_pad_frac", "0.9"])
+    padded = {n: wavfile.read(out / n)[1] for n in ("utt1.wav", "utt2.wav")}
+    assert all(padded[n].shape == ragged[n].shape for n in ragged)
+    assert np.abs(padded["utt1.wav"].astype(np.int32) - ragged["utt1.wav"].astype(np.int32)).max() <= 1
     for name in ("utt1.wav", "utt2.wav"):
         sr, pcm = wavfile.read(out / name)
         assert sr == 22050 and pcm.dtype == np.int16 and pcm.size > 0
@@ -170,7 +182,8 @@ def test_ragged_and_degenerate_batches():
     assert util.rms(o.cpu().numpy() - ref["o"].numpy()) < 1e-4
 
 
-@pytest.mark.parametrize("cname", ["tiny_sdp_b3", "tiny_dp_b2", "tiny_vocos_b2", "tiny_vits2_vocos_b2"])
+@pytest.mark.parametrize("cname", ["tiny_sdp_b3", "tiny_dp_b2", "tiny_vocos_b2", "tiny_vits2_vocos_b2",
+                                   "tiny_mono_post_b2", "tiny_mono_inter_b3"])
 def test_random_small_shapes_match_the_oracle(cname):
     """Odd batch sizes and text lengths (B = 1..5, Tx = 1..23, ragged, length-1 utterances) against the
     oracle on the same padded batch: these are the shapes the small-launch conv schedule, the scalar
@@ -356,3 +369,108 @@ def test_manual_seed_rewinds_the_noise_stream():
     torch.randn(8, device="cuda")
     f = run()
     assert a[1].shape != f[1].shape or not torch.equal(a[1], f[1])
+
+
+def test_generate_path_known_answers_through_the_c_abi():
+    """tests/golden/generate_path_kat.npz -- the reference's commons.generate_path on its edge cases (zero
+    durations, an all-zero row whose y_length clamps to 1, a single long phoneme; make_golden.py) -- through
+    wetts_durations_to_lengths + wetts_length_regulate: y_lengths, y_mask and attn EQUAL, frame2phone = -1 where no
+    phoneme owns the frame (commons.py:120-136, models.py:254-259)."""
+    from wetts_amd import _lib
+    net, case, cfg, *_ = _model("tiny_sdp_b3")
+    lib = _lib.load()
+    d = np.load(os.path.join(util.GOLDEN, "generate_path_kat.npz"))
+    dur = d["durations"][:, 0]  # [B, Tx] integer-valued w_ceil
+    B, Tx = dur.shape
+    dev = net.device
+    # logw such that ceil(exp(logw) * 1 * 1) == duration: log(d) for d > 0, -inf -> exp = 0 for d = 0
+    with np.errstate(divide="ignore"):
+        logw = torch.from_numpy(np.log(dur).astype(np.float32)).to(dev)
+    x_mask = torch.ones(B, Tx, device=dev)
+    w_ceil = torch.empty(B, Tx, device=dev)
+    cum = torch.empty(B, Tx, device=dev)
+    meta = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    status = C.c_void_p(meta.data_ptr() + 8 * B)
+    s = _lib.current_stream_ptr()
+    _lib.check(lib.wetts_durations_to_lengths(_lib.ptr(logw), _lib.ptr(x_mask), 1.0, B, Tx, _lib.ptr(w_ceil),
+                                              _lib.ptr(cum), _lib.ptr(meta), status, s), "durations_to_lengths")
+    mh = meta.cpu().numpy()
+    assert int(mh[B]) & 0xFFFFFFFF == 0
+    assert np.array_equal(w_ceil.cpu().numpy(), dur)
+    assert mh[:B].tolist() == d["y_lengths"].tolist() == [6, 1, 4, 5]
+    Ty = int(mh[:B].max())
+    I = cfg.inter_channels
+    stats = torch.randn(B, 2 * I, Tx, device=dev)
+    eps = torch.zeros(B, I, Ty, device=dev)
+    f2p = torch.empty(B, Ty, dtype=torch.int32, device=dev)
+    y_mask = torch.empty(B, Ty, device=dev)
+    attn = torch.empty(B, Ty, Tx, device=dev)
+    m_p = torch.empty(B, I, Ty, device=dev)
+    logs_p = torch.empty(B, I, Ty, device=dev)
+    z_p = torch.empty(B, I, Ty, device=dev)
+    _lib.check(lib.wetts_length_regulate(net._handle, _lib.ptr(stats), _lib.ptr(cum), _lib.ptr(x_mask),
+                                         _lib.ptr(meta), _lib.ptr(eps), I * Ty, Ty, 0.0, B, Tx, Ty, _lib.ptr(f2p),
+                                         _lib.ptr(y_mask), _lib.ptr(attn), _lib.ptr(m_p), _lib.ptr(logs_p),
+                                         _lib.ptr(z_p), s), "length_regulate")
+    ref_attn = d["attn"]  # [B,1,Ty,Tx]
+    assert np.array_equal(attn.cpu().numpy(), ref_attn[:, 0])
+    ref_mask = (np.arange(Ty)[None] < d["y_lengths"][:, None]).astype(np.float32)
+    assert np.array_equal(y_mask.cpu().numpy(), ref_mask)
+    f = f2p.cpu().numpy()
+    own = ref_attn[:, 0].argmax(-1)
+    has = ref_attn[:, 0].sum(-1) > 0
+    assert np.array_equal(f[has], own[has]) and (f[~has] == -1).all()
+    assert f[1, 0] == -1  # all-zero durations: y_length clamps to 1 and no phoneme owns that frame
+    # the prior expansion is the gather attn . m_p (models.py:262-265): frames without a phoneme get zeros
+    ref_m = torch.matmul(torch.from_numpy(ref_attn[:, 0]).to(dev), stats[:, :I].transpose(1, 2)).transpose(1, 2)
+    assert torch.equal(m_p, ref_m) and torch.equal(z_p, ref_m)  # noise_scale 0 => z_p = m_p
+
+
+def test_state_dict_reads_back_the_device_weights():
+    """state_dict() on a device model goes through wetts_get_blob: same tensors as the folded checkpoint, on the
+    module's device, and a second model built from it synthesises the same waveform."""
+    from wetts_amd import SynthesizerTrn, checkpoint, config
+    net, case, cfg, sd, W = _model("tiny_mono_post_b2")
+    out = net.state_dict()
+    assert all(v.device.type == "cuda" for v in out.values())
+    for name, *_ in checkpoint.blob_layout(cfg):
+        assert torch.equal(out[name].cpu(), W[name].to(torch.float32)), name
+    net2 = SynthesizerTrn(int(case["n_vocab"]), 513, 32, n_speakers=int(case["n_speakers"]),
+                          **config.MODEL_CONFIGS[str(case["model"])])
+    net2.load_state_dict({k: v.cpu() for k, v in out.items()}).to("cuda")
+    args = (util.t(case["x"]).cuda(), util.t(case["x_lengths"]).cuda())
+    kw = dict(sid=util.t(case["sid"]).cuda(), noise_scale=0.667, length_scale=1.0, noise_scale_w=0.8,
+              eps_w=util.t(case["eps_w"]).cuda(), eps_z=util.t(case["eps_z"]).cuda())
+    assert torch.equal(net.infer(*args, **kw)[0], net2.infer(*args, **kw)[0])
+
+
+def test_triton_min_chunk_streaming_protocol():
+    """stream_decode(min_chunk=65, chunk 70, pad 10) = the Triton twin's protocol (stream_tts/1/model.py:58-111):
+    L*hop samples; the reflect-padded last window contributes only audio of real frames; interior samples equal the
+    one-shot decode (pad 10 < receptive field, so only away from the window edges)."""
+    from wetts_amd.session import (DecoderSession, TRITON_BLOCK_SIZE, TRITON_MIN_CHUNK, TRITON_PAD_SIZE,
+                                   get_chunks_min, stream_decode)
+    net, case, cfg, *_ = _model("tiny_sdp_b3")
+    dec = DecoderSession(net)
+    sid = np.array([1], dtype=np.int64)
+    hop = net.hop_length
+    torch.manual_seed(5)
+    for L in (30, 100, 150, 211):
+        z = torch.randn(1, L, cfg.inter_channels).numpy()
+        full = dec.run(None, {"z": z, "sid": sid})[0][0, 0]
+        pieces = list(stream_decode(dec, z, sid, TRITON_BLOCK_SIZE, TRITON_PAD_SIZE, min_chunk=TRITON_MIN_CHUNK))
+        wins, pad_end = get_chunks_min(L, TRITON_BLOCK_SIZE, TRITON_PAD_SIZE, TRITON_MIN_CHUNK)
+        assert len(pieces) == len(wins)
+        cat = np.concatenate(pieces)
+        assert cat.shape == full.shape == (L * hop,)
+        err = np.abs(cat - full)
+        rf = 19  # tests/test_gpu_native.py: receptive field of the tiny generator in frames
+        interior = np.zeros(L, bool)
+        for i, (ws, we) in enumerate(wins):
+            a, b = i * TRITON_BLOCK_SIZE, min((i + 1) * TRITON_BLOCK_SIZE, L)  # frames this window emits
+            t = np.arange(a, b)
+            # the last window's reflected tail replaces the utterance's real right edge: only frames rf away from it
+            right_ok = (we - 1 - t >= rf) if (we < L or (pad_end and i == len(wins) - 1)) else np.ones_like(t, bool)
+            interior[a:b] = ((ws == 0) | (t - ws >= rf)) & right_ok
+        assert interior.any()
+        assert err.reshape(L, hop)[interior].max() < 1e-5, (L, err.reshape(L, hop)[interior].max())

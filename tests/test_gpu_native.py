@@ -1,6 +1,7 @@
 """GPU tier: a native C++ host (include/wetts_vits_model.hpp, the twin of the reference's
 runtime/core/model/vits_model.h) links libwetts_hip.so without Python / torch and reproduces the
-Python path's waveform."""
+REFERENCE's waveform for the utterance (golden tiny_sdp_b1_nonoise: B = 1, noise scales 0 -- the native host
+draws its own noise, so only a noise-free case can be compared with a reference run)."""
 import ctypes as C
 import os
 import subprocess
@@ -15,22 +16,29 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_native_vits_model_forward_and_stream(tmp_path):
-    from wetts_amd import SynthesizerTrn, build, config
+# receptive field of the "tiny" generator, one side, in input frames (decoders.py:17-82 with config.py "tiny":
+# conv_pre k7 -> 3; per stage (ups k/stride, then the widest ResBlock1: k = 7, dilations 1, 3, 5 -> 3 * (3 + 9 + 15) / ...):
+#   stage 1 (x4): ConvT k8 s4 ~1 frame, ResBlock k7: sum_d [(k-1)d/2 + (k-1)/2] = 3*(1+3+5) + 9 = 36 samples = 9 frames
+#   stage 2 (x8): ConvT k4 s2 ~0.5,   ResBlock k7: 36 samples = 4.5 frames;  conv_post k7: 3 samples
+# => 3 + 1 + 9 + 0.5 + 4.5 + 0.4 < 19 frames
+TINY_RF = 19
+
+
+@pytest.mark.parametrize("chunk,pad", [(16, 20), (16, 12), (40, 10)])
+def test_native_vits_model_forward_and_stream_vs_reference_golden(tmp_path, chunk, pad):
+    """pad >= the receptive field: EVERY streamed sample is interior (the streamed waveform equals the one-shot
+    decode and the reference golden); pad < RF (incl. the reference's defaults 40 / 10): the samples whose window
+    covers their receptive field."""
+    from wetts_amd import build
     exe = os.path.join(build.LIBDIR, "vits_model_main")
     assert os.path.exists(exe), "native test host not built (run __graft_entry__.build())"
-    case = util.load_case("tiny_sdp_nonoise")
+    case = util.load_case("tiny_sdp_b1_nonoise")
+    assert case["x"].shape[0] == 1 and tuple(case["scales"]) == (0.0, 1.0, 0.0)
     cfg, sd, W, blob = util.case_model(case)
-    net = SynthesizerTrn(int(case["n_vocab"]), 513, 32, n_speakers=int(case["n_speakers"]),
-                         **config.MODEL_CONFIGS[str(case["model"])])
-    net.load_state_dict(sd).to("cuda")
     n = int(case["x_lengths"][0])
     ph = case["x"][0, :n].astype(np.int64)
     sid = int(case["sid"][0])
-    o, *_ = net.infer(torch.from_numpy(ph)[None].cuda(), torch.tensor([n]).cuda(),
-                      sid=torch.tensor([sid]).cuda(), noise_scale=0.0, length_scale=1.0,
-                      noise_scale_w=0.0)
-    expect = o[0, 0].cpu().numpy().astype(np.float32)
+    expect = case["audio"][0, 0].astype(np.float32)  # the reference's infer() output
     path = tmp_path / "case.bin"
     with open(path, "wb") as f:
         f.write(bytes(cfg))
@@ -43,6 +51,10 @@ def test_native_vits_model_forward_and_stream(tmp_path):
         f.write(expect.tobytes())
     env = dict(os.environ, LD_LIBRARY_PATH=build.LIBDIR + ":/opt/rocm/lib:" +
                os.environ.get("LD_LIBRARY_PATH", ""))
-    r = subprocess.run([exe, str(path)], capture_output=True, text=True, env=env, timeout=300)
+    r = subprocess.run([exe, str(path), str(chunk), str(pad), str(TINY_RF)], capture_output=True, text=True,
+                       env=env, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+    if pad >= TINY_RF:  # all samples interior
+        fields = dict(kv.split("=") for kv in r.stdout.split() if "=" in kv)
+        assert float(fields["all_worst"]) < 1e-4

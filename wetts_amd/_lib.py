@@ -22,7 +22,7 @@ class WettsError(RuntimeError):
     pass
 
 
-ABI_VERSION = 6  # WETTS_ABI_VERSION of include/wetts_hip.h this binding was written against
+ABI_VERSION = 7  # WETTS_ABI_VERSION of include/wetts_hip.h this binding was written against
 
 
 class Config(C.Structure):
@@ -83,6 +83,7 @@ SIGNATURES = {
     "wetts_create": (_I32, [_CFG, _P, _I64, _P, C.POINTER(_P)]),
     "wetts_destroy": (None, [_P]),
     "wetts_hop_length": (_I32, [_P]),
+    "wetts_get_blob": (_I32, [_P, _P, _I64, _P]),
     "wetts_workspace_bytes": (_I64, [_P, _I32, _I32, _I32]),
     "wetts_speaker_embedding": (_I32, [_P, _P, _I32, _P, _P]),
     "wetts_text_encoder": (_I32, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _P]),

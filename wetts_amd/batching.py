@@ -61,17 +61,17 @@ def bucketize(sorted_lengths: Sequence[int], call_cost: float = DEFAULT_CALL_COS
     if n == 0:
         return []
     assert all(sorted_lengths[i] >= sorted_lengths[i + 1] for i in range(n - 1)), "lengths must be sorted descending"
+    import numpy as np
     mb = n if not max_batch or max_batch <= 0 else min(n, max_batch)
-    INF = float("inf")
-    best = [INF] * (n + 1)   # best[i] = cost of cutting the suffix i..n
+    best = np.full(n + 1, np.inf)   # best[i] = cost of cutting the suffix i..n
     nxt = [n] * (n + 1)
     best[n] = 0.0
-    for i in range(n - 1, -1, -1):
+    for i in range(n - 1, -1, -1):  # the inner minimisation over j is one vector op (n = thousands of utterances)
         li = max(1, int(sorted_lengths[i]))
-        for j in range(i + 1, min(n, i + mb) + 1):
-            c = (j - i) * li + call_cost + best[j]
-            if c <= best[i]:  # ties go to the LARGER bucket (equal lengths at call_cost 0 stay one bucket)
-                best[i], nxt[i] = c, j
+        hi = min(n, i + mb)
+        c = np.arange(1, hi - i + 1, dtype=np.float64) * li + call_cost + best[i + 1:hi + 1]
+        k = len(c) - 1 - int(np.argmin(c[::-1]))  # ties go to the LARGER bucket (equal lengths at call_cost 0 stay one)
+        best[i], nxt[i] = c[k], i + 1 + k
     cuts, i = [], 0
     while i < n:
         cuts.append((i, nxt[i]))

@@ -126,7 +126,10 @@ MODEL_CONFIGS["tiny_vits2_vocos"] = dict(
 MODEL_CONFIGS["tiny_mono_post"] = dict(MODEL_CONFIGS["tiny"], use_transformer_flows=True)
 MODEL_CONFIGS["tiny_mono_inter"] = dict(MODEL_CONFIGS["tiny_dp"], use_transformer_flows=True,
                                         transformer_flow_type="mono_layer_inter_residual")
-SAMPLING_RATES = {"tiny_mono_post": 22050, "tiny_mono_inter": 16000, "tiny_preconv2_spk": 22050, "vits2_v1": 22050, "vits2_vocos_v1": 24000, "tiny_vits2_vocos": 24000, "v1": 22050, "v2": 22050, "v3": 16000, "stress48k": 48000, "tiny": 22050,
+# upsample rates that are not multiples of 4 (hop 15): sample extents of a ragged batch's utterances are then
+# unaligned to the 16-byte staging of the decoder kernels (coverage config, no reference recipe)
+MODEL_CONFIGS["tiny_oddrate"] = dict(MODEL_CONFIGS["tiny"], upsample_rates=[5, 3], upsample_kernel_sizes=[9, 5])
+SAMPLING_RATES = {"tiny_oddrate": 22050, "tiny_mono_post": 22050, "tiny_mono_inter": 16000, "tiny_preconv2_spk": 22050, "vits2_v1": 22050, "vits2_vocos_v1": 24000, "tiny_vits2_vocos": 24000, "v1": 22050, "v2": 22050, "v3": 16000, "stress48k": 48000, "tiny": 22050,
                   "tiny_dp": 16000, "vocos": 16000, "tiny_vocos": 16000}
 
 

@@ -681,12 +681,9 @@ int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t 
   const float qdiv = (float)sqrt((double)dk);
   if (window >= 0 && T <= min(attn_small_max_t(), 128)) {  // 32 groups x 4 keys
     const size_t lds = attn_small_layout(T, dk, window).lds;
-    if (lds <= 150 * 1024) {
-      static bool attr_done = false;
-      if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)attn_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-      }
+    static signed char opt_in[64] = {};
+    // (a device that refuses the large-LDS opt-in takes the general path below)
+    if (lds <= 150 * 1024 && (lds <= 64 * 1024 || lds_opt_in((const void*)attn_small_kernel, opt_in))) {
       hipLaunchKernelGGL(attn_small_kernel, dim3(cdiv(T, 32), B * n_heads), dim3(1024), lds, s, q, k, v, mask,
                          emb_rel_k, emb_rel_v, window, n_heads, dk, T, qdiv, qbs, out);
       WETTS_LAUNCH_CHECK();

@@ -23,6 +23,21 @@ void set_error(const char* fmt, ...);
     }                                                                                \
   } while (0)
 
+// Opt-in for more than 64 KB of dynamic LDS, once per (kernel, device): `state` is the caller's function-local
+// `static signed char state[64]` for ONE kernel instantiation (0 = not tried, 1 = granted, -1 = refused).  Returns
+// whether the kernel may be launched with a large LDS size on the current device; a refusal is remembered and
+// leaves no sticky error behind, so callers with a smaller-footprint path can fall back to it.
+static inline bool lds_opt_in(const void* kernel, signed char* state) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (state[dev] == 0) {
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) (void)hipGetLastError();
+    state[dev] = e == hipSuccess ? 1 : -1;
+  }
+  return state[dev] > 0;
+}
+
 #define WETTS_LAUNCH_CHECK()                                                         \
   do {                                                                               \
     hipError_t _e = hipGetLastError();                                               \

@@ -227,11 +227,10 @@ bool dds_fused_supported(int mode, int C, int Cw, int nchunks, int B, int T) {
 template <int NW>
 static int32_t launch_dds(const DdsFusedParams& p, hipStream_t s) {
   const size_t lds = ((size_t)2 * p.C * NW + kDdsCG * (NW + 1) + NW + (size_t)27 * p.C) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    WETTS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dds_fused_kernel<NW>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+  static signed char opt_in[64] = {};
+  if (lds > 64 * 1024 && !lds_opt_in(reinterpret_cast<const void*>(&dds_fused_kernel<NW>), opt_in)) {
+    set_error("dds_fused_kernel: the device refused the %zu-byte dynamic LDS opt-in", lds);
+    return WETTS_E_HIP;
   }
   hipLaunchKernelGGL(dds_fused_kernel<NW>, dim3(cdiv(p.T, NW - 2 * kDdsHalo), p.B), dim3(NW * kDdsCG), lds, s, p);
   WETTS_LAUNCH_CHECK();

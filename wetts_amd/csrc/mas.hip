@@ -242,17 +242,18 @@ int32_t k_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, i
   while (C * 64 < Tx) C *= 2;
   const int R = C <= 32 ? 32 / C : 0;
   const size_t wave_lds = R ? ((size_t)((Ty + 4 * R - 1) / (4 * R)) * 4 * 64 * 4 + (size_t)Ty * 2 + 16) : 0;
-  const bool fast = C <= 16 && wave_lds <= 150 * 1024 && Ty < 0xFFFF && Tx < 0xFFFF;
-  if (fast) {
-    static bool attr_done = false;
-    if (!attr_done) {  // > 64 KB of dynamic LDS needs the opt-in
-      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)mas_wave_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_done = true;
+  bool fast = C <= 16 && wave_lds <= 150 * 1024 && Ty < 0xFFFF && Tx < 0xFFFF;
+  if (fast && wave_lds > 64 * 1024) {  // > 64 KB of dynamic LDS needs the opt-in, per device; refused => plain kernel
+    static signed char opt_in[5][64] = {};
+    switch (C) {
+      case 1: fast = lds_opt_in((const void*)mas_wave_kernel<1>, opt_in[0]); break;
+      case 2: fast = lds_opt_in((const void*)mas_wave_kernel<2>, opt_in[1]); break;
+      case 4: fast = lds_opt_in((const void*)mas_wave_kernel<4>, opt_in[2]); break;
+      case 8: fast = lds_opt_in((const void*)mas_wave_kernel<8>, opt_in[3]); break;
+      default: fast = lds_opt_in((const void*)mas_wave_kernel<16>, opt_in[4]); break;
     }
+  }
+  if (fast) {
     switch (C) {
       case 1: launch_mas_wave<1>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;
       case 2: launch_mas_wave<2>(neg_cent, t_ys, t_xs, B, Ty, Tx, path, wave_lds, s); break;

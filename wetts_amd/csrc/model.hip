@@ -991,6 +991,15 @@ void wetts_destroy(wetts_model_t* m) {
 
 int32_t wetts_hop_length(const wetts_model_t* m) { return m ? m->hop : WETTS_E_INVALID; }
 
+int32_t wetts_get_blob(const wetts_model_t* m, float* out_dev, int64_t numel, void* stream) {
+  WETTS_REQUIRE(m && out_dev, "null argument");
+  WETTS_REQUIRE(numel == m->layout.total, "blob has %lld floats, asked for %lld", (long long)m->layout.total,
+                (long long)numel);
+  WETTS_HIP_CHECK(hipMemcpyAsync(out_dev, m->blob, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice,
+                                 (hipStream_t)stream));
+  return WETTS_OK;
+}
+
 int64_t wetts_workspace_bytes(const wetts_model_t* m, int32_t B, int32_t Tx, int32_t Ty) {
   if (!m || B < 0 || Tx < 0 || Ty < 0) return WETTS_E_INVALID;
   const wetts_config_t* c = &m->cfg;

@@ -8,7 +8,11 @@ test-file line: `wav_path|speaker|ph ph ph ...` (inference.py:83-85); tables are
 (inference.py:55-64).  Writes outdir/basename(wav_path) as int16 at hps.data.sampling_rate with
 the reference's peak normalisation (inference.py:100-110).  Extra: --batch N plans the whole test file into
 length-sorted padded sub-batches of at most N utterances (wetts_amd/batching.py; the reference loops one utterance
-at a time) and writes the files in the order of the test file."""
+at a time).  Sub-batches are synthesised longest first; the wavs are written and their paths printed in the order
+of the test file, each as soon as every line before it is done (with --batch 1 that is the reference's own
+interleaving of path and RTF lines).
+--decode selects what a batched utterance's audio is: `ragged` = what the reference's one-at-a-time loop gives
+for it (default where the model supports it), `padded` = what its infer() returns inside the padded sub-batch."""
 import argparse
 import sys
 import time
@@ -34,6 +38,9 @@ def get_args(argv=None):
                         help="largest padded sub-batch per infer() call (1 = the reference's loop)")
     parser.add_argument("--max_pad_frac", type=float, default=0.08,
                         help="padding share the sub-batch plan may spend (with --batch > 1)")
+    parser.add_argument("--decode", choices=["auto", "padded", "ragged"], default="auto",
+                        help="with --batch > 1: decode every utterance over its own frames (ragged; auto = when "
+                             "the model supports it) or the whole padded sub-batch like infer() (padded)")
     parser.add_argument("--seed", type=int, default=None, help="seed for the sampling noise")
     return parser.parse_args(argv)
 
@@ -85,27 +92,32 @@ def main(argv=None):
         # utterances with a bounded padding share (wetts_amd/batching.py), written back in file order
         # ragged decode where the model supports it: every utterance's audio is then what the one-at-a-time loop
         # of the reference CLI produces for it, whatever it is batched with
-        ragged = net_g.ragged_supported()
+        ragged = net_g.ragged_supported() if args.decode == "auto" else args.decode == "ragged"
+        if ragged and not net_g.ragged_supported():
+            raise SystemExit("--decode ragged: this model's decoder has no ragged mode (float32 ResBlock1 HiFi-GAN only)")
         buckets = batching.plan([len(s) for s in seqs], 1, max_pad_frac=args.max_pad_frac,
                                 max_batch=args.batch, ragged=ragged).buckets[0]
+    pending = {}  # file index -> pcm, flushed in test-file order
+    nxt = 0
     for bk in buckets:
         st = time.time()
         audio = batching.synthesize(net_g, seqs, sids, noise_scale=0.667, noise_scale_w=0.8, length_scale=1,
                                     buckets=[bk], ragged=ragged)
         n_total = 0
-        pcms = []
         for i in bk.indices:
             a = audio[i].reshape(1, -1)
-            pcms.append((i, net_g.audio_to_int16(a).cpu().numpy()[0]))  # per-utterance peak normalisation (:100-110)
+            pending[i] = net_g.audio_to_int16(a).cpu().numpy()[0]  # per-utterance peak normalisation (:100-110)
             n_total += a.shape[1]
         torch.cuda.synchronize()
         dt = time.time() - st
-        for i, pcm in pcms:
-            audio_path = lines[i][0]
+        while nxt in pending:  # everything up to the first utterance still outstanding
+            audio_path = lines[nxt][0]
             print(audio_path)
-            wavfile.write(args.outdir + "/" + audio_path.split("/")[-1], sr, pcm.astype(np.int16))
+            wavfile.write(args.outdir + "/" + audio_path.split("/")[-1], sr, pending.pop(nxt).astype(np.int16))
+            nxt += 1
         print("RTF {}".format(dt / (float(n_total) / sr)))
         sys.stdout.flush()
+    assert not pending and nxt == len(lines)
 
 
 if __name__ == "__main__":

@@ -144,6 +144,26 @@ class SynthesizerTrn:
             self._create()
         return self
 
+    def state_dict(self):
+        """The module's tensors under the reference's `state_dict()` keys (utils/task.py:59-76 saves
+        `model.state_dict()`), read back from the model's own memory.  Weight-norm pairs are stored folded, so
+        `dec.ups.0.weight` stands where the reference has `weight_g` / `weight_v` -- the spelling
+        `remove_weight_norm()` leaves (decoders.py:84-88) and `load_state_dict` accepts.  Tensors live on the
+        module's device (views of one blob), like nn.Module.state_dict()."""
+        from collections import OrderedDict
+        n = checkpoint.blob_numel(self.cfg)
+        if self._handle is not None:
+            blob = torch.empty(n, dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.load().wetts_get_blob(self._handle, _lib.ptr(blob), n, _lib.current_stream_ptr()),
+                           "get_blob")
+        elif self._blob is not None:
+            blob = self._blob
+        else:
+            raise _lib.WettsError("no weights loaded: call load_state_dict(...) first")
+        return OrderedDict((name, blob[off:off + numel].view(shape))
+                           for name, off, numel, shape in checkpoint.blob_layout(self.cfg))
+
     def load_blob(self, blob):
         """Adopts an already packed float32 blob (CPU or device tensor), e.g. after a broadcast."""
         n = checkpoint.blob_numel(self.cfg)

@@ -224,12 +224,62 @@ def depad_bounds(chunk_num, chunk_id, block, pad, upsample, n_samples):
     return front * upsample, (front + block) * upsample
 
 
-def stream_decode(decoder, z, sid, chunk_size=40, pad_size=10):
+# The Triton streaming twin (runtime/cpu_triton_stream/model_repo/stream_tts/1/model.py:11-14,58-111) adds a minimum
+# window: MIN_CHUNK = 65 frames, VOC_BLOCK_SIZE = 70, VOC_PAD_SIZE = 10.  A last window shorter than MIN_CHUNK is
+# reflect-padded at its end (np.pad mode="reflect" along the frame axis, :82-84) and the audio decoded from those
+# `pad_end` frames is cut off again (:103-106).
+TRITON_MIN_CHUNK, TRITON_BLOCK_SIZE, TRITON_PAD_SIZE = 65, 70, 10
+
+
+def get_chunks_min(mel_len, block_size, pad_size, min_chunk=TRITON_MIN_CHUNK):
+    """stream_tts/1/model.py:58-86: ([(window_start, window_end)], pad_end) -- the windows of get_chunks plus the
+    number of reflected frames the LAST window is extended by (None when it already has min_chunk frames).
+    block_size == -1 => the reference returns the bare list `[mel]`; here ([(0, L)], None)."""
+    if block_size == -1:
+        return [(0, mel_len)], None
+    wins = [(max(0, i - pad_size), min(i + block_size + pad_size, mel_len)) for i in range(0, mel_len, block_size)]
+    pad_end = None
+    if wins and wins[-1][1] - wins[-1][0] < min_chunk:
+        pad_end = min_chunk - (wins[-1][1] - wins[-1][0])
+    return wins, pad_end
+
+
+def depad_bounds_min(chunk_num, chunk_id, block, pad, upsample, n_samples, pad_end):
+    """Sample range to keep of a window decoded under the min-chunk protocol (depadding,
+    stream_tts/1/model.py:89-111): as depad_bounds, except that the last window drops `pad_end * upsample`
+    samples at its end.  Two behaviours of the reference are NOT reproduced, because they are crashes, not
+    results: a last window that needed no padding (pad_end None) with chunk_num > 1 raises TypeError there
+    (`-pad_end * upsample`, :105) -- here the window's tail is kept, as the two other streaming clients do; a
+    single window (chunk_id 0 is also the last) keeps `block * upsample` samples there, which includes audio
+    decoded from reflected frames when L < block -- here it is clipped to the samples of real frames."""
+    front = min(chunk_id * block, pad)
+    real = n_samples - (pad_end or 0) * upsample  # samples decoded from real (not reflected) frames
+    if chunk_id == 0:
+        return 0, min(real, block * upsample)
+    if chunk_id == chunk_num - 1:
+        return front * upsample, real
+    return front * upsample, (front + block) * upsample
+
+
+def stream_decode(decoder, z, sid, chunk_size=40, pad_size=10, min_chunk=None):
     """Decodes z [1,L,C] window by window with overlap-discard; yields float32 audio pieces
-    (numpy) whose concatenation has L*hop samples.  `decoder` is a DecoderSession."""
+    (numpy) whose concatenation has L*hop samples.  `decoder` is a DecoderSession.
+
+    `min_chunk` (e.g. TRITON_MIN_CHUNK with chunk_size=TRITON_BLOCK_SIZE, pad_size=TRITON_PAD_SIZE) selects the
+    Triton twin's protocol: a short last window is reflect-padded to min_chunk frames before it is decoded."""
     hop = decoder.model.hop_length
-    wins = get_chunks(z.shape[1], chunk_size, pad_size)
+    if min_chunk is None:
+        wins, pad_end = get_chunks(z.shape[1], chunk_size, pad_size), None
+    else:
+        wins, pad_end = get_chunks_min(z.shape[1], chunk_size, pad_size, min_chunk)
     for i, (ws, we) in enumerate(wins):
-        out = decoder.run(None, {"z": z[:, ws:we], "sid": sid})[0].reshape(1, -1)
-        a, b = depad_bounds(len(wins), i, chunk_size, pad_size, hop, out.shape[1])
+        zw = z[:, ws:we]
+        last_pad = pad_end if (pad_end and i == len(wins) - 1) else None
+        if last_pad:  # the same numpy call as the reference, on the frame axis of [1, L, C]
+            zw = np.pad(np.asarray(zw), ((0, 0), (0, last_pad), (0, 0)), mode="reflect")
+        out = decoder.run(None, {"z": zw, "sid": sid})[0].reshape(1, -1)
+        if min_chunk is None:
+            a, b = depad_bounds(len(wins), i, chunk_size, pad_size, hop, out.shape[1])
+        else:
+            a, b = depad_bounds_min(len(wins), i, chunk_size, pad_size, hop, out.shape[1], last_pad)
         yield out[0, a:b]
