@@ -168,6 +168,10 @@ void free_packed(PackedConv* pc);
 
 // Launches the conv.  Fills geometry fields of `p` from `pc`; caller fills the I/O fields.
 int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream);
+// Pointwise (1x1, plain input) convs as an LDS-DMA GEMM with strip scheduling (gemm_pw.hip); launch_conv routes
+// eligible launches there.  variant: 0 = production choice, 7 / 8 / 9 = forced stage shapes (micro-benchmarks)
+bool pw_gemm_eligible(const PackedConv& pc, const ConvParams& p);
+int32_t launch_pw_gemm(const PackedConv& pc, const ConvParams& p, hipStream_t stream, int variant);
 // n independent convs of one shape class in ONE launch where that is possible (conv_mfma.hip), else n launches
 // (*launches = how many kernels went out)
 int32_t launch_conv_group(const PackedConv* const* pcs, const ConvParams* ps, int n, hipStream_t stream,

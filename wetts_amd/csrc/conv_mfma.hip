@@ -734,6 +734,11 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
     WETTS_TRY(launch_conv_small(p, stream, &taken));
     if (taken) return WETTS_OK;
   }
+  // 1x1 convs with a plain input: the LDS-DMA GEMM with strip scheduling (gemm_pw.hip)
+  {
+    const int v = conv_variant();
+    if ((v == 0 || (v >= 7 && v <= 9)) && pw_gemm_eligible(pc, p)) return launch_pw_gemm(pc, p, stream, v);
+  }
   // tile selection: fill the chip first, then maximise per-wave register reuse
   const int64_t cols = (int64_t)p.N * p.B;
   // 1x4 wave tiles (one A fragment feeds four B fragments) measured 2-3 % faster than 2x2 at
