@@ -110,6 +110,10 @@ struct ConvParams {
   float out_div;         // final true division (MRF mean: xs / num_kernels), 1 = none
   int B;
   int tag;               // 1: MRF ResBlock launch (separate kernel symbol for profiles)
+  // 1: the caller guarantees that the input rows Cin .. ceil16(Cin) - 1 of every batch item exist and hold finite
+  // values (they meet the zero tail of the packed weights): lets a reduction that is not a multiple of 16 channels
+  // take the LDS-DMA GEMM (gemm_pw.hip), whose stages are whole 16-channel chunks
+  int k_rows_padded;
   // ragged batch (wetts_hifigan_ragged): utterance b's input holds lens[b] * len_mul time steps -- it is
   // convolved as if it were alone (zero padding at ITS end) -- while Tin / Tout / N stay the dense row
   // geometry of the tensors; blocks whose tile starts behind an utterance's end exit at once.  null = dense.

@@ -264,10 +264,11 @@ bool pw_gemm_eligible(const PackedConv& pc, const ConvParams& p) {
   if (p.res && (p.out_act != OUT_NONE || p.out_mask)) return false;  // the residual is folded into the accumulator init
   if (p.res && (pc.M % 128) != 0) return false;  // ... by loads without a row predicate: whole m-tiles only
   if ((int64_t)pc.M * p.o_cs * 4 >= (1ll << 31) || (p.res && (int64_t)pc.M * p.r_cs * 4 >= (1ll << 31))) return false;
-  if ((pc.Cin % 16) != 0 || pc.Cin < 32) return false;
+  if (((pc.Cin % 16) != 0 && !p.k_rows_padded) || pc.Cin < 32) return false;
   if ((p.x_cs & 3) != 0 || (p.x_bs & 3) != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0) return false;
   if (p.Tin > p.x_cs || p.x_cs < 4 || p.Tout != p.Tin) return false;
-  if ((int64_t)pc.Cin * p.x_cs * 4 >= (1ll << 31)) return false;
+  if ((int64_t)pc.nchunks * 16 * p.x_cs * 4 >= (1ll << 31)) return false;
+  if (p.k_rows_padded && p.x_bs < (int64_t)pc.nchunks * 16 * p.x_cs) return false;
   return true;
 }
 
@@ -321,7 +322,7 @@ int32_t launch_pw_gemm(const PackedConv& pc, const ConvParams& cp, hipStream_t s
   p.x = cp.x;
   p.x_bs = cp.x_bs;
   p.x_cs = (int)cp.x_cs;
-  p.K = pc.Cin;
+  p.K = pc.nchunks * 16;  // == Cin, or Cin rounded up over the caller's padded rows (ConvParams.k_rows_padded)
   p.N = cp.Tout;
   p.wpk = pc.wpk;
   p.G = pc.nchunks * 2;

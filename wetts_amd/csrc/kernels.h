@@ -30,8 +30,9 @@ struct DdsFusedParams {
 };
 bool dds_fused_supported(int mode, int C, int Cw, int nchunks, int B, int T);
 int32_t k_dds_fused(DdsFusedParams p, hipStream_t s);
+// Tvalid (> 0): zero padding starts at column Tvalid of a row whose stride is T (rows padded to 4 columns)
 int32_t k_dwconv(const float* x, const float* mask, const float* w, const float* bias, int k,
-                 int dil, int B, int C, int T, float* out, hipStream_t s);
+                 int dil, int B, int C, int T, float* out, hipStream_t s, int Tvalid = 0);
 
 // out[b,c] = bias[c] + sum_k W[c,k] * g[b,k]   (every `cond`/`cond_layer` 1x1 conv on g[B,gin,1])
 int32_t k_cond_linear(const float* g, const float* W, const float* bias, int B, int Cout, int K,
@@ -99,17 +100,20 @@ int32_t k_audio_to_int16(const float* audio, const int64_t* lengths, int B, int6
 
 // ---- VocosGenerator (decoders.py:251-308) ---------------------------------------------------
 // ReflectionPad1d([1,0]) of (z * y_mask)[:, :, :L]: out [B,C,L+1], out[..,0] = in[..,1]
+//   Fs (>= L + 1): row stride of out, columns L + 1 .. Fs - 1 zero-filled
 int32_t k_vocos_pad(const float* z, int64_t z_bs, int64_t z_cs, const float* mask,
-                    int64_t mask_stride, int B, int C, int L, float* out, hipStream_t s);
+                    int64_t mask_stride, int B, int C, int L, float* out, hipStream_t s, int Fs = 0);
 // spec [B, 2*half, F] (log-magnitude rows then phase rows) -> [B, 2*half, F] real rows then
 // imaginary rows of  min(exp(mag), 1e2) * (cos(phase) + i sin(phase))   (decoders.py:297-303)
-int32_t k_vocos_spec(const float* spec, int B, int half, int F, float* ri, hipStream_t s);
+//   ri_bs: batch stride of ri (rows beyond 2 * half are the caller's padding of the iSTFT GEMM's reduction)
+int32_t k_vocos_spec(const float* spec, int B, int half, int F, float* ri, hipStream_t s, int64_t ri_bs = 0);
 // windowed inverse-rDFT basis as a 1x1 conv weight [n_fft][2*half]: frame[n] = hann[n] * irfft(S)[n]
 int32_t k_istft_basis(int n_fft, float* w, hipStream_t s);
 // overlap-add + window-envelope normalisation + centre trim of torch.istft (center=True):
 // frames [B, n_fft, F] -> audio [B, (F-1)*hop]
+//   Fs: row stride of frames (>= F)
 int32_t k_istft_ola(const float* frames, int B, int n_fft, int hop, int F, float* audio,
-                    hipStream_t s);
+                    hipStream_t s, int Fs = 0);
 // out[r, :] = a[r, :] * scale[r]   (rows x cols), folds ConvNeXtLayer.scale into pw_conv2
 int32_t k_scale_rows(const float* a, const float* scale, int rows, int cols, float* out,
                      hipStream_t s);
@@ -124,6 +128,9 @@ int32_t k_mono_split(const float* x, const float* mask, int B, int C, int T, flo
                      hipStream_t s);
 int32_t k_mono_coupling(const float* x, const float* m, const float* mask, int B, int C, int T, float sc, float* out,
                         hipStream_t s);
+// rows re-strided: dst[r][c] = c < cols_src ? src[r][c] : 0, c < cols_dst
+int32_t k_copy_rows(const float* src, int64_t src_stride, int cols_src, float* dst, int64_t dst_stride, int cols_dst,
+                    int64_t rows, hipStream_t s);
 // out = a + b (out may alias a)
 int32_t k_add(const float* a, const float* b, int64_t n, float* out, hipStream_t s);
 

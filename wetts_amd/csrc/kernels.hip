@@ -204,9 +204,11 @@ int32_t k_layernorm(const float* a, const float* add, const float* gamma, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tv: the valid length of a row (zero padding starts there); T: the row stride.  Tv < T for the ConvNeXt stack, whose
+// rows are padded to a multiple of 4 columns (columns >= Tv hold finite junk that must not leak into column Tv - 1)
 __global__ void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ mask,
                               const float* __restrict__ w, const float* __restrict__ bias, int k,
-                              int dil, int B, int C, int T, float* __restrict__ out) {
+                              int dil, int B, int C, int T, int Tv, float* __restrict__ out) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t total = (int64_t)B * C * T;
   if (idx >= total) return;
@@ -219,17 +221,17 @@ __global__ void dwconv_kernel(const float* __restrict__ x, const float* __restri
   float acc = bias[c];
   for (int j = 0; j < k; ++j) {
     int tt = t + j * dil - pad;
-    if (tt >= 0 && tt < T) acc += w[c * k + j] * (mr ? xr[tt] * mr[tt] : xr[tt]);
+    if (tt >= 0 && tt < Tv) acc += w[c * k + j] * (mr ? xr[tt] * mr[tt] : xr[tt]);
   }
   out[idx] = acc;
 }
 
 int32_t k_dwconv(const float* x, const float* mask, const float* w, const float* bias, int k,
-                 int dil, int B, int C, int T, float* out, hipStream_t s) {
+                 int dil, int B, int C, int T, float* out, hipStream_t s, int Tvalid) {
   int64_t n = (int64_t)B * C * T;
   if (n == 0) return WETTS_OK;
   hipLaunchKernelGGL(dwconv_kernel, grid1d(n, 256), dim3(256), 0, s, x, mask, w, bias, k, dil, B,
-                     C, T, out);
+                     C, T, Tvalid > 0 ? Tvalid : T, out);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -838,48 +840,53 @@ int32_t k_audio_to_int16(const float* audio, const int64_t* lengths, int B, int6
 // ---------------------------------------------------------------------------------------------
 __global__ void vocos_pad_kernel(const float* __restrict__ z, int64_t z_bs, int64_t z_cs,
                                  const float* __restrict__ mask, int64_t mask_stride, int B, int C,
-                                 int L, float* __restrict__ out) {
+                                 int L, int Fs, float* __restrict__ out) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int F = L + 1;
-  if (idx >= (int64_t)B * C * F) return;
-  const int f = (int)(idx % F);
-  const int c = (int)((idx / F) % C);
-  const int b = (int)(idx / ((int64_t)F * C));
-  const int t = f == 0 ? 1 : f - 1;  // reflect: padded[0] = x[1]
-  float v = z[(int64_t)b * z_bs + (int64_t)c * z_cs + t];
-  if (mask) v *= mask[(int64_t)b * mask_stride + t];
+  if (idx >= (int64_t)B * C * Fs) return;
+  const int f = (int)(idx % Fs);
+  const int c = (int)((idx / Fs) % C);
+  const int b = (int)(idx / ((int64_t)Fs * C));
+  float v = 0.f;  // columns F .. Fs - 1: row padding (kept finite)
+  if (f < F) {
+    const int t = f == 0 ? 1 : f - 1;  // reflect: padded[0] = x[1]
+    v = z[(int64_t)b * z_bs + (int64_t)c * z_cs + t];
+    if (mask) v *= mask[(int64_t)b * mask_stride + t];
+  }
   out[idx] = v;
 }
 
 int32_t k_vocos_pad(const float* z, int64_t z_bs, int64_t z_cs, const float* mask,
-                    int64_t mask_stride, int B, int C, int L, float* out, hipStream_t s) {
-  int64_t n = (int64_t)B * C * (L + 1);
+                    int64_t mask_stride, int B, int C, int L, float* out, hipStream_t s, int Fs) {
+  if (Fs <= 0) Fs = L + 1;
+  int64_t n = (int64_t)B * C * Fs;
   if (n == 0) return WETTS_OK;
   hipLaunchKernelGGL(vocos_pad_kernel, grid1d(n, 256), dim3(256), 0, s, z, z_bs, z_cs, mask,
-                     mask_stride, B, C, L, out);
+                     mask_stride, B, C, L, Fs, out);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
 
-__global__ void vocos_spec_kernel(const float* __restrict__ spec, int B, int half, int F,
+__global__ void vocos_spec_kernel(const float* __restrict__ spec, int B, int half, int F, int64_t ri_bs,
                                   float* __restrict__ ri) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)B * half * F) return;
   const int f = (int)(idx % F);
   const int k = (int)((idx / F) % half);
   const int b = (int)(idx / ((int64_t)F * half));
-  const int64_t base = (int64_t)b * 2 * half * F;
+  const int64_t base = (int64_t)b * 2 * half * F, obase = (int64_t)b * ri_bs;
   const float lm = spec[base + (int64_t)k * F + f];
   const float ph = spec[base + (int64_t)(half + k) * F + f];
   const float mag = fminf(expf(lm), 1e2f);  // mag.exp().clamp_max(1e2)
-  ri[base + (int64_t)k * F + f] = mag * cosf(ph);
-  ri[base + (int64_t)(half + k) * F + f] = mag * sinf(ph);
+  ri[obase + (int64_t)k * F + f] = mag * cosf(ph);
+  ri[obase + (int64_t)(half + k) * F + f] = mag * sinf(ph);
 }
 
-int32_t k_vocos_spec(const float* spec, int B, int half, int F, float* ri, hipStream_t s) {
+int32_t k_vocos_spec(const float* spec, int B, int half, int F, float* ri, hipStream_t s, int64_t ri_bs) {
   int64_t n = (int64_t)B * half * F;
   if (n == 0) return WETTS_OK;
-  hipLaunchKernelGGL(vocos_spec_kernel, grid1d(n, 256), dim3(256), 0, s, spec, B, half, F, ri);
+  if (ri_bs <= 0) ri_bs = (int64_t)2 * half * F;
+  hipLaunchKernelGGL(vocos_spec_kernel, grid1d(n, 256), dim3(256), 0, s, spec, B, half, F, ri_bs, ri);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -910,7 +917,7 @@ int32_t k_istft_basis(int n_fft, float* w, hipStream_t s) {
   return WETTS_OK;
 }
 
-__global__ void istft_ola_kernel(const float* __restrict__ frames, int B, int n_fft, int hop, int F,
+__global__ void istft_ola_kernel(const float* __restrict__ frames, int B, int n_fft, int hop, int F, int Fs,
                                  float* __restrict__ audio) {
   const int64_t Ls = (int64_t)(F - 1) * hop;
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -922,12 +929,12 @@ __global__ void istft_ola_kernel(const float* __restrict__ frames, int B, int n_
   if (f_hi > F - 1) f_hi = F - 1;
   int64_t f_lo = (m - n_fft + hop) / hop;  // ceil((m - n_fft + 1) / hop) for m - n_fft + 1 > 0
   if (m - n_fft + 1 <= 0) f_lo = 0;
-  const float* fb = frames + (int64_t)b * n_fft * F;
+  const float* fb = frames + (int64_t)b * n_fft * Fs;
   const float pi2 = 6.283185307179586f;
   float y = 0.f, env = 0.f;
   for (int64_t f = f_lo; f <= f_hi; ++f) {
     const int j = (int)(m - f * hop);  // 0 <= j < n_fft
-    y += fb[(int64_t)j * F + f];
+    y += fb[(int64_t)j * Fs + f];
     const float wv = 0.5f - 0.5f * cosf(pi2 * (float)j / (float)n_fft);
     env += wv * wv;
   }
@@ -935,11 +942,11 @@ __global__ void istft_ola_kernel(const float* __restrict__ frames, int B, int n_
 }
 
 int32_t k_istft_ola(const float* frames, int B, int n_fft, int hop, int F, float* audio,
-                    hipStream_t s) {
+                    hipStream_t s, int Fs) {
   int64_t n = (int64_t)B * (F - 1) * hop;
   if (n <= 0) return WETTS_OK;
   hipLaunchKernelGGL(istft_ola_kernel, grid1d(n, 256), dim3(256), 0, s, frames, B, n_fft, hop, F,
-                     audio);
+                     Fs > 0 ? Fs : F, audio);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -1029,6 +1036,27 @@ int32_t k_mono_coupling(const float* x, const float* m, const float* mask, int B
   int64_t n = (int64_t)B * C * T;
   if (n == 0) return WETTS_OK;
   hipLaunchKernelGGL(mono_coupling_kernel, grid1d(n, 256), dim3(256), 0, s, x, m, mask, B, C, T, sc, out);
+  WETTS_LAUNCH_CHECK();
+  return WETTS_OK;
+}
+
+// dst[r][c] = c < cols_src ? src[r][c] : 0 for c < cols_dst: rows re-strided (padded to a multiple of 4 columns
+// on the way in, trimmed on the way out)
+__global__ void copy_rows_kernel(const float* __restrict__ src, int64_t src_stride, int cols_src,
+                                 float* __restrict__ dst, int64_t dst_stride, int cols_dst, int64_t rows) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols_dst) return;
+  const int c = (int)(idx % cols_dst);
+  const int64_t r = idx / cols_dst;
+  dst[r * dst_stride + c] = c < cols_src ? src[r * src_stride + c] : 0.f;
+}
+
+int32_t k_copy_rows(const float* src, int64_t src_stride, int cols_src, float* dst, int64_t dst_stride, int cols_dst,
+                    int64_t rows, hipStream_t s) {
+  int64_t n = rows * cols_dst;
+  if (n == 0) return WETTS_OK;
+  hipLaunchKernelGGL(copy_rows_kernel, grid1d(n, 256), dim3(256), 0, s, src, src_stride, cols_src, dst, dst_stride,
+                     cols_dst, rows);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

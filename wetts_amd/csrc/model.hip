@@ -790,9 +790,10 @@ static int64_t ws_dp(const wetts_config_t* c, int B, int Tx) {
   return A256(B * H * Tx) + 2 * A256(B * Fd * Tx) + A256(B * H);
 }
 
-static int64_t ws_flow(const wetts_config_t* c, int B, int Ty) {
+static int64_t ws_flow(const wetts_config_t* c, int B, int Ty_) {
   const int64_t H = c->hidden_channels, I = c->inter_channels;
-  int64_t n = 2 * A256(B * I * Ty) + 3 * A256(B * H * Ty) + 2 * A256(B * 2 * H * Ty) +
+  const int64_t Ty = ((int64_t)Ty_ + 3) & ~3ll;  // rows padded to 4 frames (see wetts_flow_reverse)
+  int64_t n = 3 * A256(B * I * Ty) + A256(B * Ty) + 3 * A256(B * H * Ty) + 2 * A256(B * 2 * H * Ty) +
               A256(B * (I / 2) * Ty) + A256(B * 2 * H * c->flow_wn_layers);
   // 16-bit WN mode: channel-last h, gate output (H), in_layer / res_skip outputs (2H) at 16 bit,
   // the skip sum at f32 channel-last
@@ -819,10 +820,15 @@ static int64_t dec_max_elems(const wetts_config_t* c, int B, int L) {
   return mx;
 }
 
+// The ConvNeXt stack keeps its rows padded to a multiple of 4 frames (16-byte rows: the LDS-DMA GEMM of gemm_pw.hip
+// and 16-byte staging need that), and the iSTFT GEMM's input has its n_fft + 2 rows padded to a multiple of 16.
+static int64_t vocos_fs(int L) { return ((int64_t)L + 1 + 3) & ~3ll; }
+static int64_t vocos_rows(const wetts_config_t* c) { return ((int64_t)c->istft_n_fft + 2 + 15) & ~15ll; }
+
 static int64_t ws_vocos(const wetts_config_t* c, int B, int L) {
-  const int64_t F = L + 1, VC = c->vocos_channels, VH = c->vocos_h_channels, NF = c->istft_n_fft;
+  const int64_t F = vocos_fs(L), VC = c->vocos_channels, VH = c->vocos_h_channels, NF = c->istft_n_fft;
   return A256(B * c->inter_channels * F) + 3 * A256(B * VC * F) + A256(B * VH * F) +
-         2 * A256(B * (NF + 2) * F) + A256(B * NF * F) + A256(B * VC);
+         A256(B * (NF + 2) * F) + A256(B * vocos_rows(c) * F) + A256(B * NF * F) + A256(B * VC);
 }
 
 static int64_t ws_decoder(const wetts_config_t* c, int B, int L) {
@@ -1399,16 +1405,25 @@ int32_t wetts_set_flow_precision(const wetts_model_t* m, int32_t precision) {
   return WETTS_OK;
 }
 
-int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float* y_mask,
-                           const float* g, int32_t B, int32_t Ty, float* z_out, void* workspace,
+int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p_in, const float* y_mask_in,
+                           const float* g, int32_t B, int32_t Ty_in, float* z_out_user, void* workspace,
                            int64_t workspace_bytes, void* stream) {
-  WETTS_REQUIRE(m && z_p && y_mask && z_out, "null argument");
+  WETTS_REQUIRE(m && z_p_in && y_mask_in && z_out_user, "null argument");
   SmallConvScope small_scope(m->small_max_tiles);
-  if (B == 0 || Ty == 0) return WETTS_OK;
+  if (B == 0 || Ty_in == 0) return WETTS_OK;
   hipStream_t s = (hipStream_t)stream;
   const wetts_config_t* c = &m->cfg;
   const int H = c->hidden_channels, I = c->inter_channels, NL = c->flow_wn_layers;
   Bump ws(workspace, workspace_bytes);
+  // The flow works on rows of Ty = Ty_in rounded up to a multiple of 4 frames: every internal tensor then has
+  // 16-byte rows (LDS-DMA GEMM for the 1x1 convs, 16-byte staging for the k = 5 convs).  The extra frames are
+  // frames with mask 0 -- exactly what a shorter utterance's tail is in a padded batch: every masked tensor is zero
+  // there and the un-masked ones (gate output, skip sum) only feed 1x1 convs or masked inputs.  When Ty_in is not a
+  // multiple of 4, z_p and the mask are copied into padded rows first and z is copied out at the end.
+  const int Ty = (Ty_in + 3) & ~3;
+  const bool repad = Ty != Ty_in;
+  float* zp_pad = ws.take<float>(repad ? (int64_t)B * I * Ty : 0);
+  float* mask_pad = ws.take<float>(repad ? (int64_t)B * Ty : 0);
   float* xa = ws.take<float>((int64_t)B * I * Ty);
   float* xb = ws.take<float>((int64_t)B * I * Ty);
   float* h = ws.take<float>((int64_t)B * H * Ty);
@@ -1441,6 +1456,15 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
     set_error("flow_reverse: workspace too small");
     return WETTS_E_WORKSPACE;
   }
+  const float* z_p = z_p_in;
+  const float* y_mask = y_mask_in;
+  float* z_out = z_out_user;
+  if (repad) {
+    WETTS_TRY(k_copy_rows(z_p_in, Ty_in, Ty_in, zp_pad, Ty, Ty, (int64_t)B * I, s));
+    WETTS_TRY(k_copy_rows(y_mask_in, Ty_in, Ty_in, mask_pad, Ty, Ty, B, s));
+    z_p = zp_pad;
+    y_mask = mask_pad;
+  }
   const float* cur = z_p;
   for (int f = c->flow_n_flows - 1; f >= 0; --f) {
     const FlowW& fw = m->flows[f];
@@ -1464,7 +1488,7 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
       WETTS_TRY(k_mono_coupling(cur, mm, y_mask, B, I, Ty, sc, mdst, s));
       cur = mdst;
     }
-    float* dst = (f == 0) ? z_out : ((cur == xa) ? xb : xa);
+    float* dst = (f == 0 && !repad) ? z_out : ((cur == xa) ? xb : xa);
     // Flip then ResidualCouplingLayer(reverse): x0 = flipped[:I/2] = cur[I-1 .. I/2]
     if (c->transformer_flows == 1) {
       // VITS2 "pre_conv" (flows.py:145-150): x0_ = pre_transformer(x0 * mask, mask) + x0,
@@ -1583,6 +1607,7 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p, const float
     WETTS_TRY(k_coupling_flip(cur, mm, y_mask, B, I, Ty, dst, s));
     cur = dst;
   }
+  if (repad) WETTS_TRY(k_copy_rows(cur, Ty, Ty_in, z_out_user, Ty_in, Ty_in, (int64_t)B * I, s));
   return WETTS_OK;
 }
 
@@ -1604,25 +1629,29 @@ static int32_t run_vocos(const wetts_model* m, const float* z, int64_t z_bs, int
   const wetts_config_t* c = &m->cfg;
   const int I = c->inter_channels, VC = c->vocos_channels, VH = c->vocos_h_channels;
   const int NF = c->istft_n_fft, VO = NF + 2, F = L + 1;
+  const int Fs = (int)vocos_fs(L), VOp = (int)vocos_rows(c);  // padded row stride / padded iSTFT reduction
   // nn.ReflectionPad1d([1, 0]) needs at least two frames (PyTorch raises otherwise)
   WETTS_REQUIRE(L >= 2, "vocos decoder needs at least 2 frames (ReflectionPad1d([1,0]), decoders.py:265)");
   Bump ws(workspace, workspace_bytes);
-  float* xpad = ws.take<float>((int64_t)B * I * F);
-  float* h = ws.take<float>((int64_t)B * VC * F);
-  float* t1 = ws.take<float>((int64_t)B * VC * F);
-  float* t2 = ws.take<float>((int64_t)B * VC * F);
-  float* u = ws.take<float>((int64_t)B * VH * F);
-  float* spec = ws.take<float>((int64_t)B * VO * F);
-  float* ri = ws.take<float>((int64_t)B * VO * F);
-  float* frames = ws.take<float>((int64_t)B * NF * F);
+  float* xpad = ws.take<float>((int64_t)B * I * Fs);
+  float* h = ws.take<float>((int64_t)B * VC * Fs);
+  float* t1 = ws.take<float>((int64_t)B * VC * Fs);
+  float* t2 = ws.take<float>((int64_t)B * VC * Fs);
+  float* u = ws.take<float>((int64_t)B * VH * Fs);
+  float* spec = ws.take<float>((int64_t)B * VO * Fs);
+  float* ri = ws.take<float>((int64_t)B * VOp * Fs);
+  float* frames = ws.take<float>((int64_t)B * NF * Fs);
   float* cond = ws.take<float>((int64_t)B * VC);
   if (!ws.ok) {
     set_error("vocos: workspace too small (need %lld bytes)", (long long)ws_decoder(c, B, L));
     return WETTS_E_WORKSPACE;
   }
-  WETTS_TRY(k_vocos_pad(z, z_bs, z_cs, y_mask, mask_stride, B, I, L, xpad, s));
+  // Every tensor below is [B][C][Fs]: Fs - F (< 4) junk columns per row ride along.  All ops are column-wise
+  // except the depthwise conv, which takes the valid length, so junk never reaches a valid column; it stays finite
+  // (zero-filled here, LayerNorm / GELU / GEMMs of finite values after that).
+  WETTS_TRY(k_vocos_pad(z, z_bs, z_cs, y_mask, mask_stride, B, I, L, xpad, s, Fs));
   {
-    ConvParams p = conv_io(xpad, I, F, t1, VC, B);
+    ConvParams p = conv_io(xpad, I, Fs, t1, VC, B);
     if (has_g(c) && g) {
       WETTS_TRY(k_cond_linear(g, m->dec_cond_w, m->dec_cond_b, B, VC, c->gin_channels, cond, s));
       p.bias_b = cond;
@@ -1630,7 +1659,7 @@ static int32_t run_vocos(const wetts_model* m, const float* z, int64_t z_bs, int
     }
     WETTS_TRY(launch_conv(m->v_in, p, s));
   }
-  WETTS_TRY(k_layernorm(t1, nullptr, m->v_npre_g, m->v_npre_b, nullptr, nullptr, 0, B, VC, F, h, s));
+  WETTS_TRY(k_layernorm(t1, nullptr, m->v_npre_g, m->v_npre_b, nullptr, nullptr, 0, B, VC, Fs, h, s));
   // live timing of the dominant class (the ConvNeXt stack = 99 % of the flops), same mechanism as
   // the HiFi-GAN MRF events
   hipEvent_t lv0 = nullptr, lv1 = nullptr;
@@ -1640,15 +1669,15 @@ static int32_t run_vocos(const wetts_model* m, const float* z, int64_t z_bs, int
     WETTS_HIP_CHECK(hipEventRecord(lv0, s));
   }
   for (const ConvNeXt& cn : m->v_layers) {
-    WETTS_TRY(k_dwconv(h, nullptr, cn.dw_w, cn.dw_b, 3, 1, B, VC, F, t1, s));
-    WETTS_TRY(k_layernorm(t1, nullptr, cn.ng, cn.nb, nullptr, nullptr, 0, B, VC, F, t2, s));
-    ConvParams p1 = conv_io(t2, VC, F, u, VH, B);
+    WETTS_TRY(k_dwconv(h, nullptr, cn.dw_w, cn.dw_b, 3, 1, B, VC, Fs, t1, s, F));
+    WETTS_TRY(k_layernorm(t1, nullptr, cn.ng, cn.nb, nullptr, nullptr, 0, B, VC, Fs, t2, s));
+    ConvParams p1 = conv_io(t2, VC, Fs, u, VH, B);
     p1.out_act = OUT_GELU;
     WETTS_TRY(launch_conv(cn.pw1, p1, s));
-    ConvParams p2 = conv_io(u, VH, F, t1, VC, B);  // x = res + scale * pw2(u)
+    ConvParams p2 = conv_io(u, VH, Fs, t1, VC, B);  // x = res + scale * pw2(u)
     p2.res = h;
-    p2.r_bs = (int64_t)VC * F;
-    p2.r_cs = F;
+    p2.r_bs = (int64_t)VC * Fs;
+    p2.r_cs = Fs;
     WETTS_TRY(launch_conv(cn.pw2, p2, s));
     float* sw = h; h = t1; t1 = sw;
   }
@@ -1658,11 +1687,20 @@ static int32_t run_vocos(const wetts_model* m, const float* z, int64_t z_bs, int
     m->mrf_launches += 2 * (int64_t)m->v_layers.size();  // the two pointwise GEMMs per layer
     m->mrf_calls += 1;
   }
-  WETTS_TRY(k_layernorm(h, nullptr, m->v_npost_g, m->v_npost_b, nullptr, nullptr, 0, B, VC, F, t2, s));
-  WETTS_TRY(launch_conv(m->v_out, conv_io(t2, VC, F, spec, VO, B), s));
-  WETTS_TRY(k_vocos_spec(spec, B, VO / 2, F, ri, s));
-  WETTS_TRY(launch_conv(m->v_istft, conv_io(ri, VO, F, frames, NF, B), s));
-  return k_istft_ola(frames, B, NF, c->istft_hop_length, F, audio, s);
+  WETTS_TRY(k_layernorm(h, nullptr, m->v_npost_g, m->v_npost_b, nullptr, nullptr, 0, B, VC, Fs, t2, s));
+  WETTS_TRY(launch_conv(m->v_out, conv_io(t2, VC, Fs, spec, VO, B), s));
+  // rows VO .. VOp - 1 of every item: zeros against the zero tail of the packed basis (k_rows_padded)
+  if (VOp > VO)
+    WETTS_HIP_CHECK(hipMemset2DAsync(ri + (int64_t)VO * Fs, (size_t)VOp * Fs * sizeof(float), 0,
+                                     (size_t)(VOp - VO) * Fs * sizeof(float), (size_t)B, s));
+  WETTS_TRY(k_vocos_spec(spec, B, VO / 2, Fs, ri, s, (int64_t)VOp * Fs));
+  {
+    ConvParams p = conv_io(ri, VO, Fs, frames, NF, B);
+    p.x_bs = (int64_t)VOp * Fs;
+    p.k_rows_padded = 1;
+    WETTS_TRY(launch_conv(m->v_istft, p, s));
+  }
+  return k_istft_ola(frames, B, NF, c->istft_hop_length, F, audio, s, Fs);
 }
 
 // output columns per block of the fused ResBlock pair kernels (resblock32.hip / resblock16.hip)
