@@ -617,6 +617,8 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
       hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 1, true>), grid, blk, lds, stream, p);
     else
       hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 2, true>), grid, blk, lds, stream, p);
+  } else if (plain && p.out_div == 1.f && fast) {  // (the flow's in_layers, FFN convs on 16-byte rows)
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 1, false, true>), grid, blk, lds, stream, p);
   } else if (plain && p.out_div == 1.f) {
     hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 1, false>), grid, blk, lds, stream, p);
   } else if (plain) {

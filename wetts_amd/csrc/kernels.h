@@ -109,6 +109,10 @@ int32_t k_vocos_pad(const float* z, int64_t z_bs, int64_t z_cs, const float* mas
 int32_t k_vocos_spec(const float* spec, int B, int half, int F, float* ri, hipStream_t s, int64_t ri_bs = 0);
 // windowed inverse-rDFT basis as a 1x1 conv weight [n_fft][2*half]: frame[n] = hann[n] * irfft(S)[n]
 int32_t k_istft_basis(int n_fft, float* w, hipStream_t s);
+// ConvNeXtLayer front half (decoders.py:241-243): out = LayerNorm_C(dw_conv k3 (x)) in one pass (rows of stride T,
+// zero padding from column Tvalid); false = shape not covered, run k_dwconv + k_layernorm
+bool k_convnext_dwln(const float* x, const float* w, const float* wb, const float* gamma, const float* beta, int B, int C,
+                     int T, int Tvalid, float* out, hipStream_t s, int32_t* rc);
 // overlap-add + window-envelope normalisation + centre trim of torch.istft (center=True):
 // frames [B, n_fft, F] -> audio [B, (F-1)*hop]
 //   Fs: row stride of frames (>= F)

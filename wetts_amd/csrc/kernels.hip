@@ -237,6 +237,84 @@ int32_t k_dwconv(const float* x, const float* mask, const float* w, const float*
 }
 
 // ---------------------------------------------------------------------------------------------
+// ConvNeXtLayer front half (decoders.py:241-243): y = LayerNorm_C(dw_conv_k3(x)) in ONE pass -- x read once, y written
+// once (the two-kernel form is four tensor passes and two launches per layer).  Block = 16 waves over 62 output
+// columns: lane l of every wave holds column t0 - 1 + l (lanes 0 / 63 are the halo, their neighbours' taps come by
+// DPP wave shifts), wave w owns channels w * PER .. and keeps its PER conv outputs in registers; mean and variance
+// are the exact two-pass form, reduced over the 16 waves through LDS.  Rows: stride T, zero padding from column Tv.
+template <int PER>
+__global__ __launch_bounds__(1024) void convnext_dwln_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ wb, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int C, int T, int Tv, float eps,
+                                                            float* __restrict__ out) {
+  __shared__ float red[2][16][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tblocks = (T + 61) / 62;
+  const int b = blockIdx.x / tblocks;
+  const int t = (blockIdx.x % tblocks) * 62 - 1 + lane;
+  const bool inr = t >= 0 && t < Tv;
+  const int c0 = wave * PER;
+  const float* xb = x + ((int64_t)b * C + c0) * T + (inr ? t : 0);
+  float xv[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) xv[j] = xb[(int64_t)j * T];  // every load issued (clamped column), dropped below
+  float y[PER];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const float x0 = inr ? xv[j] : 0.f;
+    const float xm = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x0), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    const float xp = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x0), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+    const int c = c0 + j;
+    y[j] = wb[c] + w[c * 3] * xm + w[c * 3 + 1] * x0 + w[c * 3 + 2] * xp;
+    sum += y[j];
+  }
+  red[0][wave][lane] = sum;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) tot += red[0][q][lane];
+  const float mean = tot / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const float d = y[j] - mean;
+    sq += d * d;
+  }
+  red[1][wave][lane] = sq;
+  __syncthreads();
+  tot = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) tot += red[1][q][lane];
+  const float rstd = 1.f / sqrtf(tot / (float)C + eps);
+  if (lane == 0 || lane == 63 || t >= T) return;
+  float* ob = out + ((int64_t)b * C + c0) * T + t;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) ob[(int64_t)j * T] = (y[j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j];
+}
+
+// returns false when the shape is not covered (the caller then runs k_dwconv + k_layernorm)
+bool k_convnext_dwln(const float* x, const float* w, const float* wb, const float* gamma, const float* beta, int B, int C,
+                     int T, int Tvalid, float* out, hipStream_t s, int32_t* rc) {
+  *rc = WETTS_OK;
+  if (B * T == 0) return true;
+  if (C % 16 != 0 || (C / 16 != 32 && C / 16 != 16 && C / 16 != 4)) return false;
+  const dim3 grid((unsigned)(B * cdiv(T, 62))), blk(1024);
+  if (C / 16 == 32)
+    hipLaunchKernelGGL(convnext_dwln_kernel<32>, grid, blk, 0, s, x, w, wb, gamma, beta, C, T, Tvalid, 1e-5f, out);
+  else if (C / 16 == 16)
+    hipLaunchKernelGGL(convnext_dwln_kernel<16>, grid, blk, 0, s, x, w, wb, gamma, beta, C, T, Tvalid, 1e-5f, out);
+  else
+    hipLaunchKernelGGL(convnext_dwln_kernel<4>, grid, blk, 0, s, x, w, wb, gamma, beta, C, T, Tvalid, 1e-5f, out);
+  if (hipGetLastError() != hipSuccess) {
+    set_error("convnext_dwln_kernel launch failed");
+    *rc = WETTS_E_HIP;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // one wave per (b, c): lanes stride over K, shuffle-reduce
 __global__ __launch_bounds__(256) void cond_linear_kernel(const float* __restrict__ g,
                                                           const float* __restrict__ W,

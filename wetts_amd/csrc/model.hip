@@ -1669,8 +1669,12 @@ static int32_t run_vocos(const wetts_model* m, const float* z, int64_t z_bs, int
     WETTS_HIP_CHECK(hipEventRecord(lv0, s));
   }
   for (const ConvNeXt& cn : m->v_layers) {
-    WETTS_TRY(k_dwconv(h, nullptr, cn.dw_w, cn.dw_b, 3, 1, B, VC, Fs, t1, s, F));
-    WETTS_TRY(k_layernorm(t1, nullptr, cn.ng, cn.nb, nullptr, nullptr, 0, B, VC, Fs, t2, s));
+    int32_t rc = WETTS_OK;
+    if (!k_convnext_dwln(h, cn.dw_w, cn.dw_b, cn.ng, cn.nb, B, VC, Fs, F, t2, s, &rc)) {
+      WETTS_TRY(k_dwconv(h, nullptr, cn.dw_w, cn.dw_b, 3, 1, B, VC, Fs, t1, s, F));
+      WETTS_TRY(k_layernorm(t1, nullptr, cn.ng, cn.nb, nullptr, nullptr, 0, B, VC, Fs, t2, s));
+    }
+    WETTS_TRY(rc);
     ConvParams p1 = conv_io(t2, VC, Fs, u, VH, B);
     p1.out_act = OUT_GELU;
     WETTS_TRY(launch_conv(cn.pw1, p1, s));
