@@ -237,7 +237,7 @@ def test_hifigan_bf16_mode_matches_its_numerics_spec(name):
     assert util.rms(back - f32) < ABS_RMS_OURS  # switching back restores the exact-f32 path
 
 
-@pytest.mark.parametrize("cname", ["v1_b2", "v3_b2"])
+@pytest.mark.parametrize("cname", ["v1_b2", "v3_b2", "v3_b2:stage"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("L", [1, 37, 200])
 def test_fused_resblock_pair_bit_identical(dtype, L, cname):
@@ -246,11 +246,18 @@ def test_fused_resblock_pair_bit_identical(dtype, L, cname):
     arithmetic of two conv launches in the same order with the same rounding points: outputs must
     be EQUAL, including at tile seams
     (L*hop spans several time tiles), sequence ends (zero padding of c2's input) and L=1."""
-    case = util.load_case(cname)  # v1: ResBlock1 pairs; v3: ResBlock2 chains (RB2 instantiations)
+    # v1: ResBlock1 pairs; v3: ResBlock2 chains (RB2 instantiations), one launch per chain -- or, ":stage", one launch
+    # per STAGE at 16 bit (resblock2_stage16.hip: all chains of a stage, the running sum in registers)
+    cname, _, variant = cname.partition(":")
+    if variant == "stage" and dtype == torch.float32:
+        pytest.skip("the stage kernel is a 16-bit decoder kernel")
+    stage_pct = 100 if variant == "stage" else 0
+    case = util.load_case(cname)
     # also fuse launches too small to fill the chip, ResBlock2 shapes with a wide second halo, and whole
     # ResBlock1 chains whatever their halo costs (every fused kernel must be exercised here)
     os.environ["WETTS_TUNE"] = ("fuse_min_blocks=0,fuse2_waste_pct=100,chain_whole_pct=100,chain_whole_maxc=128,"
-                                "chain16_pct=100,small_max_tiles=0")  # (conv_small_kernel sums K in another order)
+                                f"chain16_pct=100,stage2_pct={stage_pct},"
+                                "small_max_tiles=0")  # (conv_small_kernel sums K in another order)
     try:
         net, cfg, W = _model(case)
     finally:

@@ -74,6 +74,26 @@ bool resblock2_chain16_supported(const PackedConvB& c1, const PackedConvB& c2, i
 int32_t launch_resblock2_chain16(const PackedConvB& c1, const PackedConvB& c2, ResPairParams p,
                                  hipStream_t stream);
 
+// a whole MRF stage of ResBlock2 blocks (up to three chains of two residual convs) in one launch, the running
+// sum kept in registers (resblock2_stage16.hip)
+constexpr int RESSTAGE2_MAX_CHAINS = 3;
+struct ResStage2Params {
+  const unsigned short* x;  // [B][T][C] channel-last
+  unsigned short* out;      // [B][T][C] (never aliases x)
+  const unsigned short *wpk1[RESSTAGE2_MAX_CHAINS], *wpk2[RESSTAGE2_MAX_CHAINS];
+  const float *bias1[RESSTAGE2_MAX_CHAINS], *bias2[RESSTAGE2_MAX_CHAINS];
+  int ktaps[RESSTAGE2_MAX_CHAINS], dil1[RESSTAGE2_MAX_CHAINS], dil2[RESSTAGE2_MAX_CHAINS];
+  int nchain;
+  int origin;     // widest c2 halo of the stage: column c of every chain <-> time n0 - origin + c
+  int T, B;
+  float out_div;  // applied with the last chain (x = xs / num_kernels)
+  float slope;
+  int ntiles, nblocks;
+};
+int resblock2_stage16_nto(const PackedConvB* const* c1, const PackedConvB* const* c2, int nchain, int max_waste_pct);
+int32_t launch_resblock2_stage16(const PackedConvB* const* c1, const PackedConvB* const* c2, int nchain,
+                                 ResStage2Params p, hipStream_t stream);
+
 // a whole ResBlock1 (up to three (c1, c2) pairs) in one launch at C <= 64 (resblock1_chain16.hip)
 constexpr int RESCHAIN16_MAX_PAIRS = 3;
 constexpr int RESCHAIN16_MAX_HALO = 25;  // widest single-conv halo (k-1)/2 * dilation the tile margins are sized for

@@ -464,6 +464,9 @@ struct wetts_model {
   // WETTS_TUNE dds_fused: a DDSConv of the duration predictor in one launch (dds_fused.hip).  1: for small launches
   // (B * ceil(Tx / 6) <= 128 blocks of 32 columns, 6 of them valid: encoder call 1.70 -> 1.63 ms at B = 1, Tx = 64);
   // 2: always (64-column tiles; no faster than the 12 launches it replaces, profiles/r03_dds_fused_ab.txt); 0: never
+  // WETTS_TUNE stage2_pct: 16-bit decoder, a whole stage of ResBlock2 blocks in one launch when the widest c2 halo
+  // wastes at most this share of the tile (resblock2_stage16.hip; bit-identical to chain by chain); 0 = never
+  int stage2_pct = 30;
   int dds_fused = 1;
   int wn_fuse = 1;      // WETTS_TUNE wn_fuse: the f32 flow's residual / skip update in the res_skip conv's epilogue (1: small launches, 2: always, 0: wn_update_kernel)
   int small_fork = 1;   // WETTS_TUNE small_fork: the chains of a small (streaming-window) stage on their own streams
@@ -915,7 +918,7 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     // WETTS_TUNE="name=value,name=value", names as in the table below
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {
-        {"dds_fused", &m->dds_fused}, {"wn_fuse", &m->wn_fuse}, {"mrf_streams", &m->mrf_streams},         {"mrf_streams16", &m->mrf_streams16},         {"fuse32_lds", &m->fuse32_lds},
+        {"stage2_pct", &m->stage2_pct}, {"dds_fused", &m->dds_fused}, {"wn_fuse", &m->wn_fuse}, {"mrf_streams", &m->mrf_streams},         {"mrf_streams16", &m->mrf_streams16},         {"fuse32_lds", &m->fuse32_lds},
         {"fuse32_kmax128", &m->fuse32_kmax128},   {"fuse32_maxc", &m->fuse32_maxc},
         {"fuse32_kmax", &m->fuse32_kmax},         {"fuse32_kwide", &m->fuse32_kwide},
         {"fuse2_maxc", &m->fuse2_maxc},           {"fuse2_waste_pct", &m->fuse2_waste_pct},
@@ -2300,6 +2303,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
     // Three launches in flight fill each other's ramp and tail (2.7 of 3 resident blocks per CU on average for one
     // pair launch, profiles/r03_pair16_phase_clock.txt).  Launches of a few blocks (streaming windows) fork too.
     const bool forked = fork_ok;
+    bool stage_done = false;
     if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_fork, s));
     for (int j = 0; j < nk; ++j) {
       const int n = i * nk + j;
@@ -2307,6 +2311,29 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
       if (sj != s) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_fork, 0));
       unsigned short *fa = fas[j], *fb = fbs[j], *ft = fts[j];
       const unsigned short* rx = bt;
+      // a whole stage of ResBlock2 blocks in one launch (resblock2_stage16.hip): x read once, the sum written once
+      if (j == 0 && c->resblock == 2 && nd == 2 && nk <= RESSTAGE2_MAX_CHAINS && !m->dec_unfused && m->stage2_pct > 0) {
+        const PackedConvB *c1s[RESSTAGE2_MAX_CHAINS], *c2s[RESSTAGE2_MAX_CHAINS];
+        for (int q = 0; q < nk; ++q) {
+          c1s[q] = &m->b_c1[i * nk + q][0];
+          c2s[q] = &m->b_c1[i * nk + q][1];
+        }
+        const int nto = resblock2_stage16_nto(c1s, c2s, nk, m->stage2_pct);
+        if (nto > 0 && cdiv(len, nto) * B >= m->fuse_min_blocks) {
+          ResStage2Params sp;
+          memset(&sp, 0, sizeof(sp));
+          sp.x = bt;
+          sp.out = xsum;
+          sp.T = len;
+          sp.B = B;
+          sp.out_div = (float)nk;
+          sp.slope = 0.1f;
+          WETTS_TRY(launch_resblock2_stage16(c1s, c2s, nk, sp, s));
+          if (m->mrf_timing) m->mrf_launches += 1;
+          stage_done = true;
+          break;  // every chain of the stage is done (on the caller's stream: nothing to join)
+        }
+      }
       // a whole ResBlock1 in one launch (resblock1_chain16.hip): x read once, the MRF sum written once
       if (c->resblock == 1 && !m->dec_unfused && m->chain16_waste_pct > 0 && nd <= RESCHAIN16_MAX_PAIRS) {
         const int nto = resblock1_chain16_nto(m->b_c1[n].data(), m->b_c2[n].data(), nd, m->chain16_waste_pct);
@@ -2396,7 +2423,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
       }
       if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_chain[j], sj));
     }
-    if (forked) WETTS_HIP_CHECK(hipStreamWaitEvent(s, m->ev_chain[nk - 1], 0));
+    if (forked && !stage_done) WETTS_HIP_CHECK(hipStreamWaitEvent(s, m->ev_chain[nk - 1], 0));
     if (m->mrf_timing) {
       WETTS_HIP_CHECK(hipEventRecord(lv1, s));
       m->mrf_events.emplace_back(lv0, lv1);
