@@ -72,6 +72,9 @@ def parse_args():
     ap.add_argument("--flow-dtype", default=None, choices=["f32", "bf16", "f16"],
                     help="arithmetic of the flow's WaveNet layers (wetts_set_flow_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-fixture", type=int, default=16,
+                    help="also time the oracle on the first N utterances of the batch as ONE padded call (SURVEY 8d's "
+                         "fixture) at the sweep's best thread count; 0 = skip")
     ap.add_argument("--cpu-sample", type=int, default=1,
                     help="utterances in the CPU sample (1 = the reference CLI's own call shape, inference.py:83-110)")
     # secondary mode: streaming (chunked decoder) latency at B = 1 instead of the throughput step
@@ -204,7 +207,7 @@ PRESETS = {
 }
 
 
-def cpu_baseline(cfg, sd, x, lens, sid, n_utts, sr, hop, length_scale=1.0):
+def cpu_baseline(cfg, sd, x, lens, sid, n_utts, sr, hop, length_scale=1.0, n_fixture=0):
     """Times the oracle (CPU port of the reference path; /root/reference does not exist on the GPU
     box, so `kind` is "port": same ATen CPU kernels, same module order) on ONE bounded sample of the
     workload -- the first `n_utts` utterances, the same sample at every thread count -- at 1 / 8 / 16 / 32
@@ -242,7 +245,25 @@ def cpu_baseline(cfg, sd, x, lens, sid, n_utts, sr, hop, length_scale=1.0):
     finally:
         torch.set_num_threads(saved)
     best = max(sweep, key=lambda r: r["samples_per_s"])
-    return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"],
+    # SURVEY 8(d)'s fixture itself (the benched batch, up to 16 utterances) at the best thread count of the sweep:
+    # one warm-up + one timed run (a B = 16 x 128 run is ~5-10 s of host time)
+    fixture = None
+    if n_fixture > n_utts:
+        try:
+            torch.set_num_threads(best["threads"])
+            xf, lf, sf = x[:n_fixture], lens[:n_fixture], sid[:n_fixture]
+            for rep in range(2):
+                torch.manual_seed(1)
+                t0 = time.perf_counter()
+                o, _, y_mask, _ = vo.infer(W, cd, xf, lf, sf, noise_scale=0.667, length_scale=length_scale,
+                                           noise_scale_w=0.8)
+                dtf = time.perf_counter() - t0
+            sf_ = float(y_mask.sum().item()) * hop
+            fixture = {"utterances": n_fixture, "threads": best["threads"], "samples_per_s": sf_ / dtf,
+                       "seconds": dtf, "rtf": dtf / (sf_ / sr), "method": "1 warm-up + 1 timed run of the padded batch"}
+        finally:
+            torch.set_num_threads(saved)
+    return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "batch_fixture": fixture,
             "kind": "port",
             "kind_reason": "the GPU box has no /root/reference; oracle/vits_oracle.py restates it on "
                            "the same ATen CPU kernels and is pinned to it by tests/golden",
@@ -633,7 +654,7 @@ def main():
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
             for f in reversed(files):
                 d = json.load(open(f))
-                if key in d and default_shape:
+                if key in d and (default_shape or key == "pw_" + str(args.model)):
                     return d[key]["hbm_bytes_per_launch"], os.path.basename(f)
         except Exception:
             pass
@@ -646,7 +667,8 @@ def main():
             "kernel": "the quantised Conv nodes of the MRF ResBlocks: qminmax + qquantize + qconv_i8_kernel "
                       "(v_mfma_i32_32x32x32_i8) per node; ConvTranspose1d stays f32 (conv_mfma_kernel)",
             "bound": "hbm", "achieved": mrf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": mrf_gbs / HBM_PEAK_GBS, "traffic": None,
+            "frac": mrf_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("mrf_uint8")[0],
+            "traffic_unit": "HBM bytes per Conv node (its quantise + integer-conv kernels), PMC",
             "launches": int(mrf_launches), "avg_launch_ms": mrf_ms / nl_,
             "launches_note": "one 'launch' = one Conv node = three kernels (range, quantise, integer conv)",
             "bytes_per_launch": mby * decoded_frames / nl_,
@@ -661,7 +683,7 @@ def main():
         gbs = 0.5 * mrf_gbs
         traffic, traffic_src = pmc_traffic(f"mrf16_{args.config}")
         roofline = {
-            "kernel": "the 16-bit MRF ResBlock class: resblock_chain16_kernel / resblock_pair16_kernel / conv_bf16_kernel "
+            "kernel": "the 16-bit MRF ResBlock class: rb2_stage16_kernel / resblock_pair16_kernel / conv_bf16_kernel "
                       f"({ddtype} channel-last)",
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
@@ -673,10 +695,17 @@ def main():
                           "frac": mrf_tflops / 2500.0},
             "mrf_share_of_step": mrf_ms / (elapsed * 1e3),
         }
+        # `achieved` counts SURVEY 8(d)'s per-conv algorithmic bytes; the fused kernels move fewer through HBM, so the
+        # figure is an accounting rate and can exceed what a copy reaches.  The bandwidth the class really drew:
+        if traffic and mrf_ms > 0:
+            real = traffic / (mrf_ms / nl_ * 1e-3) / 1e9
+            roofline["hbm_real"] = {"achieved": real, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": real / HBM_PEAK_GBS,
+                                    "note": "PMC bytes per launch / live launch duration"}
     else:
-        traffic, traffic_src = pmc_traffic("dominant_conv_mfma") if args.config == "baker" else (None, None)
+        traffic, traffic_src = pmc_traffic("pw_" + mname if "vocos" in mname else
+                                           "dominant_conv_mfma" if args.config == "baker" else "none")
         roofline = {
-            "kernel": ("conv_mfma_kernel (Vocos ConvNeXt pointwise GEMMs 512<->1536)"
+            "kernel": ("pw_gemm_kernel (Vocos ConvNeXt pointwise GEMMs 512<->1536, LDS-DMA GEMM of gemm_pw.hip)"
                        if "vocos" in mname else
                        "the MRF ResBlock conv class: conv_mfma_kernel<.., MRF=true, FAST=true> (single "
                        "convs) + resblock_chain32_kernel (whole ResBlock1 / single pairs)"),
@@ -688,8 +717,8 @@ def main():
             "flops_per_launch": mrf_flops / nl_,
             "hbm_view": {"achieved": mrf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": mrf_gbs / HBM_PEAK_GBS,
-                         "note": "per-conv algorithmic bytes (SURVEY 8d); fp32 convs are "
-                                 "compute-bound (AI 113 flop/B > ridge ~20)"},
+                         "note": "per-conv algorithmic bytes (SURVEY 8d); fp32 convs are compute-bound (AI "
+                                 f"{(mfl / mby) if mby > 0 else 0.0:.0f} flop/B from wetts_hifigan_cost > ridge ~20)"},
             "mrf_share_of_step": mrf_ms / (elapsed * 1e3),
         }
     backend = dist.get_backend() if world > 1 else "none"
@@ -699,6 +728,12 @@ def main():
             ddtype + " decoder") + \
         ("" if fdtype == "f32" else f" + {fdtype} flow WaveNet layers")
     valid_phonemes = float(lens.sum())
+    # the BASELINE.json label only when the preset's own model and shape run; an override is named as one
+    overridden = [k for k, v in (("model", args.model), ("batch", args.batch), ("phonemes", args.phonemes),
+                                 ("speakers", args.speakers), ("decoder-dtype", args.decoder_dtype),
+                                 ("flow-dtype", args.flow_dtype)) if v]
+    wtag = pre["tag"] if not overridden else \
+        "not a BASELINE.json config: preset '" + args.config + "' with --" + ", --".join(overridden) + " overridden"
     out = {
         "metric": "audio samples/sec + RTF @22.05 kHz, VITS-Baker, 1/2/4/8 MI355X",
         "value": value, "unit": "samples/s", "n_gpus": observed_world, "steps": args.steps,
@@ -712,7 +747,7 @@ def main():
         "rtf": elapsed / (samples / sr), "x_realtime": (samples / sr) / elapsed,
         "config": {"workload": f"{args.config}_{mname} infer(): B={batch}/GPU x "
                                f"{phonemes} phonemes{' ragged U{32..' + str(phonemes) + '}' if ragged else ''}, "
-                               f"{prec}, {n_speakers} speaker(s), {sr} Hz ({pre['tag']})",
+                               f"{prec}, {n_speakers} speaker(s), {sr} Hz ({wtag})",
                    "global_batch": total, "phonemes": phonemes, "hop": hop,
                    "padded_sub_batches_per_step": nb, "decode": decode,
                    "sub_batch_plan": {"chosen_by": "equal-count (--buckets)" if args.buckets > 0 else
@@ -745,7 +780,7 @@ def main():
     # (rank 0, after the timed region and its barrier; the other ranks wait at the final barrier)
     if not args.no_cpu_baseline and (world == 1 or args.cpu_baseline_multi):
         out["cpu_baseline"] = cpu_baseline(cfg, sd, x, lens, sid, min(args.cpu_sample, total), sr, hop,
-                                           args.length_scale)
+                                           args.length_scale, n_fixture=min(args.cpu_fixture, total))
     print(json.dumps(out), file=json_out(), flush=True)
     if world > 1:
         dist.barrier()

@@ -11,15 +11,16 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra_env=None, args=()):
+def _run(extra_env=None, args=(), gpus=2, batch=8):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     env.update(WETTS_BENCH_TEST_BACKEND="tests.bench_stub:StubBackend", WETTS_DIST_BACKEND="gloo",
                PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
     env.update(extra_env or {})
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--config", "aishell3", "--model", "tiny", "--batch", "8", "--presteps-s", "0.02", "--no-cpu-baseline"] + list(args)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
+           "--config", "aishell3", "--model", "tiny", "--presteps-s", "0.02", "--no-cpu-baseline"] + \
+        (["--batch", str(batch)] if batch else []) + list(args)
     return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
 
 
@@ -60,6 +61,31 @@ def test_bench_two_ranks_control_flow_and_reductions():
     w = batching.RAGGED_PAD_WEIGHT
     assert w * f / ((1 - f) + w * f) <= 0.08 + 1e-9
     assert d["roofline"]["launches"] > 0 and d["roofline"]["frac"] > 0
+
+
+def test_bench_eight_ranks_aishell3_preset_plan_and_imbalance():
+    """BASELINE.json configs[3] as the driver will launch it on an 8-GPU node -- `bench.py --gpus 8 --config aishell3`:
+    512 ragged utterances (64 per rank), LPT deal, per-rank ragged plans -- through the same spawn / gloo / broadcast /
+    reduce path, on the stub backend: all 8 ranks seen, every utterance counted once, the padded-slot imbalance of the
+    plan and the per-rank times in the line."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from tests import bench_stub
+    from wetts_amd import batching
+    p = _run(gpus=8, batch=0)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["blob_checksum_ok"] is True and len(d["rank_ms"]) == 8
+    assert d["config"]["global_batch"] == 512 and d["scaling"] == "weak"
+    x, lens, sid = bench.make_inputs("tiny", 256, 218, 512, 128, True)
+    assert abs(d["config"]["valid_frames_per_step"] - bench_stub.expected_frames(lens.tolist(), 0.92)) < 1e-6
+    pl = batching.plan(lens.tolist(), 8, max_pad_frac=0.08, ragged=True)
+    assert sorted(i for sh in pl.shards for i in sh) == list(range(512)) and all(len(sh) == 64 for sh in pl.shards)
+    assert abs(d["plan_slot_imbalance"] - pl.stats["imbalance"]) < 1e-9 and pl.stats["imbalance"] < 0.05
+    assert d["config"]["sub_batch_plan"]["sizes_rank0"] == [len(b) for b in pl.buckets[0]]
+    assert "not a BASELINE.json config" in d["config"]["workload"]  # --model tiny is an override and is named as one
 
 
 def test_bench_refuses_a_corrupted_broadcast():

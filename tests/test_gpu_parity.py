@@ -241,8 +241,8 @@ def test_hifigan_bf16_mode_matches_its_numerics_spec(name):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("L", [1, 37, 200])
 def test_fused_resblock_pair_bit_identical(dtype, L, cname):
-    """The fused ResBlock kernels (resblock_chain32.hip / resblock32.hip at f32, resblock16.hip / resblock1_chain16.hip
-    at 16 bit: whole ResBlock1 chains at C <= 64, pairs at C = 128) perform the
+    """The fused ResBlock kernels (resblock_chain32.hip / resblock32.hip at f32; resblock16.hip pairs / ResBlock2
+    chains and resblock2_stage16.hip whole stages at 16 bit) perform the
     arithmetic of two conv launches in the same order with the same rounding points: outputs must
     be EQUAL, including at tile seams
     (L*hop spans several time tiles), sequence ends (zero padding of c2's input) and L=1."""
@@ -256,7 +256,7 @@ def test_fused_resblock_pair_bit_identical(dtype, L, cname):
     # also fuse launches too small to fill the chip, ResBlock2 shapes with a wide second halo, and whole
     # ResBlock1 chains whatever their halo costs (every fused kernel must be exercised here)
     os.environ["WETTS_TUNE"] = ("fuse_min_blocks=0,fuse2_waste_pct=100,chain_whole_pct=100,chain_whole_maxc=128,"
-                                f"chain16_pct=100,stage2_pct={stage_pct},"
+                                f"stage2_pct={stage_pct},"
                                 "small_max_tiles=0")  # (conv_small_kernel sums K in another order)
     try:
         net, cfg, W = _model(case)

@@ -19,6 +19,10 @@ for a, b in [("prof_stats_baker/r_kernel_stats.csv", "kernel_stats.csv"), ("benc
              ("prof_stats_cfg2/r_kernel_stats.csv", "kernel_stats_cfg2_multilingual_bf16.csv"),
              ("prof_stats_bf16/r_kernel_stats.csv", "kernel_stats_bf16.csv"),
              ("prof_stats_stress48k/r_kernel_stats.csv", "kernel_stats_cfg4_stress48k_f16.csv"),
+             ("prof_stats_vocos/r_kernel_stats.csv", "kernel_stats_vocos.csv"),
+             ("prof_stats_vits2vocos/r_kernel_stats.csv", "kernel_stats_vits2_vocos_v1.csv"),
+             ("prof_stats_uint8/r_kernel_stats.csv", "kernel_stats_uint8.csv"),
+             ("pytest_gpu_margins.txt",) * 2, ("stream_v1_graph.json",) * 2,
              ("conv16_fused_pair.txt",) * 2, ("conv_microbench.txt",) * 2,
              ("stream_v1.json",) * 2, ("stream_vits2_vocos.json",) * 2, ("mas.json", "mas_bench.json"),
              ("bench_vocos.json",) * 2, ("bench_vits2_vocos.json",) * 2,
@@ -60,7 +64,27 @@ out = {"note": "per kernel name; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per 
                "uncalibrated, so read this as an upper bound on reads).  Class keys: dominant_conv_mfma = the f32 "
                "headline's MRF class, mrf16_<config> = the 16-bit MRF class of bench.py --config <config> "
                "(baker = --decoder-dtype bf16)"}
-for key, sub in (("dominant_conv_mfma", "baker"), ("mrf16_baker", "bf16"), ("mrf16_stress48k", "stress48k")):
+def is_pw(k):
+    return "pw_gemm_kernel" in k
+
+
+def is_u8(k):
+    return "qconv_i8_kernel" in k or "qquantize" in k or "qminmax" in k or "qrange" in k
+
+
+def _mrf16(k):
+    return is_mrf(k) or "rb2_stage16_kernel" in k
+
+
+# key in the JSON -> (sub-directory tag of the three rocprofv3 passes, kernel-class predicate,
+#                     launches of the class counted as: kernels (None) or this kernel-name substring only)
+CLASSES = (("dominant_conv_mfma", "baker", is_mrf, None), ("mrf16_baker", "bf16", _mrf16, None),
+           ("mrf16_stress48k", "stress48k", _mrf16, None), ("mrf16_multilingual", "cfg2", _mrf16, None),
+           ("pw_vocos", "vocos", is_pw, None), ("pw_vits2_vocos_v1", "vits2vocos", is_pw, None),
+           # uint8: bench.py counts one launch per Conv node = its qconv_i8_kernel (the quantise / range kernels'
+           # bytes are charged to that node)
+           ("mrf_uint8", "uint8", is_u8, "qconv_i8_kernel"))
+for key, sub, in_class, count_only in CLASSES:
     f = agg(f"{src}/pmc_fetch_{sub}/r_counter_collection.csv", "FETCH_SIZE")
     w = agg(f"{src}/pmc_write_{sub}/r_counter_collection.csv", "WRITE_SIZE")
     sp = f"{src}/prof_stats_{sub}/r_kernel_stats.csv"
@@ -77,12 +101,12 @@ for key, sub in (("dominant_conv_mfma", "baker"), ("mrf16_baker", "bf16"), ("mrf
             ent["calls_in_stats_run"] = int(stats[k]["Calls"])
         if len(kernels) < 12:
             kernels[k] = ent
-        if is_mrf(k):
-            dom["launches"] += n
+        if in_class(k):
+            dom["launches"] += n if (count_only is None or count_only in k) else 0
             dom["fetch_kb"] += sum(f[k])
             dom["write_kb"] += sum(w.get(k, [0]))
             if k in stats:
-                dom["stat_calls"] = dom.get("stat_calls", 0) + int(stats[k]["Calls"])
+                dom["stat_calls"] = dom.get("stat_calls", 0) + (int(stats[k]["Calls"]) if (count_only is None or count_only in k) else 0)
                 dom["stat_ns"] = dom.get("stat_ns", 0.0) + float(stats[k]["TotalDurationNs"])
     out[key] = {
         "launches": dom["launches"],
@@ -94,5 +118,8 @@ for key, sub in (("dominant_conv_mfma", "baker"), ("mrf16_baker", "bf16"), ("mrf
         "rocprof_calls": dom.get("stat_calls", 0),
         "kernels": kernels,
     }
+    if not f:
+        del out[key]  # this pass was not run
+        continue
     print(key, json.dumps({k: v for k, v in out[key].items() if k != "kernels"}))
 json.dump(out, open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libwetts_hip.so")
-SOURCES = ["conv_mfma.hip", "gemm_pw.hip", "conv_small.hip", "conv_bf16.hip", "conv16_mb2.hip", "resblock16.hip", "resblock2_stage16.hip", "resblock1_chain16.hip", "wn16.hip", "qconv_u8.hip", "resblock32.hip", "resblock_chain32.hip", "kernels.hip", "dds_fused.hip", "attention.hip", "mas.hip", "model.hip"]
+SOURCES = ["conv_mfma.hip", "gemm_pw.hip", "conv_small.hip", "conv_bf16.hip", "resblock16.hip", "resblock2_stage16.hip", "wn16.hip", "qconv_u8.hip", "resblock32.hip", "resblock_chain32.hip", "kernels.hip", "dds_fused.hip", "attention.hip", "mas.hip", "model.hip"]
 # measurement tooling (tools/bench_*.py): its own library, linked against the product one
 BENCH_SOURCES = ["bench_conv.hip"]
 BENCH_LIB = os.path.join(LIBDIR, "libwetts_bench.so")

@@ -64,7 +64,6 @@ struct ResPairParams {
   float out_div;
   float slope;     // leaky-relu slope in front of both convs
   int ntiles, nblocks;
-  unsigned long long* prof;  // measurement aid (WETTS_PAIR16_PROF=1): per-block phase timestamps, null in production
 };
 bool resblock_pair16_supported(const PackedConvB& c1, const PackedConvB& c2);
 int32_t launch_resblock_pair16(const PackedConvB& c1, const PackedConvB& c2, ResPairParams p,
@@ -94,37 +93,11 @@ int resblock2_stage16_nto(const PackedConvB* const* c1, const PackedConvB* const
 int32_t launch_resblock2_stage16(const PackedConvB* const* c1, const PackedConvB* const* c2, int nchain,
                                  ResStage2Params p, hipStream_t stream);
 
-// a whole ResBlock1 (up to three (c1, c2) pairs) in one launch at C <= 64 (resblock1_chain16.hip)
-constexpr int RESCHAIN16_MAX_PAIRS = 3;
-constexpr int RESCHAIN16_MAX_HALO = 25;  // widest single-conv halo (k-1)/2 * dilation the tile margins are sized for
-struct ResChain16Params {
-  const unsigned short* x;  // [B][T][C] channel-last
-  unsigned short* out;      // [B][T][C] (never aliases x)
-  const unsigned short *wpk1[RESCHAIN16_MAX_PAIRS], *wpk2[RESCHAIN16_MAX_PAIRS];
-  const float *bias1[RESCHAIN16_MAX_PAIRS], *bias2[RESCHAIN16_MAX_PAIRS];
-  int dil[RESCHAIN16_MAX_PAIRS];
-  int npairs, ktaps;
-  int halo, margin;  // sum of the convs' halos (valid columns shrink by it on each side); widest single halo
-  int T, B;
-  int accum;         // add the previous contents of out (running MRF sum)
-  float out_div;
-  float slope;
-  int ntiles, nblocks;
-};
-// valid output columns per block, or 0 when the kernel does not take the chain (shape, or 2 * halo above
-// max_waste_pct of the tile)
-int resblock1_chain16_nto(const PackedConvB* c1, const PackedConvB* c2, int npairs, int max_waste_pct);
-int32_t launch_resblock1_chain16(const PackedConvB* c1, const PackedConvB* c2, int npairs, ResChain16Params p,
-                                 hipStream_t stream);
-
 int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
                               int dil, int pad, int transposed, int up, int f16, hipStream_t stream,
                               PackedConvB* out, int gate_h = 0);
 void free_packed_bf16(PackedConvB* pc);
 int32_t launch_conv_bf16(const PackedConvB& pc, ConvBParams p, hipStream_t stream);
-// conv16_mb2.hip: plain stride-1 convs with >= 256 output channels on 64-row wave tiles (two MFMAs per LDS read)
-bool conv16_mb2_supported(const PackedConvB& pc, const ConvBParams& p);
-int32_t launch_conv16_mb2(const ConvBParams& p, bool f16, hipStream_t stream);
 int resblock_pair16_ntc(int C);
 int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, int f16,
                        hipStream_t s);

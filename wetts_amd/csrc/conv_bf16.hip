@@ -495,14 +495,6 @@ int32_t launch_conv_bf16(const PackedConvB& pc, ConvBParams p, hipStream_t strea
   WETTS_REQUIRE(p.span <= 128, "conv receptive field too wide");
   WETTS_REQUIRE(pc.Cout % 32 == 0 && pc.Cin % 8 == 0, "bf16 path needs Cout %% 32 == 0, Cin %% 8 == 0");
   p.N = p.up > 0 ? p.Tin + p.ktaps - 1 : p.Tout;
-  {  // WETTS_CONV16_MB2=1: 64-row wave tiles for the C >= 256 convs (measured slower: profiles/r03_pair16_mb2.txt)
-    static int mb2 = -1;
-    if (mb2 < 0) {
-      const char* e = getenv("WETTS_CONV16_MB2");
-      mb2 = e ? atoi(e) : 0;
-    }
-    if (mb2 && !p.basic && conv16_mb2_supported(pc, p)) return launch_conv16_mb2(p, pc.f16 != 0, stream);
-  }
   if (pc.CKB == 64) {
     if (p.M >= 128) return launch_b<4, 4, 1, 64>(p, stream, pc.f16 != 0);
     return launch_b<4, 2, 2, 64>(p, stream, pc.f16 != 0);

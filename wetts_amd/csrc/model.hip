@@ -432,9 +432,6 @@ struct wetts_model {
   // C = 64: k = 3), single pairs at C = 32 (every k) and for k <= chain_pair_kmax at any width
   int small_max_tiles = 256;      // conv launches of at most this many 64x64 tiles use conv_small_kernel (0: off)
   int chain_whole_waste_pct = 15; // WETTS_CHAIN_WHOLE_PCT (0 disables whole-ResBlock launches)
-  // 16-bit decoder: whole ResBlock1 per launch at C <= 64 when 2 * halo <= this % of the tile.  Bit-identical to the
-  // pair launches and measured 1 % SLOWER on the MRF class at 10-15 %, 6 % at 30 % (profiles/r03_chain16_ab.txt): off
-  int chain16_waste_pct = 0;
   int chain_whole_maxc = 64;      // WETTS_CHAIN_WHOLE_MAXC
   int chain_pair_maxc = 32;       // WETTS_CHAIN_PAIR_MAXC: widest stage whose pairs all run on the chain kernel
   int chain_pair_kmax = 3;        // WETTS_CHAIN_PAIR_KMAX: ... and pairs with at most this many taps at any width
@@ -458,9 +455,6 @@ struct wetts_model {
   // the model's own standard-normal stream (wetts_infer with eps == NULL)
   mutable uint64_t rng_seed = 0, rng_offset = 0;
   int mrf_streams = 1;
-  // 16-bit decoder, > 1: the k = 3 / 7 / 11 chains of a stage on their own streams (run_hifigan_bf16).  Measured a
-  // wash -- the MRF class 2.7 % faster, the step not (profiles/r03_mrf_streams16.txt) -- so off by default
-  int mrf_streams16 = 1;
   // WETTS_TUNE dds_fused: a DDSConv of the duration predictor in one launch (dds_fused.hip).  1: for small launches
   // (B * ceil(Tx / 6) <= 128 blocks of 32 columns, 6 of them valid: encoder call 1.70 -> 1.63 ms at B = 1, Tx = 64);
   // 2: always (64-column tiles; no faster than the 12 launches it replaces, profiles/r03_dds_fused_ab.txt); 0: never
@@ -918,11 +912,11 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     // WETTS_TUNE="name=value,name=value", names as in the table below
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {
-        {"stage2_pct", &m->stage2_pct}, {"dds_fused", &m->dds_fused}, {"wn_fuse", &m->wn_fuse}, {"mrf_streams", &m->mrf_streams},         {"mrf_streams16", &m->mrf_streams16},         {"fuse32_lds", &m->fuse32_lds},
+        {"stage2_pct", &m->stage2_pct}, {"dds_fused", &m->dds_fused}, {"wn_fuse", &m->wn_fuse}, {"mrf_streams", &m->mrf_streams},                  {"fuse32_lds", &m->fuse32_lds},
         {"fuse32_kmax128", &m->fuse32_kmax128},   {"fuse32_maxc", &m->fuse32_maxc},
         {"fuse32_kmax", &m->fuse32_kmax},         {"fuse32_kwide", &m->fuse32_kwide},
         {"fuse2_maxc", &m->fuse2_maxc},           {"fuse2_waste_pct", &m->fuse2_waste_pct},
-        {"fuse_min_blocks", &m->fuse_min_blocks}, {"chain16_pct", &m->chain16_waste_pct}, {"chain_whole_pct", &m->chain_whole_waste_pct},
+        {"fuse_min_blocks", &m->fuse_min_blocks}, {"chain_whole_pct", &m->chain_whole_waste_pct},
         {"chain_whole_maxc", &m->chain_whole_maxc}, {"chain_pair_maxc", &m->chain_pair_maxc},
         {"chain_pair_kmax", &m->chain_pair_kmax}, {"small_max_tiles", &m->small_max_tiles},
         {"conv_groups", &m->conv_groups},       {"small_fork", &m->small_fork},
@@ -2250,16 +2244,9 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
   unsigned short* bt = ws.take<unsigned short>(mx);
   unsigned short* bs = ws.take<unsigned short>(mx);
   const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
-  // ResBlock1 chains on their own streams: each needs its own ping-pong pair (and c1 output, for the unfused convs)
-  const bool fork_ok = c->resblock == 1 && m->mrf_streams16 > 1 && nk > 1 && nk <= WETTS_MAX_RB_KERNELS &&
-                       m->aux_stream[nk - 1] != nullptr;
-  unsigned short *fas[WETTS_MAX_RB_KERNELS], *fbs[WETTS_MAX_RB_KERNELS], *fts[WETTS_MAX_RB_KERNELS];
-  for (int j = 0; j < (fork_ok ? nk : 1); ++j) {
-    fas[j] = ws.take<unsigned short>(mx);
-    fbs[j] = ws.take<unsigned short>(mx);
-    fts[j] = ws.take<unsigned short>(mx);
-  }
-  for (int j = 1; j < nk && !fork_ok && j < WETTS_MAX_RB_KERNELS; ++j) { fas[j] = fas[0]; fbs[j] = fbs[0]; fts[j] = fts[0]; }
+  unsigned short* fa = ws.take<unsigned short>(mx);
+  unsigned short* fb = ws.take<unsigned short>(mx);
+  unsigned short* ft = ws.take<unsigned short>(mx);
   float* cond = ws.take<float>((int64_t)B * C0);
   if (!ws.ok) {
     set_error("hifigan(bf16): workspace too small");
@@ -2298,18 +2285,10 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
       WETTS_HIP_CHECK(hipEventCreate(&lv1));
       WETTS_HIP_CHECK(hipEventRecord(lv0, s));
     }
-    // Fork: the chains of a stage are independent up to their last launch, which adds into the running sum -- those
-    // are ordered chain j-1 -> chain j by events, so the sum is formed in the sequential order (bit-identical).
-    // Three launches in flight fill each other's ramp and tail (2.7 of 3 resident blocks per CU on average for one
-    // pair launch, profiles/r03_pair16_phase_clock.txt).  Launches of a few blocks (streaming windows) fork too.
-    const bool forked = fork_ok;
     bool stage_done = false;
-    if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_fork, s));
     for (int j = 0; j < nk; ++j) {
       const int n = i * nk + j;
-      hipStream_t sj = (forked && j > 0) ? m->aux_stream[j] : s;
-      if (sj != s) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_fork, 0));
-      unsigned short *fa = fas[j], *fb = fbs[j], *ft = fts[j];
+      hipStream_t sj = s;
       const unsigned short* rx = bt;
       // a whole stage of ResBlock2 blocks in one launch (resblock2_stage16.hip): x read once, the sum written once
       if (j == 0 && c->resblock == 2 && nd == 2 && nk <= RESSTAGE2_MAX_CHAINS && !m->dec_unfused && m->stage2_pct > 0) {
@@ -2332,26 +2311,6 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           if (m->mrf_timing) m->mrf_launches += 1;
           stage_done = true;
           break;  // every chain of the stage is done (on the caller's stream: nothing to join)
-        }
-      }
-      // a whole ResBlock1 in one launch (resblock1_chain16.hip): x read once, the MRF sum written once
-      if (c->resblock == 1 && !m->dec_unfused && m->chain16_waste_pct > 0 && nd <= RESCHAIN16_MAX_PAIRS) {
-        const int nto = resblock1_chain16_nto(m->b_c1[n].data(), m->b_c2[n].data(), nd, m->chain16_waste_pct);
-        if (nto > 0 && cdiv(len, nto) * B >= m->fuse_min_blocks) {
-          ResChain16Params cp;
-          memset(&cp, 0, sizeof(cp));
-          cp.x = rx;
-          cp.out = xsum;
-          cp.T = len;
-          cp.B = B;
-          cp.accum = (j > 0) ? 1 : 0;
-          cp.out_div = (j == nk - 1) ? (float)nk : 1.f;  // x = xs / self.num_kernels
-          cp.slope = 0.1f;
-          if (forked && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
-          WETTS_TRY(launch_resblock1_chain16(m->b_c1[n].data(), m->b_c2[n].data(), nd, cp, sj));
-          if (m->mrf_timing) m->mrf_launches += 1;
-          if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_chain[j], sj));
-          continue;
         }
       }
       for (int d = 0; d < nd; ++d) {
@@ -2391,7 +2350,6 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           pp.accum = accum;
           pp.out_div = odiv;
           pp.slope = 0.1f;
-          if (forked && last_d && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
           WETTS_TRY(launch_resblock_pair16(m->b_c1[n][d], m->b_c2[n][d], pp, sj));
           if (m->mrf_timing) m->mrf_launches += 1;
         } else if (c->resblock == 1) {
@@ -2399,7 +2357,6 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           p1.basic = m->dec_unfused;
           p1.tag = 1;
           WETTS_TRY(launch_conv_bf16(m->b_c1[n][d], p1, sj));
-          if (forked && last_d && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
           ConvBParams p2 = convb_io(ft, ch, len, outp, ch, len, B);
           p2.basic = m->dec_unfused;
           p2.tag = 1;
@@ -2421,9 +2378,8 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
         }
         rx = outp;
       }
-      if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_chain[j], sj));
     }
-    if (forked && !stage_done) WETTS_HIP_CHECK(hipStreamWaitEvent(s, m->ev_chain[nk - 1], 0));
+    (void)stage_done;
     if (m->mrf_timing) {
       WETTS_HIP_CHECK(hipEventRecord(lv1, s));
       m->mrf_events.emplace_back(lv0, lv1);

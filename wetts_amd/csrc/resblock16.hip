@@ -85,17 +85,6 @@ void resblock_pair16_kernel(const ResPairParams p) {
   const int tx0 = n0 - h2 - h1;  // time of LDS row 0 of the x tile
 
   const unsigned short* xb = p.x + (int64_t)b * p.T * C;
-  // phase timestamps of wave 0 (measurement aid; p.prof is null in production -- one uniform branch per stamp)
-  // (slots 0..7: s_memtime = shader cycles; behind them, per block, the constant 100 MHz counter at entry and exit:
-  // the ratio is the clock the chip actually sustained under this kernel's power draw)
-  auto stamp = [&](int k) {
-    if (p.prof && tid == 0) {
-      p.prof[(int64_t)bid * 8 + k] = __builtin_amdgcn_s_memtime();
-      if (k == 0 || k == 7) p.prof[(int64_t)p.nblocks * 8 + (int64_t)bid * 2 + (k == 7)] = wall_clock64();
-    }
-  };
-  stamp(0);
-
   // ---- A streams -----------------------------------------------------------------------------
   const int G = NCH * p.ktaps;
   const uint4* abase1 = reinterpret_cast<const uint4*>(p.wpk1) + ((int64_t)(wm * MB) * G * KS) * 64 + lane;
@@ -162,9 +151,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
       }
     }
   }
-  stamp(1);
   __syncthreads();
-  stamp(2);
 
   f32x16 acc[MB][NB];
 #pragma unroll
@@ -258,7 +245,6 @@ void resblock_pair16_kernel(const ResPairParams p) {
 
   // ---- 2. c1 ---------------------------------------------------------------------------------
   conv_loop(abase1, p.dil);
-  stamp(3);
 
   // c2's first A groups are requested now; they land during step 3.  (MB = 1 also requests the raw residual
   // here; with two m-blocks per wave its 64 registers on top of the 128 accumulators spill, so MB = 2 loads it
@@ -315,7 +301,6 @@ void resblock_pair16_kernel(const ResPairParams p) {
     }
     __syncthreads();
   }
-  stamp(4);
 
   // ---- 4. c2, accumulator = residual (+ running sum) -------------------------------------------
   unsigned short* ob = p.out + (int64_t)b * p.T * C;
@@ -365,9 +350,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
     }
     if (MB == 2) __builtin_amdgcn_sched_barrier(0);
   }
-  stamp(5);
   conv_loop(abase2, dil2);
-  stamp(6);
 
   // ---- 5. epilogue -----------------------------------------------------------------------------
   float bia[MB][16];
@@ -398,16 +381,6 @@ void resblock_pair16_kernel(const ResPairParams p) {
         *reinterpret_cast<uint4*>(ob + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half) = o;
       }
   }
-  stamp(7);
-}
-
-static int g_pair16_mb = -1;  // WETTS_PAIR16_MB=2: 64-row wave tiles at C >= 64 (measured slower: profiles/r03_pair16_mb2.txt)
-static int pair16_mb() {
-  if (g_pair16_mb < 0) {
-    const char* e = getenv("WETTS_PAIR16_MB");
-    g_pair16_mb = e ? atoi(e) : 1;
-  }
-  return g_pair16_mb;
 }
 
 template <int C, int NR, int OCC, bool RB2, int MB>
@@ -425,47 +398,16 @@ static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream
   p.nblocks = (int)nb;
   const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);
   const size_t lds = (size_t)(NTC + 2 * (h1 > h2 ? h1 : h2)) * RS;
-  static const bool prof_on = getenv("WETTS_PAIR16_PROF") != nullptr;  // micro-benchmark aid: phase timeline of a block
-  static unsigned long long* prof_buf = nullptr;
-  static int prof_left = getenv("WETTS_PAIR16_PROF_N") ? atoi(getenv("WETTS_PAIR16_PROF_N")) : 3;  // launches to print (later ones are warm)
-  p.prof = nullptr;
-  if (prof_on && prof_left > 0 && nb * 10 <= ((int64_t)8 << 20)) {
-    if (!prof_buf) WETTS_HIP_CHECK(hipMalloc((void**)&prof_buf, (size_t)(1 << 20) * 8 * sizeof(unsigned long long)));
-    p.prof = prof_buf;
-  }
   if (f16)
     hipLaunchKernelGGL((resblock_pair16_kernel<C, true, NR, OCC, RB2, MB>), dim3(grid), dim3(NTH), lds, stream, p);
   else
     hipLaunchKernelGGL((resblock_pair16_kernel<C, false, NR, OCC, RB2, MB>), dim3(grid), dim3(NTH), lds, stream, p);
   WETTS_LAUNCH_CHECK();
-  if (p.prof) {
-    --prof_left;
-    WETTS_HIP_CHECK(hipStreamSynchronize(stream));
-    std::vector<unsigned long long> h((size_t)nb * 10);
-    WETTS_HIP_CHECK(hipMemcpy(h.data(), prof_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double sum[7] = {0, 0, 0, 0, 0, 0, 0}, cyc = 0, wall = 0;
-    unsigned long long w_min = ~0ull, w_max = 0;
-    for (int64_t q = 0; q < nb; ++q) {
-      for (int k = 0; k < 7; ++k) sum[k] += (double)(h[q * 8 + k + 1] - h[q * 8 + k]);
-      const unsigned long long w0 = h[nb * 8 + q * 2], w1 = h[nb * 8 + q * 2 + 1];
-      cyc += (double)(h[q * 8 + 7] - h[q * 8]);
-      wall += (double)(w1 - w0);
-      if (w0 < w_min) w_min = w0;
-      if (w1 > w_max) w_max = w1;
-    }
-    fprintf(stderr, "[pair16 prof] C=%d k=%d d=%d MB=%d blocks=%lld  s_memtime ticks per block: stage %.0f | barrier %.0f | "
-            "c1 loop %.0f | ft epilogue %.0f | c2 init %.0f | c2 loop %.0f | store %.0f | block life %.1f us, launch %.1f us, "
-            "%.2f blocks resident per CU on average, sustained clock %.0f MHz\n",
-            C, p.ktaps, p.dil, MB, (long long)nb, sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[4] / nb, sum[5] / nb,
-            sum[6] / nb, wall / nb / 100.0, (double)(w_max - w_min) / 100.0, wall / (double)(w_max - w_min) / 256.0,
-            wall > 0 ? cyc / wall * 100.0 : 0.0);
-  }
   return WETTS_OK;
 }
 
 // output columns a block of the pair kernel computes per conv (the decoder's tile arithmetic, model.hip)
 int resblock_pair16_ntc(int C) {
-  if (pair16_mb() == 2 && C >= 64) return C == 128 ? 128 : 256;
   return 128 * (4 / (C / 32));
 }
 
@@ -490,11 +432,10 @@ int32_t launch_resblock_pair16(const PackedConvB& c1, const PackedConvB& c2, Res
   // ring depth 2 at 3 waves/SIMD measured best (profiles/r01_conv16_fused_pair.txt: deeper rings
   // cost occupancy or issue slots and lose 5-15 %)
   p.dil2 = 1;
-  const bool mb2 = pair16_mb() == 2;
   switch (c1.Cin) {
     case 32: return launch_pair<32, 2, 3, false, 1>(p, h, stream);
-    case 64: return mb2 ? launch_pair<64, 2, 2, false, 2>(p, h, stream) : launch_pair<64, 2, 3, false, 1>(p, h, stream);
-    default: return mb2 ? launch_pair<128, 2, 2, false, 2>(p, h, stream) : launch_pair<128, 2, 3, false, 1>(p, h, stream);
+    case 64: return launch_pair<64, 2, 3, false, 1>(p, h, stream);
+    default: return launch_pair<128, 2, 3, false, 1>(p, h, stream);
   }
 }
 
@@ -520,11 +461,10 @@ int32_t launch_resblock2_chain16(const PackedConvB& c1, const PackedConvB& c2, R
   p.dil = c1.dil;
   p.dil2 = c2.dil;
   const bool h = c1.f16 != 0;
-  const bool mb2 = pair16_mb() == 2;
   switch (c1.Cin) {
     case 32: return launch_pair<32, 2, 3, true, 1>(p, h, stream);
-    case 64: return mb2 ? launch_pair<64, 2, 2, true, 2>(p, h, stream) : launch_pair<64, 2, 3, true, 1>(p, h, stream);
-    default: return mb2 ? launch_pair<128, 2, 2, true, 2>(p, h, stream) : launch_pair<128, 2, 3, true, 1>(p, h, stream);
+    case 64: return launch_pair<64, 2, 3, true, 1>(p, h, stream);
+    default: return launch_pair<128, 2, 3, true, 1>(p, h, stream);
   }
 }
 
