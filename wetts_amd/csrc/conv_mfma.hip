@@ -623,6 +623,8 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 1, false>), grid, blk, lds, stream, p);
   } else if (plain) {
     hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 2, false>), grid, blk, lds, stream, p);
+  } else if (fast) {  // generic epilogue (activation + mask: FFN conv_1) on 16-byte staging
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 0, false, true>), grid, blk, lds, stream, p);
   } else {
     hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 0, false>), grid, blk, lds, stream, p);
   }
@@ -741,6 +743,11 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
     static const int pw_on = [] { const char* e = getenv("WETTS_PW_GEMM"); return e ? atoi(e) : 1; }();  // A/B switch
     const int v = conv_variant();
     if (pw_on && (v == 0 || (v >= 7 && v <= 9)) && pw_gemm_eligible(pc, p)) return launch_pw_gemm(pc, p, stream, v);
+    if (pw_on && (v == 0 || v == 10) && conv_dma_eligible(pc, p)) {
+      bool taken = true;
+      WETTS_TRY(launch_conv_dma(pc, p, stream, v == 10 ? nullptr : &taken));
+      if (taken) return WETTS_OK;
+    }
   }
   // tile selection: fill the chip first, then maximise per-wave register reuse
   const int64_t cols = (int64_t)p.N * p.B;

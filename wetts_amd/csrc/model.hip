@@ -1053,20 +1053,21 @@ static int32_t run_enc_layers(const std::vector<EncLayer>& layers, float* xa, co
                               x_mask, e.rel_k, e.rel_v, window, B, nh, dk, T, sc, att, s));
     (void)k; (void)v;
     WETTS_TRY(launch_conv(e.o, conv_io(att, H, T, y, H, B), s));
-    // x = norm_layers_1(x + y)
-    WETTS_TRY(k_layernorm(xa, y, e.n1g, e.n1b, nullptr, nullptr, 0, B, H, T, xb, s));
-    // FFN: conv_1(pad(x*mask)) -> relu -> conv_2(pad(.*mask)) * mask
+    // x = norm_layers_1(x + y), written MASKED: columns with mask 0 are zero from here on.  That is what the FFN wants
+    // as its input (conv_1(pad(x * mask))), and nothing else can tell: the residual and LayerNorm below are per
+    // column, masked columns never reach a valid one (attention masks its keys, the convs read zeros either way)
+    // and the stack's output is masked.  The convs then see a plain input: LDS-DMA / 16-byte staging.
+    WETTS_TRY(k_layernorm(xa, y, e.n1g, e.n1b, nullptr, x_mask, 0, B, H, T, xb, s));
+    // FFN: conv_1(pad(x*mask)) -> relu -> conv_2(pad(.*mask)) * mask; the hidden tensor is masked by conv_1's epilogue
     {
       ConvParams p = conv_io(xb, H, T, hid, F, B);
-      p.in_mask = x_mask;
-      p.in_mask_stride = T;
       p.out_act = OUT_RELU;
+      p.out_mask = x_mask;
+      p.out_mask_stride = T;
       WETTS_TRY(launch_conv(e.f1, p, s));
     }
     {
       ConvParams p = conv_io(hid, F, T, y, H, B);
-      p.in_mask = x_mask;
-      p.in_mask_stride = T;
       p.out_mask = x_mask;
       p.out_mask_stride = T;
       WETTS_TRY(launch_conv(e.f2, p, s));
