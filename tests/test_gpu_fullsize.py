@@ -447,3 +447,32 @@ def test_ragged_decode_with_upsample_rates_that_are_not_multiples_of_four():
         ref = vo.infer(W, cd, x[b:b + 1, :tb], xl[b:b + 1], sid[b:b + 1], 0.667, 1.0, 0.8,
                        eps_w=eps_w[b:b + 1, :, :tb], eps_z=eps_z[b:b + 1, :, :fb])[0]
         assert util.rms(o_r[b, 0, :n].cpu().numpy() - ref[0, 0].numpy()) < 1e-4, b
+
+
+def test_flow_at_b64_matches_oracle_on_sub_batch():
+    """The f32 flow at B = 64 x ~760 frames is where the large-launch kernels run -- conv_dma_kernel (in_layers k = 5 on
+    the LDS-DMA structure with edge-tile zero padding), pw_gemm_kernel strips with residual / mask epilogues -- and the
+    frame count is not a multiple of 4 for ragged lengths (rows re-padded on the way in and out).  The flow is masked,
+    so a sub-batch is exact: three utterances (first, a short one, last) against oracle.flow_reverse on the device's
+    own z_p."""
+    from oracle import vits_oracle as vo
+    from wetts_amd import checkpoint
+    net, sd = _net("v3", 256, 2)
+    g = torch.Generator().manual_seed(3)
+    B, Tx = 64, 128
+    x = torch.randint(0, 256, (B, Tx), generator=g)
+    xl = torch.randint(40, Tx + 1, (B,), generator=g).long()
+    xl[0] = Tx
+    sid = torch.arange(B) % 2
+    o, attn, ym, (z, z_p, _, _) = _run(net, x, xl, sid, torch.zeros(B, 2, Tx))
+    W = checkpoint.fold_weight_norm(sd)
+    cd = util.cfg_dict(net.cfg)
+    short = int(torch.argmin(xl))
+    pick = torch.tensor([0, short, B - 1])
+    gg = torch.nn.functional.embedding(sid[pick], W["emb_g.weight"]).unsqueeze(-1)
+    with torch.no_grad():
+        ref = vo.flow_reverse(W, cd, z_p[pick].cpu(), ym[pick].cpu(), gg)
+    valid = ym[pick].cpu().bool().expand_as(ref).numpy()
+    err = util.rel_rms(z[pick].cpu().numpy()[valid], ref.numpy()[valid])
+    print("flow at B = 64, Ty =", ym.shape[-1], ": z rel rms vs the oracle", err)
+    assert err < 2e-4

@@ -23,7 +23,7 @@ for a, b in [("prof_stats_baker/r_kernel_stats.csv", "kernel_stats.csv"), ("benc
              ("prof_stats_vits2vocos/r_kernel_stats.csv", "kernel_stats_vits2_vocos_v1.csv"),
              ("prof_stats_uint8/r_kernel_stats.csv", "kernel_stats_uint8.csv"),
              ("pytest_gpu_margins.txt",) * 2, ("stream_v1_graph.json",) * 2,
-             ("conv16_fused_pair.txt",) * 2, ("conv_microbench.txt",) * 2,
+             ("conv16_fused_pair.txt",) * 2, ("conv_microbench.txt",) * 2, ("pw_gemm_microbench.txt",) * 2,
              ("stream_v1.json",) * 2, ("stream_vits2_vocos.json",) * 2, ("mas.json", "mas_bench.json"),
              ("bench_vocos.json",) * 2, ("bench_vits2_vocos.json",) * 2,
              ("bench_cfg2_multilingual_bf16.json",) * 2, ("bench_cfg2_multilingual_f32.json",) * 2,
