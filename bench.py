@@ -245,14 +245,13 @@ def cpu_baseline(cfg, sd, x, lens, sid, n_utts, sr, hop, length_scale=1.0, n_fix
     finally:
         torch.set_num_threads(saved)
     best = max(sweep, key=lambda r: r["samples_per_s"])
-    # SURVEY 8(d)'s fixture itself (the benched batch, up to 16 utterances) at the best thread count of the sweep:
-    # one warm-up + one timed run (a B = 16 x 128 run is ~5-10 s of host time)
+    # SURVEY 8(d)'s fixture itself (the benched batch, up to 16 utterances) at the best thread count of the sweep
     fixture = None
     if n_fixture > n_utts:
         try:
             torch.set_num_threads(best["threads"])
             xf, lf, sf = x[:n_fixture], lens[:n_fixture], sid[:n_fixture]
-            for rep in range(2):
+            for rep in range(1):  # (the sweep above has warmed ATen; a B = 16 run is 10-25 s of host time)
                 torch.manual_seed(1)
                 t0 = time.perf_counter()
                 o, _, y_mask, _ = vo.infer(W, cd, xf, lf, sf, noise_scale=0.667, length_scale=length_scale,
@@ -260,7 +259,7 @@ def cpu_baseline(cfg, sd, x, lens, sid, n_utts, sr, hop, length_scale=1.0, n_fix
                 dtf = time.perf_counter() - t0
             sf_ = float(y_mask.sum().item()) * hop
             fixture = {"utterances": n_fixture, "threads": best["threads"], "samples_per_s": sf_ / dtf,
-                       "seconds": dtf, "rtf": dtf / (sf_ / sr), "method": "1 warm-up + 1 timed run of the padded batch"}
+                       "seconds": dtf, "rtf": dtf / (sf_ / sr), "method": "one timed run of the padded batch, after the sweep"}
         finally:
             torch.set_num_threads(saved)
     return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "batch_fixture": fixture,

@@ -64,8 +64,8 @@ out = {"note": "per kernel name; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per 
                "uncalibrated, so read this as an upper bound on reads).  Class keys: dominant_conv_mfma = the f32 "
                "headline's MRF class, mrf16_<config> = the 16-bit MRF class of bench.py --config <config> "
                "(baker = --decoder-dtype bf16)"}
-def is_pw(k):
-    return "pw_gemm_kernel" in k
+def is_pw(k):  # the tagged launches: the ConvNeXt GEMMs bench.py times for the Vocos models
+    return "pw_gemm_kernel" in k and ", true>" in k
 
 
 def is_u8(k):

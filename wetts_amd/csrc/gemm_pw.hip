@@ -224,7 +224,9 @@ __device__ __forceinline__ void pw_pass(const PwParams& p, float* smem, int b, i
   pw_epilogue<NBP>(p, acc, b, rowu, colj0, half);
 }
 
-template <int CKS, int NBMAX>
+// TAG = name tag of the launches bench.py times as its dominant class (the ConvNeXt GEMMs of the Vocos models; no code
+// difference): rocprofv3 then separates them from the flow / encoder 1x1 convs that share the instantiation
+template <int CKS, int NBMAX, bool TAG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void pw_gemm_kernel(const PwParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -465,14 +467,17 @@ static void pw_schedule(int strips, int U, int K, int slots, int* S_out, int* up
 }
 
 template <int CKS, int NBMAX>
-static int32_t launch_pw(const PwParams& p, int64_t blocks, hipStream_t stream) {
+static int32_t launch_pw(const PwParams& p, int64_t blocks, hipStream_t stream, bool tag = false) {
   const size_t lds = PwLds<CKS, NBMAX>::kBytes;
   static signed char opt_in[64] = {};
   if (lds > 64 * 1024 && !lds_opt_in(reinterpret_cast<const void*>(&pw_gemm_kernel<CKS, NBMAX>), opt_in)) {
     set_error("pw_gemm_kernel: the device refused the %zu-byte dynamic LDS opt-in", lds);
     return WETTS_E_HIP;
   }
-  hipLaunchKernelGGL((pw_gemm_kernel<CKS, NBMAX>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  if (tag && lds <= 64 * 1024)
+    hipLaunchKernelGGL((pw_gemm_kernel<CKS, NBMAX, true>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  else
+    hipLaunchKernelGGL((pw_gemm_kernel<CKS, NBMAX>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -567,7 +572,7 @@ int32_t launch_pw_gemm(const PackedConv& pc, const ConvParams& cp, hipStream_t s
   WETTS_REQUIRE(blocks < (1ll << 31), "pw_gemm grid too large");
   if (variant == 8 && deep) return launch_pw<32, 4>(p, blocks, stream);
   if (variant == 9 && deep && p.upb <= 3) return launch_pw<32, 2>(p, blocks, stream);
-  return launch_pw<16, 4>(p, blocks, stream);
+  return launch_pw<16, 4>(p, blocks, stream, cp.tag != 0);
 }
 
 }  // namespace wetts

@@ -1675,8 +1675,10 @@ static int32_t run_vocos(const wetts_model* m, const float* z, int64_t z_bs, int
     WETTS_TRY(rc);
     ConvParams p1 = conv_io(t2, VC, Fs, u, VH, B);
     p1.out_act = OUT_GELU;
+    p1.tag = 1;  // the Vocos models' dominant class: own kernel symbol for the profiles
     WETTS_TRY(launch_conv(cn.pw1, p1, s));
     ConvParams p2 = conv_io(u, VH, Fs, t1, VC, B);  // x = res + scale * pw2(u)
+    p2.tag = 1;
     p2.res = h;
     p2.r_bs = (int64_t)VC * Fs;
     p2.r_cs = Fs;
