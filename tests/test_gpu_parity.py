@@ -277,8 +277,8 @@ def test_fused_resblock_pair_bit_identical(dtype, L, cname):
 @pytest.mark.parametrize("name", ["tiny_sdp_b3", "v1_b2", "v1_b4x128"])
 def test_wn_update_in_the_conv_epilogue_is_bit_identical(name):
     """The f32 flow's residual / skip update (modules.py:79-86) runs in the epilogue of the res_skip conv
-    (ConvParams.wn_*; conv_small_kernel for short calls, conv_mfma_kernel's generic epilogue for B = 4 x 128) instead
-    of wn_update_kernel: the same additions on the same values, so z and the audio must be EQUAL."""
+    (ConvParams.wn_*; conv_small_kernel for short calls, pw_gemm_kernel for B = 4 x 128) instead of wn_update_kernel:
+    for the short calls the same additions on the same values, so z and the audio must be EQUAL."""
     case = util.load_case(name)
     outs = []
     for fuse in ("2", "0"):  # 2 = at every size (1, the default, fuses only the small launches)
@@ -294,6 +294,11 @@ def test_wn_update_in_the_conv_epilogue_is_bit_identical(name):
                                       eps_z=util.t(case["eps_z"]).cuda())
         outs.append((z.cpu().numpy(), o.cpu().numpy()))
     assert np.isfinite(outs[0][0]).all()
+    if name == "v1_b4x128":
+        # launches above the small-launch limit take the LDS-DMA GEMM (gemm_pw.hip), where the old h / skip values come in
+        # through the accumulator init: (h + conv) + bias instead of h + (conv + bias) -- one rounding apart per element
+        assert util.rel_rms(outs[0][0], outs[1][0]) < 1e-6 and util.rel_rms(outs[0][1], outs[1][1]) < 1e-5
+        return
     assert np.array_equal(outs[0][0], outs[1][0]), f"z: max |diff| {np.abs(outs[0][0] - outs[1][0]).max()}"
     assert np.array_equal(outs[0][1], outs[1][1])
 

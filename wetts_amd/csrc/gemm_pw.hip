@@ -54,7 +54,44 @@ struct PwParams {
   int out_act;
   int B, S, upb, U, mtiles;
   int ktaps, pad, Tin;  // k-tap convs (conv_dma_kernel): taps at dilation 1, "same" padding, valid input length
+  // WaveNet residual / skip update instead of a store (modules.py:79-86; ConvParams.wn_*): rows < wn_H (not on the last
+  // layer) -> h = (h + v) * mask, the others -> skip (+)= v.  h, skip: contiguous [B][wn_H][N].  wn_H % 32 == 0.
+  float* wn_h;
+  float* wn_skip;
+  const float* wn_mask;
+  int64_t wn_mask_stride;
+  int wn_H, wn_last, wn_first;
 };
+
+// Where a wave's 32 rows come from / go to.  Plain convs: the residual and output tensors of the launch.  WaveNet
+// update: the wave's rows are either h rows (read-modify-write through the accumulator init, masked) or skip rows
+// (accumulated unless this is the first layer) -- uniform per wave because wn_H is a multiple of 32.
+struct PwIo {
+  const float* res;  // accumulator init (null: zero), rows r_row0 + ..
+  float* out;
+  const float* mask;  // output mask row of this batch item (null: none)
+  int r_cs, r_row0, o_cs, o_row0;
+};
+__device__ __forceinline__ PwIo pw_io(const PwParams& p, int b, int rowu) {
+  PwIo io;
+  if (p.wn_skip) {
+    const bool to_h = !p.wn_last && rowu < p.wn_H;
+    float* base = (to_h ? p.wn_h : p.wn_skip) + (int64_t)b * p.wn_H * p.N;
+    io.out = base;
+    io.res = (to_h || !p.wn_first) ? base : nullptr;
+    io.mask = to_h ? p.wn_mask + (int64_t)b * p.wn_mask_stride : nullptr;
+    io.r_cs = io.o_cs = p.N;
+    io.r_row0 = io.o_row0 = (to_h || p.wn_last) ? rowu : rowu - p.wn_H;
+    return io;
+  }
+  io.res = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
+  io.out = p.out + (int64_t)b * p.o_bs;
+  io.mask = p.out_mask ? p.out_mask + (int64_t)b * p.out_mask_stride : nullptr;
+  io.r_cs = p.r_cs;
+  io.o_cs = p.o_cs;
+  io.r_row0 = io.o_row0 = rowu;
+  return io;
+}
 
 // exact-erf GELU (F.gelu default, decoders.py:243) with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 --
 // an order below float32 round-off of the GEMM in front of it) on the hardware exp2 / rcp: 16 VALU operations where
@@ -87,14 +124,15 @@ template <int NBP>
 __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[NBP], int b, int rowu, int colj0, int half) {
   // ---- epilogue -------------------------------------------------------------------------------------------------
   // bias: rows rowu + rr (+ 4 for the upper half-wave) are uniform addresses -> scalar loads, one select per row
-  __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out + (int64_t)b * p.o_bs, 0, 0x7FFFFFFF, kPwRsrcDword3);
+  const PwIo io = pw_io(p, b, rowu);
+  __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(io.out, 0, 0x7FFFFFFF, kPwRsrcDword3);
   int voff[NBP];
   float om[NBP];
 #pragma unroll
   for (int j = 0; j < NBP; ++j) {
     const int col = colj0 + 32 * j;
-    voff[j] = (4 * half * p.o_cs + col) * 4;
-    om[j] = (p.out_mask && col < p.N) ? p.out_mask[(int64_t)b * p.out_mask_stride + col] : 1.f;
+    voff[j] = (4 * half * io.o_cs + col) * 4;
+    om[j] = (io.mask && col < p.N) ? io.mask[col] : 1.f;
   }
   const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
 #pragma unroll
@@ -106,14 +144,14 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[NBP
     if (bb) { b0 += bb[rlo]; b1 += bb[rhi]; }
     const float bia = half ? b1 : b0;
     if (rowu + rr + 4 * half >= p.M) continue;
-    const int soff = __builtin_amdgcn_readfirstlane((rowu + rr) * p.o_cs * 4);
+    const int soff = __builtin_amdgcn_readfirstlane((io.o_row0 + rr) * io.o_cs * 4);
 #pragma unroll
     for (int j = 0; j < NBP; ++j) {
       if (colj0 + 32 * j >= p.N) continue;
       float v = acc[j][r] + bia;
       if (p.out_act == OUT_GELU) v = gelu_erf_fast(v);
       else if (p.out_act == OUT_RELU) v = fmaxf(v, 0.f);
-      if (p.out_mask) v *= om[j];
+      if (io.mask) v *= om[j];
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rso, voff[j], soff, 0);
     }
   }
@@ -127,15 +165,15 @@ __device__ __forceinline__ void pw_acc_init(const PwParams& p, f32x16 (&acc)[NBP
   for (int j = 0; j < NBP; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  if (p.res) {
-    __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.res + (int64_t)b * p.r_bs), 0, 0x7FFFFFFF, kPwRsrcDword3);
+  const PwIo io = pw_io(p, b, rowu);
+  if (io.res && rowu < p.M) {  // (uniform: M is a multiple of 32 whenever there is an init, see pw_gemm_eligible)
+    __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(io.res), 0, 0x7FFFFFFF, kPwRsrcDword3);
     int voff[NBP];
 #pragma unroll
-    for (int j = 0; j < NBP; ++j) voff[j] = (4 * half * p.r_cs + min(colj0 + 32 * j, p.N - 1)) * 4;
+    for (int j = 0; j < NBP; ++j) voff[j] = (4 * half * io.r_cs + min(colj0 + 32 * j, p.N - 1)) * 4;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int soff = __builtin_amdgcn_readfirstlane((rowu + (r & 3) + 8 * (r >> 2)) * p.r_cs * 4);
+      const int soff = __builtin_amdgcn_readfirstlane((io.r_row0 + (r & 3) + 8 * (r >> 2)) * io.r_cs * 4);
 #pragma unroll
       for (int j = 0; j < NBP; ++j)
         acc[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsr, voff[j], soff, 0));
@@ -409,9 +447,12 @@ static int device_cus() {
 bool pw_gemm_eligible(const PackedConv& pc, const ConvParams& p) {
   if (pc.ktaps != 1 || pc.up != 0 || pc.pad != 0) return false;
   if (p.in_act != IN_NONE || p.in_mask != nullptr || p.in_rev_base >= 0 || p.lens != nullptr) return false;
-  if (p.accum || p.out_div != 1.f || p.wn_skip != nullptr) return false;
+  if (p.accum || p.out_div != 1.f) return false;
+  if (p.wn_skip && ((p.wn_H % 32) != 0 || (pc.M % 32) != 0 || p.res || p.out_act != OUT_NONE || p.out_mask ||
+                    p.wn_mask_stride < p.Tout))
+    return false;  // WaveNet update: whole 32-row blocks on either side of wn_H, read-modify-write without row predicates
   if (p.res && (p.out_act != OUT_NONE || p.out_mask)) return false;  // the residual is folded into the accumulator init
-  if (p.res && (pc.M % 128) != 0) return false;  // ... by loads without a row predicate: whole m-tiles only
+  if (p.res && (pc.M % 32) != 0) return false;  // ... by loads without a row predicate: whole 32-row wave blocks only
   if ((int64_t)pc.M * p.o_cs * 4 >= (1ll << 31) || (p.res && (int64_t)pc.M * p.r_cs * 4 >= (1ll << 31))) return false;
   if (((pc.Cin % 16) != 0 && !p.k_rows_padded) || pc.Cin < 32) return false;
   if ((p.x_cs & 3) != 0 || (p.x_bs & 3) != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0) return false;
@@ -561,6 +602,13 @@ int32_t launch_pw_gemm(const PackedConv& pc, const ConvParams& cp, hipStream_t s
   p.out_mask = cp.out_mask;
   p.out_mask_stride = cp.out_mask_stride;
   p.out_act = cp.out_act;
+  p.wn_h = cp.wn_h;
+  p.wn_skip = cp.wn_skip;
+  p.wn_mask = cp.wn_mask;
+  p.wn_mask_stride = cp.wn_mask_stride;
+  p.wn_H = cp.wn_H;
+  p.wn_last = cp.wn_last;
+  p.wn_first = cp.wn_first;
   p.B = cp.B;
   p.U = cdiv(p.N, 32);
   if (p.B <= 0 || p.N <= 0 || p.M <= 0) return WETTS_OK;

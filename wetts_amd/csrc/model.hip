@@ -1580,8 +1580,11 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p_in, const fl
       // residual / skip update in the conv's epilogue (rs never exists, one launch less per layer) where launches are
       // the cost: the calls the small-launch conv kernel takes.  Big batches keep the specialised conv epilogue and
       // the separate update -- the generic epilogue costs them 0.2 % of the headline step (profiles/r03_wn_fuse_ab.txt)
+      // ... and launches the LDS-DMA GEMM takes (gemm_pw.hip: h / skip rows come in through the accumulator init, so
+      // its epilogue stays a plain store; rows of the flow are 16-byte aligned here, see the top of this function)
       const bool fuse_upd = m->wn_fuse == 2 ||
-                            (m->wn_fuse == 1 && (int64_t)cdiv(last ? H : 2 * H, 64) * cdiv(Ty, 64) * B <= m->small_max_tiles);
+                            (m->wn_fuse == 1 && ((int64_t)cdiv(last ? H : 2 * H, 64) * cdiv(Ty, 64) * B <= m->small_max_tiles ||
+                                                 (H % 32) == 0));
       if (fuse_upd) {
         p2.wn_h = h;
         p2.wn_skip = skip;
