@@ -474,3 +474,32 @@ def test_triton_min_chunk_streaming_protocol():
             interior[a:b] = ((ws == 0) | (t - ws >= rf)) & right_ok
         assert interior.any()
         assert err.reshape(L, hop)[interior].max() < 1e-5, (L, err.reshape(L, hop)[interior].max())
+
+
+def test_graphed_encoder_matches_plain_and_keeps_the_noise_stream():
+    """session.GraphedEncoder replays the encoder call from two captured HIP graphs (before / after the call's one
+    host sync; the second per frame bucket, extra frames masked).  Same seed => same durations, same alignment (EQUAL)
+    and z within round-off of the plain call (the flow's tile shapes follow the bucketed length); replays with other
+    inputs of the same shape do not leak state; errors the plain path raises are raised."""
+    from wetts_amd.session import EncoderSession
+    net, case, cfg, sd, W = _model("tiny_sdp_b3")
+    plain, graphed = EncoderSession(net), EncoderSession(net, use_graph=True, frame_bucket=16)
+    scales = np.tile(np.array([[0.667, 1.0, 0.8]], np.float32), (case["x"].shape[0], 1))
+    g = np.random.default_rng(0)
+    for rep in range(4):
+        x = case["x"] if rep == 0 else g.integers(0, int(case["n_vocab"]), size=case["x"].shape)
+        feeds = {"input": x, "input_lengths": case["x_lengths"], "scales": scales, "sid": case["sid"]}
+        torch.manual_seed(10 + rep)
+        a = plain.run(None, feeds)[0]
+        torch.manual_seed(10 + rep)
+        b = graphed.run(None, feeds)[0]
+        assert a.shape == b.shape, (a.shape, b.shape)  # same frame count: the durations saw the same noise
+        assert util.rel_rms(b, a) < 1e-5, (rep, util.rel_rms(b, a))
+        assert np.array_equal(b == 0, a == 0)  # the same frames are masked
+    assert len(graphed._graphed._pre) == 1 and 1 <= len(graphed._graphed._post) <= 4
+    bad = dict(feeds, input=np.full_like(case["x"], int(case["n_vocab"]) + 5))
+    with pytest.raises(IndexError):
+        graphed.run(None, bad)
+    torch.manual_seed(3)
+    ok = graphed.run(None, feeds)[0]  # and the entry still works afterwards
+    assert np.isfinite(ok).all()

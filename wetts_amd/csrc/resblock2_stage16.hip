@@ -215,7 +215,8 @@ void rb2_stage16_kernel(const ResStage2Params p) {
                                           acc[j][8 * i + 2 * e + 1] + bia[8 * i + 2 * e + 1]);
             acc[j][8 * i + 2 * e] = lo16<F16>(r16);
             acc[j][8 * i + 2 * e + 1] = hi16<F16>(r16);
-            w[e] = inside ? lrelu_pk<F16>(r16, p.slope) : 0u;
+            // lrelu_pk(r16) on the values just unpacked (same operations, two unpacks less)
+            w[e] = inside ? pk2<F16>(lrelu_max(acc[j][8 * i + 2 * e], p.slope), lrelu_max(acc[j][8 * i + 2 * e + 1], p.slope)) : 0u;
           }
           *reinterpret_cast<uint4*>(smem_r + (size_t)(col + h2) * RS + (co_blk + 16 * i + 8 * half) * 2) =
               make_uint4(w[0], w[1], w[2], w[3]);
@@ -246,6 +247,8 @@ void rb2_stage16_kernel(const ResStage2Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) bia[r] = p.bias2[ch][co_blk + 16 * (r >> 3) + 8 * half + (r & 7)];
       const bool dodiv = ch == p.nchain - 1 && p.out_div != 1.f;
+      const bool fastdiv = p.out_div == 3.f || p.out_div == 2.f;  // (num_kernels of every recipe: 3)
+      const float dinv = 1.f / p.out_div;
 #pragma unroll
       for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -254,7 +257,7 @@ void rb2_stage16_kernel(const ResStage2Params p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             v[e] = acc[j][8 * i + e] + bia[8 * i + e];
-            if (dodiv) v[e] = v[e] / p.out_div;
+            if (dodiv) v[e] = fastdiv ? div_small_const(v[e], p.out_div, dinv) : v[e] / p.out_div;
           }
           sum[j][i].x = pk2<F16>(v[0], v[1]); sum[j][i].y = pk2<F16>(v[2], v[3]);
           sum[j][i].z = pk2<F16>(v[4], v[5]); sum[j][i].w = pk2<F16>(v[6], v[7]);

@@ -259,23 +259,10 @@ class SynthesizerTrn:
         """Everything of infer() up to and including flow^-1 (== infer_encoder, models.py:282-331).
         Returns a dict of stage tensors."""
         lib = self._require()
-        dev = self.device
         x = self._ids(x)
         x_lengths = self._ids(x_lengths)
-        B, Tx = x.shape
-        H, I = self.hidden_channels, self.inter_channels
-        s = _lib.current_stream_ptr()
-        # [B] y_lengths + one word of WETTS_STATUS_* bits: read back together, one sync
-        # (the library zeroes the low word it registers; the high word of that int64 is ignored)
-        meta = torch.empty(B + 1, dtype=torch.int64, device=dev)
-        y_lengths = meta[:B]
-        status_ptr = C.c_void_p(meta.data_ptr() + 8 * B)
-        _lib.check(lib.wetts_set_status_word(self._handle, status_ptr, s), "set_status_word")
-        try:
-            return self._encode_stages(lib, x, x_lengths, sid, noise_scale, length_scale,
-                                       noise_scale_w, eps_w, eps_z, meta, y_lengths, status_ptr, s)
-        finally:
-            lib.wetts_set_status_word(self._handle, None, s)
+        return self._encode_stages(lib, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, eps_w, eps_z,
+                                   None, None, None, None)
 
     def _randn(self, *shape):
         """Standard-normal tensor from the library's Philox kernel (replaces torch.randn).
@@ -284,52 +271,75 @@ class SynthesizerTrn:
         and advanced here exactly as an ATen kernel would: torch.manual_seed(s) therefore rewinds the stream
         (also when s is the seed already in use: the reference's `manual_seed(0); a = infer(); manual_seed(0);
         b = infer()` gives a == b, and so does this), successive calls continue it, and no ATen kernel runs."""
+        return self._randn_into(torch.empty(*shape, dtype=torch.float32, device=self.device))
+
+    def _randn_into(self, out):
+        """Fills a contiguous float32 device tensor from the same stream (see _randn)."""
         lib = self._require()
         gen = torch.cuda.default_generators[self.device.index]
         seed = gen.initial_seed() & 0xFFFFFFFFFFFFFFFF
         offset = int(gen.get_offset())
-        out = torch.empty(*shape, dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.dtype == torch.float32
         n = out.numel()
         _lib.check(lib.wetts_randn(_lib.ptr(out), n, seed, offset, _lib.current_stream_ptr()), "randn")
         used = (n + 3) // 4  # Philox counters consumed (4 normals each)
         gen.set_offset(offset + (used + 3) // 4 * 4)  # ATen keeps the offset a multiple of 4
         return out
 
-    def _encode_stages(self, lib, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w,
-                       eps_w, eps_z, meta, y_lengths, status_ptr, s):
+    # The encoder call in two halves around its one host synchronisation.  Each half is (a) a set of device buffers
+    # and (b) stream-ordered launches that touch nothing else -- so a half can also be captured once into a HIP graph
+    # and replayed (session.GraphedEncoder), which is why the buffers are explicit.
+    def _pre_buffers(self, B, Tx, own=False):
+        """Buffers of the first half: speaker vector -> text encoder -> duration predictor -> durations.  `own`: also the
+        input tensors and a private workspace (a captured graph bakes every pointer in)."""
         dev = self.device
-        B, Tx = x.shape
         H, I = self.hidden_channels, self.inter_channels
-        g = self._speaker(sid, B)
-        ws, nws = self._workspace(B, Tx, 0)
-        x_enc = torch.empty(B, H, Tx, dtype=torch.float32, device=dev)
-        stats = torch.empty(B, 2 * I, Tx, dtype=torch.float32, device=dev)
-        x_mask = torch.empty(B, Tx, dtype=torch.float32, device=dev)
-        _lib.check(lib.wetts_text_encoder(self._handle, _lib.ptr(x), _lib.ptr(x_lengths),
-                                          _lib.ptr(g), B, Tx,
-                                          _lib.ptr(x_enc), _lib.ptr(stats), _lib.ptr(x_mask),
-                                          _lib.ptr(ws), nws, s), "text_encoder")
-        logw = torch.empty(B, Tx, dtype=torch.float32, device=dev)
-        if self.use_sdp:
-            eps_w = self._randn(B, 2, Tx) if eps_w is None else self._f32(eps_w)
-            if tuple(eps_w.shape) != (B, 2, Tx):
-                raise ValueError(f"eps_w must be [{B},2,{Tx}]")
-            _lib.check(lib.wetts_duration_sdp(self._handle, _lib.ptr(x_enc), _lib.ptr(x_mask),
-                                              _lib.ptr(g), _lib.ptr(eps_w), float(noise_scale_w),
-                                              B, Tx, _lib.ptr(logw), status_ptr,
-                                              _lib.ptr(ws), nws, s), "duration_sdp")
-        else:
-            _lib.check(lib.wetts_duration_dp(self._handle, _lib.ptr(x_enc), _lib.ptr(x_mask),
-                                             _lib.ptr(g), B, Tx, _lib.ptr(logw), _lib.ptr(ws),
-                                             nws, s), "duration_dp")
-        w_ceil = torch.empty(B, Tx, dtype=torch.float32, device=dev)
-        cum = torch.empty(B, Tx, dtype=torch.float32, device=dev)
-        _lib.check(lib.wetts_durations_to_lengths(_lib.ptr(logw), _lib.ptr(x_mask),
-                                                  float(length_scale), B, Tx, _lib.ptr(w_ceil),
-                                                  _lib.ptr(cum), _lib.ptr(y_lengths), status_ptr,
-                                                  s), "durations_to_lengths")
-        # the one host sync of infer(): output length is data dependent (commons.py:114-115)
-        meta_host = meta.cpu()
+        f32 = dict(dtype=torch.float32, device=dev)
+        pb = dict(
+            B=B, Tx=Tx, g=torch.empty(B, max(1, self.gin_channels), **f32),
+            x_enc=torch.empty(B, H, Tx, **f32), stats=torch.empty(B, 2 * I, Tx, **f32),
+            x_mask=torch.empty(B, Tx, **f32), logw=torch.empty(B, Tx, **f32), w_ceil=torch.empty(B, Tx, **f32),
+            cum=torch.empty(B, Tx, **f32), eps_w=None, sid=None,
+            # [B] y_lengths + one word of WETTS_STATUS_* bits: read back together, one sync
+            meta=torch.empty(B + 1, dtype=torch.int64, device=dev))
+        if own:
+            nws = int(_lib.load().wetts_workspace_bytes(self._handle, B, Tx, 0))
+            pb.update(x=torch.zeros(B, Tx, dtype=torch.int64, device=dev),
+                      x_lengths=torch.zeros(B, dtype=torch.int64, device=dev),
+                      sid=torch.zeros(B, dtype=torch.int64, device=dev), eps_w=torch.zeros(B, 2, Tx, **f32),
+                      ws=torch.empty(max(nws, 16), dtype=torch.uint8, device=dev), nws=nws)
+        return pb
+
+    def _launch_pre(self, lib, pb, length_scale, noise_scale_w):
+        B, Tx = pb["B"], pb["Tx"]
+        s = _lib.current_stream_ptr()
+        status_ptr = C.c_void_p(pb["meta"].data_ptr() + 8 * B)
+        _lib.check(lib.wetts_set_status_word(self._handle, status_ptr, s), "set_status_word")
+        try:
+            g = pb["g"] if self.n_speakers > 0 else None
+            _lib.check(lib.wetts_speaker_embedding(self._handle, _lib.ptr(pb["sid"]) if self.n_speakers > 0 else None, B,
+                                                   _lib.ptr(pb["g"]), s), "speaker_embedding")
+            _lib.check(lib.wetts_text_encoder(self._handle, _lib.ptr(pb["x"]), _lib.ptr(pb["x_lengths"]), _lib.ptr(g), B,
+                                              Tx, _lib.ptr(pb["x_enc"]), _lib.ptr(pb["stats"]), _lib.ptr(pb["x_mask"]),
+                                              _lib.ptr(pb["ws"]), pb["nws"], s), "text_encoder")
+            if self.use_sdp:
+                _lib.check(lib.wetts_duration_sdp(self._handle, _lib.ptr(pb["x_enc"]), _lib.ptr(pb["x_mask"]), _lib.ptr(g),
+                                                  _lib.ptr(pb["eps_w"]), float(noise_scale_w), B, Tx, _lib.ptr(pb["logw"]),
+                                                  status_ptr, _lib.ptr(pb["ws"]), pb["nws"], s), "duration_sdp")
+            else:
+                _lib.check(lib.wetts_duration_dp(self._handle, _lib.ptr(pb["x_enc"]), _lib.ptr(pb["x_mask"]), _lib.ptr(g), B,
+                                                 Tx, _lib.ptr(pb["logw"]), _lib.ptr(pb["ws"]), pb["nws"], s), "duration_dp")
+            _lib.check(lib.wetts_durations_to_lengths(_lib.ptr(pb["logw"]), _lib.ptr(pb["x_mask"]), float(length_scale), B,
+                                                      Tx, _lib.ptr(pb["w_ceil"]), _lib.ptr(pb["cum"]), _lib.ptr(pb["meta"]),
+                                                      status_ptr, s), "durations_to_lengths")
+        finally:
+            lib.wetts_set_status_word(self._handle, None, s)
+
+    def _read_lengths(self, pb):
+        """The one host sync of infer(): y_lengths and the status word in one D2H copy (the output length is data
+        dependent, commons.py:114-115); raises what the reference raises from inside its modules."""
+        B = pb["B"]
+        meta_host = pb["meta"].cpu()
         y_host = meta_host[:B]
         self.last_status = int(meta_host[B].item()) & 0xFFFFFFFF
         if self.last_status & _lib.STATUS_PHONE_ID_RANGE:
@@ -339,30 +349,67 @@ class SynthesizerTrn:
         if self.last_status & (_lib.STATUS_SPLINE_DOMAIN | _lib.STATUS_DURATION_NONFINITE):
             # the reference dies on `assert (discriminant >= 0).all()` (transforms.py:171)
             raise AssertionError("spline inverse: negative discriminant (transforms.py:171)")
-        Ty = int(y_host.max().item()) if B > 0 else 0
-        eps_z = self._randn(B, I, Ty) if eps_z is None else self._f32(eps_z)
-        if tuple(eps_z.shape) != (B, I, Ty):
-            raise ValueError(f"eps_z must be [{B},{I},{Ty}], got {tuple(eps_z.shape)}")
-        f2p = torch.empty(B, Ty, dtype=torch.int32, device=dev)
-        y_mask = torch.empty(B, Ty, dtype=torch.float32, device=dev)
-        attn = torch.empty(B, Ty, Tx, dtype=torch.float32, device=dev)
-        m_p = torch.empty(B, I, Ty, dtype=torch.float32, device=dev)
-        logs_p = torch.empty(B, I, Ty, dtype=torch.float32, device=dev)
-        z_p = torch.empty(B, I, Ty, dtype=torch.float32, device=dev)
-        _lib.check(lib.wetts_length_regulate(self._handle, _lib.ptr(stats), _lib.ptr(cum),
-                                             _lib.ptr(x_mask), _lib.ptr(y_lengths),
-                                             _lib.ptr(eps_z), I * Ty, Ty, float(noise_scale), B,
-                                             Tx, Ty, _lib.ptr(f2p), _lib.ptr(y_mask),
-                                             _lib.ptr(attn), _lib.ptr(m_p), _lib.ptr(logs_p),
-                                             _lib.ptr(z_p), s), "length_regulate")
-        ws, nws = self._workspace(B, Tx, Ty)
-        z = torch.empty(B, I, Ty, dtype=torch.float32, device=dev)
-        _lib.check(lib.wetts_flow_reverse(self._handle, _lib.ptr(z_p), _lib.ptr(y_mask),
-                                          _lib.ptr(g), B, Ty, _lib.ptr(z), _lib.ptr(ws), nws, s),
-                   "flow_reverse")
-        return dict(g=g, x_enc=x_enc, stats=stats, x_mask=x_mask, logw=logw, w_ceil=w_ceil,
-                    y_lengths=y_lengths, y_lengths_host=y_host, frame2phone=f2p, y_mask=y_mask,
-                    attn=attn, m_p=m_p, logs_p=logs_p, z_p=z_p, z=z, B=B, Tx=Tx, Ty=Ty)
+        return y_host, (int(y_host.max().item()) if B > 0 else 0)
+
+    def _post_buffers(self, B, Tx, Ty, own=False):
+        """Buffers of the second half: length regulation -> prior sampling -> flow^-1, for Ty frames."""
+        dev = self.device
+        I = self.inter_channels
+        f32 = dict(dtype=torch.float32, device=dev)
+        qb = dict(B=B, Tx=Tx, Ty=Ty, eps_z=None,
+                  f2p=torch.empty(B, Ty, dtype=torch.int32, device=dev), y_mask=torch.empty(B, Ty, **f32),
+                  attn=torch.empty(B, Ty, Tx, **f32), m_p=torch.empty(B, I, Ty, **f32),
+                  logs_p=torch.empty(B, I, Ty, **f32), z_p=torch.empty(B, I, Ty, **f32), z=torch.empty(B, I, Ty, **f32))
+        if own:
+            nws = int(_lib.load().wetts_workspace_bytes(self._handle, B, Tx, Ty))
+            qb.update(eps_z=torch.zeros(B, I, Ty, **f32), ws=torch.empty(max(nws, 16), dtype=torch.uint8, device=dev),
+                      nws=nws)
+        return qb
+
+    def _launch_post(self, lib, pb, qb, noise_scale):
+        B, Tx, Ty = qb["B"], qb["Tx"], qb["Ty"]
+        I = self.inter_channels
+        s = _lib.current_stream_ptr()
+        g = pb["g"] if self.n_speakers > 0 else None
+        _lib.check(lib.wetts_length_regulate(self._handle, _lib.ptr(pb["stats"]), _lib.ptr(pb["cum"]),
+                                             _lib.ptr(pb["x_mask"]), _lib.ptr(pb["meta"]), _lib.ptr(qb["eps_z"]), I * Ty, Ty,
+                                             float(noise_scale), B, Tx, Ty, _lib.ptr(qb["f2p"]), _lib.ptr(qb["y_mask"]),
+                                             _lib.ptr(qb["attn"]), _lib.ptr(qb["m_p"]), _lib.ptr(qb["logs_p"]),
+                                             _lib.ptr(qb["z_p"]), s), "length_regulate")
+        _lib.check(lib.wetts_flow_reverse(self._handle, _lib.ptr(qb["z_p"]), _lib.ptr(qb["y_mask"]), _lib.ptr(g), B, Ty,
+                                          _lib.ptr(qb["z"]), _lib.ptr(qb["ws"]), qb["nws"], s), "flow_reverse")
+
+    def _encode_stages(self, lib, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w,
+                       eps_w, eps_z, meta, y_lengths, status_ptr, s):
+        B, Tx = x.shape
+        I = self.inter_channels
+        if self.n_speakers > 0 and sid is None:
+            raise ValueError("sid is required when n_speakers > 0")
+        pb = self._pre_buffers(B, Tx)
+        pb["x"], pb["x_lengths"] = x, x_lengths
+        if self.n_speakers > 0:
+            pb["sid"] = self._ids(sid)
+        pb["ws"], pb["nws"] = self._workspace(B, Tx, 0)
+        if self.use_sdp:
+            pb["eps_w"] = self._randn(B, 2, Tx) if eps_w is None else self._f32(eps_w)
+            if tuple(pb["eps_w"].shape) != (B, 2, Tx):
+                raise ValueError(f"eps_w must be [{B},2,{Tx}]")
+        self._launch_pre(lib, pb, length_scale, noise_scale_w)
+        y_host, Ty = self._read_lengths(pb)
+        qb = self._post_buffers(B, Tx, Ty)
+        qb["eps_z"] = self._randn(B, I, Ty) if eps_z is None else self._f32(eps_z)
+        if tuple(qb["eps_z"].shape) != (B, I, Ty):
+            raise ValueError(f"eps_z must be [{B},{I},{Ty}], got {tuple(qb['eps_z'].shape)}")
+        qb["ws"], qb["nws"] = self._workspace(B, Tx, Ty)
+        self._launch_post(lib, pb, qb, noise_scale)
+        return self._stage_dict(pb, qb, y_host, Ty)
+
+    def _stage_dict(self, pb, qb, y_host, Ty):
+        B = pb["B"]
+        return dict(g=pb["g"] if self.n_speakers > 0 else None, x_enc=pb["x_enc"], stats=pb["stats"], x_mask=pb["x_mask"],
+                    logw=pb["logw"], w_ceil=pb["w_ceil"], y_lengths=pb["meta"][:B], y_lengths_host=y_host,
+                    frame2phone=qb["f2p"], y_mask=qb["y_mask"], attn=qb["attn"], m_p=qb["m_p"], logs_p=qb["logs_p"],
+                    z_p=qb["z_p"], z=qb["z"], B=B, Tx=pb["Tx"], Ty=Ty)
 
     def ragged_supported(self):
         """True when the decoder can run a batch ragged (`infer(..., ragged=True)`): float32 ResBlock1 HiFi-GAN."""

@@ -101,7 +101,12 @@ class InferenceSession(_SessionBase):
 
 
 class EncoderSession(_SessionBase):
-    """Streaming front half (export_encoder_forward, models.py:346-358): -> z [B, L, inter]."""
+    """Streaming front half (export_encoder_forward, models.py:346-358): -> z [B, L, inter].
+    `use_graph=True` replays captured HIP graphs for repeating shapes (see GraphedEncoder)."""
+
+    def __init__(self, model, use_graph=False, frame_bucket=32):
+        super().__init__(model)
+        self._graphed = GraphedEncoder(model, frame_bucket) if use_graph else None
 
     def get_inputs(self):
         return InferenceSession.get_inputs(self)
@@ -115,8 +120,91 @@ class EncoderSession(_SessionBase):
         xl = self._dev(feeds["input_lengths"], torch.int64)
         scales = np.asarray(feeds["scales"], dtype=np.float32)
         sid = self._dev(feeds["sid"], torch.int64)
+        if self._graphed is not None:
+            # export_encoder_forward (models.py:346-358): row 0 of `scales`, z * y_mask, time-major
+            st = self._graphed.encode(x, xl, sid, float(scales[0][0]), float(scales[0][1]), float(scales[0][2]))
+            z = (st["z"] * st["y_mask"].unsqueeze(1)).transpose(1, 2)
+            return [z.contiguous().cpu().numpy()]
         z = self.model.export_encoder_forward(x, xl, torch.from_numpy(scales), sid)
         return [z.contiguous().cpu().numpy()]
+
+
+class GraphedEncoder:
+    """hipGraph replay of the encoder call (infer_encoder, models.py:282-331) for repeating shapes.
+
+    The B = 1 encoder call is ~140 launches of ~10 us each with the host issuing them one by one; a kernel trace
+    shows 15-20 % of its span idle between launches (profiles/r04_b1_anatomy.txt).  Its two halves -- up to the
+    durations, and from length regulation through the flow -- sit on either side of the call's one host
+    synchronisation (the frame count is data dependent), so each is captured into its own graph:
+      * the first half per (B, Tx): speaker vector, text encoder, duration predictor, durations -> lengths;
+      * the second half per (B, Tx, frame bucket): the frame count is rounded up to a multiple of `frame_bucket` and
+        the extra frames are frames with mask 0 -- what a shorter utterance's tail is in a padded batch -- so that
+        utterances of similar length replay the same graph.  Results are returned as views of the first Ty frames.
+    Same kernels as the plain path; the flow's tile shapes follow the bucketed length, so z agrees with the plain call
+    to round-off (1e-6), not bit for bit.  The two standard-normal draws are made OUTSIDE the graphs (the Philox
+    (seed, offset) pair is a kernel argument) into the graphs' input buffers, from the same stream positions as the
+    plain path: a seed gives the same audio either way.  Buffers, workspaces included, are owned per graph entry
+    because a graph bakes the pointers in."""
+
+    def __init__(self, model: SynthesizerTrn, frame_bucket=32):
+        if model._handle is None:
+            raise RuntimeError("model must have weights loaded and live on a HIP device")
+        self.model = model
+        self.frame_bucket = int(frame_bucket)
+        self._pre = {}
+        self._post = {}
+
+    def _capture(self, launch):
+        launch()  # un-captured first: one-time initialisation must not land in the capture
+        torch.cuda.synchronize(self.model.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            launch()
+        return graph
+
+    def encode(self, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w):
+        """-> the stage dict of SynthesizerTrn._encode (tensors are views of graph-owned buffers: consume or copy them
+        before the next call with the same shapes)."""
+        from . import _lib
+        m = self.model
+        lib = _lib.load()
+        B, Tx = x.shape
+        I = m.inter_channels
+        key = (int(B), int(Tx), float(length_scale), float(noise_scale_w))
+        e = self._pre.get(key)
+        if e is None:
+            pb = m._pre_buffers(B, Tx, own=True)
+            e = self._pre[key] = {"pb": pb}
+            e["graph"] = self._capture(lambda: m._launch_pre(lib, pb, length_scale, noise_scale_w))
+        pb = e["pb"]
+        pb["x"].copy_(x)
+        pb["x_lengths"].copy_(x_lengths)
+        if m.n_speakers > 0:
+            pb["sid"].copy_(sid)
+        if m.use_sdp:
+            m._randn_into(pb["eps_w"])
+        e["graph"].replay()
+        y_host, Ty = m._read_lengths(pb)
+        fb = self.frame_bucket
+        Tyb = max(fb, -(-Ty // fb) * fb)
+        key2 = key + (Tyb, float(noise_scale))  # (the second graph reads the first one's buffers: same entry)
+        e2 = self._post.get(key2)
+        if e2 is None:
+            qb = m._post_buffers(B, Tx, Tyb, own=True)
+            e2 = self._post[key2] = {"qb": qb}
+            e2["graph"] = self._capture(lambda: m._launch_post(lib, pb, qb, noise_scale))
+        qb = e2["qb"]
+        # randn_like(m_p) of models.py:267 is [B, I, Ty]: drawn contiguously, as the plain path draws it, and placed
+        # in the first Ty frames of the bucketed buffer (the rest is multiplied by mask 0)
+        if Tyb == Ty:
+            m._randn_into(qb["eps_z"])
+        else:
+            qb["eps_z"][:, :, :Ty].copy_(m._randn(B, I, Ty))
+        e2["graph"].replay()
+        view = {k: (qb[k][:, :Ty] if k in ("f2p", "y_mask", "attn") else qb[k][:, :, :Ty])
+                for k in ("f2p", "y_mask", "attn", "m_p", "logs_p", "z_p", "z")}
+        st = m._stage_dict(pb, dict(view, B=B, Tx=Tx, Ty=Ty), y_host, Ty)
+        return st
 
 
 class GraphedDecoder:
