@@ -71,6 +71,9 @@ def parse_args():
                          "export_onnx.py --quant dynamic-quantisation variant)")
     ap.add_argument("--flow-dtype", default=None, choices=["f32", "bf16", "f16"],
                     help="arithmetic of the flow's WaveNet layers (wetts_set_flow_precision)")
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="1: SynthesizerTrn.set_overlap(True) -- the encoder stages of step k + 1 run on a side stream beside "
+                         "the decoder of step k (back-to-back calls as a two-stage pipeline); 0: strictly one stage at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-fixture", type=int, default=16,
                     help="also time the oracle on the first N utterances of the batch as ONE padded call (SURVEY 8d's "
@@ -425,7 +428,8 @@ class HipBackend:
         t_ = time.perf_counter()
         for _ in range(n):
             for hb in pinned:
-                xd2, ld2, sd2 = (t.to(dev, non_blocking=True) for t in hb)
+                # (net.upload: on the stream that reads the ids -- the encoder's side stream when calls are pipelined)
+                xd2, ld2, sd2 = (net.upload(t) if hasattr(net, "upload") else t.to(dev, non_blocking=True) for t in hb)
                 o, _, y_mask, _ = net.infer(xd2, ld2, sid=sd2, **infer_kw)
                 if not pipelined:
                     _ = o.cpu()
@@ -553,6 +557,8 @@ def main():
         if not blob_ok:  # never time a rank that decodes with other weights
             raise SystemExit(f"rank {rank}: weight blob differs across ranks after the broadcast")
     net.load_blob(blob)
+    if args.overlap and hasattr(net, "set_overlap"):
+        net.set_overlap(True)
     if ddtype != "f32":
         net.set_decoder_dtype(ddtype)
     if fdtype != "f32":
@@ -618,6 +624,22 @@ def main():
     be.set_mrf_timing(net, False)
     padded_frames = float(sum(ym.numel() for ym in masks))  # B*Ty: what a padded decode computes
     decoded_frames = frames if decode == "ragged" else padded_frames  # ragged: every row over its own frames
+    # In the timed region the dominant class shares the chip with the NEXT step's encoder stages (--overlap 1), so
+    # its launches last longer than they do alone.  A few extra steps with the pipelining off give the class's
+    # isolated duration -- kernel quality -- beside the timed region's figure (reported as roofline.isolated).
+    iso = None
+    if args.overlap and hasattr(net, "set_overlap"):
+        net.set_overlap(False)
+        be.set_mrf_timing(net, True)
+        iso_frames = 0.0
+        for _ in range(max(1, min(3, args.steps))):
+            _, yms = step()
+            iso_frames += float(sum((ym.sum().item() if decode == "ragged" else ym.numel()) for ym in yms))
+        be.sync()
+        iso_ms, iso_launches = be.read_mrf_timing(net)
+        be.set_mrf_timing(net, False)
+        net.set_overlap(True)
+        iso = (iso_ms, iso_launches, iso_frames)
 
     # PCIe-inclusive variant (SURVEY 8d's wall: H2D of the ids, D2H of the audio; the driver contract
     # says inputs are resident when the timed region starts, so this is reported beside `value`,
@@ -733,6 +755,15 @@ def main():
                                  f"{(mfl / mby) if mby > 0 else 0.0:.0f} flop/B from wetts_hifigan_cost > ridge ~20)"},
             "mrf_share_of_step": mrf_ms / (elapsed * 1e3),
         }
+    if iso and iso[0] > 0 and roofline.get("unit") in ("TFLOP/s", "GB/s"):
+        iso_ms, iso_launches, iso_frames = iso
+        per = (mfl if roofline["unit"] == "TFLOP/s" else (0.5 if ddtype in ("bf16", "f16") else 1.0) * mby) * iso_frames
+        ach = per / (iso_ms * 1e-3) / (1e12 if roofline["unit"] == "TFLOP/s" else 1e9)
+        roofline["isolated"] = {
+            "achieved": ach, "frac": ach / roofline["peak"], "avg_launch_ms": iso_ms / max(1, iso_launches),
+            "note": "the same class over extra steps with the pipelining off (nothing else on the chip): kernel quality; "
+                    "`achieved` / `frac` above are the timed region's, where the class runs beside the next step's "
+                    "encoder stages"}
     backend = dist.get_backend() if world > 1 else "none"
     observed_world = dist.get_world_size() if world > 1 else 1
     prec = ("fp32" if ddtype == "f32" else
@@ -762,6 +793,8 @@ def main():
                                f"{prec}, {n_speakers} speaker(s), {sr} Hz ({wtag})",
                    "global_batch": total, "phonemes": phonemes, "hop": hop,
                    "padded_sub_batches_per_step": nb, "decode": decode,
+                   "pipelining": ("encoder stages of call k + 1 on a side stream beside the decoder of call k "
+                                  "(SynthesizerTrn.set_overlap)") if args.overlap else "none",
                    "sub_batch_plan": {"chosen_by": "equal-count (--buckets)" if args.buckets > 0 else
                                       "wetts_amd.batching.plan (DP over the length-sorted shard)",
                                       "max_pad_frac": args.max_pad_frac, "phoneme_pad_frac": pl.stats["pad_frac"],

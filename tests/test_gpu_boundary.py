@@ -503,3 +503,38 @@ def test_graphed_encoder_matches_plain_and_keeps_the_noise_stream():
     torch.manual_seed(3)
     ok = graphed.run(None, feeds)[0]  # and the entry still works afterwards
     assert np.isfinite(ok).all()
+
+
+def test_overlap_mode_pipelines_calls_without_changing_results():
+    """set_overlap(True): the encoder stages of a call run on a side stream beside the previous call's decoder.  A
+    sequence of back-to-back calls of changing shapes (no synchronisation in between) must return exactly what the
+    same calls return one at a time -- audio, alignment, z -- and switching modes mid-stream must be safe."""
+    net, case, cfg, sd, W = _model("tiny_sdp_b3")
+    g = torch.Generator().manual_seed(4)
+    calls = []
+    for B, Tx in [(3, 12), (1, 5), (4, 20), (2, 12), (3, 12), (5, 17)]:
+        x = torch.randint(0, int(case["n_vocab"]), (B, Tx), generator=g).cuda()
+        xl = torch.randint(1, Tx + 1, (B,), generator=g)
+        xl[0] = Tx
+        calls.append((x, xl.cuda(), torch.randint(0, int(case["n_speakers"]), (B,), generator=g).cuda()))
+    torch.cuda.synchronize()
+
+    def run_all(overlap, sync_each):
+        net.set_overlap(overlap)
+        torch.manual_seed(21)
+        outs = []
+        for x, xl, sid in calls:
+            o, attn, ym, (z, *_r) = net.infer(x, xl, sid=sid, noise_scale=0.667, length_scale=1.0, noise_scale_w=0.8)
+            outs.append((o, attn, z))
+            if sync_each:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return [tuple(t.cpu() for t in r) for r in outs]
+
+    ref = run_all(False, True)
+    piped = run_all(True, False)
+    again = run_all(False, False)
+    for a, b, c in zip(ref, piped, again):
+        for ta, tb, tc in zip(a, b, c):
+            assert ta.shape == tb.shape == tc.shape and torch.equal(ta, tb) and torch.equal(ta, tc)
+    net.set_overlap(False)

@@ -167,7 +167,8 @@ def synthesize(net, seqs, sids=None, noise_scale=0.667, length_scale=1.0, noise_
             x[r, :lens[i]] = torch.as_tensor(seqs[i], dtype=torch.long)
         xl = torch.tensor([lens[i] for i in b.indices], dtype=torch.long)
         sid = None if sids is None else torch.tensor([int(sids[i]) for i in b.indices], dtype=torch.long)
-        o, _, y_mask, _ = net.infer(x.to(dev), xl.to(dev), sid=None if sid is None else sid.to(dev),
+        up = getattr(net, "upload", None) or (lambda t, dtype=None: t.to(dev))
+        o, _, y_mask, _ = net.infer(up(x), up(xl), sid=None if sid is None else up(sid),
                                     noise_scale=noise_scale, length_scale=length_scale,
                                     noise_scale_w=noise_scale_w, ragged=ragged)
         yl = net._last["y_lengths_host"]

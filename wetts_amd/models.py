@@ -78,6 +78,9 @@ class SynthesizerTrn:
         self._blob = None      # CPU float32 blob (weights live here until .to(device))
         self._handle = None    # wetts_model_t*
         self._ws = _Workspace()
+        self._ws_dec = _Workspace()  # the decoder's own scratch in overlap mode (see set_overlap)
+        self._enc_stream = None
+        self.overlap = False
         self.quiet = True      # the reference prints stage timers on every call (:273-279)
         self.last_status = 0
 
@@ -132,6 +135,32 @@ class SynthesizerTrn:
             _lib.check(_lib.load().wetts_set_flow_precision(self._handle, prec),
                        "set_flow_precision")
         return self
+
+    def set_overlap(self, on=True):
+        """Back-to-back calls as a two-stage pipeline (not in the reference).  With overlap on, the encoder stages of
+        an infer() call -- text encoder, durations, flow: a few hundred small launches that cannot fill the chip --
+        run on a side stream and therefore BESIDE whatever the caller's stream still holds, in a serving loop the
+        previous call's decoder; the decoder waits for them by an event and runs on the caller's stream with its own
+        workspace.  Results are identical; every returned tensor is safe to use on the caller's stream.  Contract: the
+        input tensors of a call must already be materialised when it is made -- they are read on the side stream
+        without waiting for the caller's stream (waiting would put the call behind the previous decoder again).  Device
+        tensors that exist before the serving loop starts, or that come from `upload()`, satisfy it."""
+        if bool(on) != self.overlap and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)  # the two modes share the encoder workspace differently: drain first
+        self.overlap = bool(on)
+        return self
+
+    def upload(self, t, dtype=None):
+        """Host tensor / array -> device tensor on the stream that will read it: the caller's stream, or in overlap
+        mode the encoder's side stream (whose work is NOT ordered behind the caller's stream, see set_overlap).  The
+        wetts_amd hosts (sessions, batching, CLI) put their inputs on the device through this."""
+        t = torch.as_tensor(t)
+        if not (self.overlap and self.device.type == "cuda"):
+            return t.to(device=self.device, dtype=dtype)
+        if self._enc_stream is None:
+            self._enc_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._enc_stream):
+            return t.to(device=self.device, dtype=dtype)
 
     def blob_layout(self):
         return checkpoint.blob_layout(self.cfg)
@@ -261,8 +290,7 @@ class SynthesizerTrn:
         lib = self._require()
         x = self._ids(x)
         x_lengths = self._ids(x_lengths)
-        return self._encode_stages(lib, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, eps_w, eps_z,
-                                   None, None, None, None)
+        return self._encode_stages(lib, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, eps_w, eps_z)
 
     def _randn(self, *shape):
         """Standard-normal tensor from the library's Philox kernel (replaces torch.randn).
@@ -379,8 +407,7 @@ class SynthesizerTrn:
         _lib.check(lib.wetts_flow_reverse(self._handle, _lib.ptr(qb["z_p"]), _lib.ptr(qb["y_mask"]), _lib.ptr(g), B, Ty,
                                           _lib.ptr(qb["z"]), _lib.ptr(qb["ws"]), qb["nws"], s), "flow_reverse")
 
-    def _encode_stages(self, lib, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w,
-                       eps_w, eps_z, meta, y_lengths, status_ptr, s):
+    def _encode_stages(self, lib, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, eps_w, eps_z):
         B, Tx = x.shape
         I = self.inter_channels
         if self.n_speakers > 0 and sid is None:
@@ -423,7 +450,13 @@ class SynthesizerTrn:
         B = z.shape[0]
         if B == 0 or L == 0:  # (z * y_mask)[:, :, :0] -> empty audio, nothing to launch
             return torch.empty(B, 1, 0, dtype=torch.float32, device=self.device)
-        ws, nws = self._workspace(B, 0, L)
+        if self.overlap:  # the next call's encoder stages may be using self._ws on the side stream by now
+            nws = lib.wetts_workspace_bytes(self._handle, B, 0, L)
+            if nws < 0:
+                raise _lib.WettsError("workspace_bytes failed")
+            ws = self._ws_dec.get(nws, self.device)
+        else:
+            ws, nws = self._workspace(B, 0, L)
         audio = torch.empty(B, 1, L * self.hop_length, dtype=torch.float32, device=self.device)
         if y_lengths is not None:
             _lib.check(lib.wetts_hifigan_ragged(self._handle, _lib.ptr(z), z.stride(0), z.stride(1),
@@ -447,8 +480,22 @@ class SynthesizerTrn:
         padded batch to the longest utterance; ragged decodes row b over its own y_lengths[b] frames -- the audio
         the reference returns when that utterance is synthesised alone (its CLI's call shape) -- and writes zeros
         behind it.  The masked stages (encoder, durations, flow) are batch independent either way."""
-        st = self._encode(x, x_lengths, sid, float(noise_scale), float(length_scale),
-                          float(noise_scale_w), eps_w, eps_z)
+        if self.overlap and self.device.type == "cuda":
+            main = torch.cuda.current_stream(self.device)
+            if self._enc_stream is None:
+                self._enc_stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._enc_stream):
+                st = self._encode(x, x_lengths, sid, float(noise_scale), float(length_scale),
+                                  float(noise_scale_w), eps_w, eps_z)
+                done = torch.cuda.Event()
+                done.record(self._enc_stream)
+            main.wait_event(done)
+            for v in st.values():  # allocated on the side stream, consumed (and later freed) on the caller's
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    v.record_stream(main)
+        else:
+            st = self._encode(x, x_lengths, sid, float(noise_scale), float(length_scale),
+                              float(noise_scale_w), eps_w, eps_z)
         Ty = st["Ty"]
         L = Ty if max_len is None else max(0, min(Ty, int(max_len)))
         o = self._decode(st["z"], st["g"], st["y_mask"], L, st["y_lengths"] if ragged else None)

@@ -27,7 +27,7 @@ class _SessionBase:
         self.model = model
 
     def _dev(self, a, dtype):
-        return torch.as_tensor(np.asarray(a)).to(device=self.model.device, dtype=dtype)
+        return self.model.upload(np.asarray(a), dtype)
 
     def get_providers(self):
         return ["WettsHIPExecutionProvider"]
