@@ -303,6 +303,31 @@ def test_wn_update_in_the_conv_epilogue_is_bit_identical(name):
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("name", ["tiny_sdp_b3", "v1_b2", "v1_b4x128", "aishell3_b4x128", "tiny_mono_post_b2x64"])
+def test_wn_gate_in_the_conv_epilogue_is_bit_identical(name):
+    """The f32 flow's gate tanh(a[:H]) * sigmoid(a[H:]) (commons.py:98-105) runs in the epilogue of the in_layer conv
+    (OUT_GATE: weight rows packed interleaved so that a lane holds both halves of an output row; conv_small_kernel for
+    short calls, the 64x64 tiles above) instead of gate_kernel on the 2H-row tensor: the same sums, the same bias order,
+    the same tanhf / expf, so z and the audio must be EQUAL -- with and without the speaker term."""
+    case = util.load_case(name)
+    outs = []
+    for gate in ("1", "0"):
+        os.environ["WETTS_TUNE"] = "wn_gate=" + gate
+        try:
+            net, cfg, W = _model(case)
+        finally:
+            del os.environ["WETTS_TUNE"]
+        ns, ls, nsw = [float(v) for v in case["scales"]]
+        o, _, _, (z, *_r) = net.infer(util.t(case["x"]).cuda(), util.t(case["x_lengths"]).cuda(),
+                                      sid=util.t(case["sid"]).cuda(), noise_scale=ns, length_scale=ls,
+                                      noise_scale_w=nsw, eps_w=util.t(case["eps_w"]).cuda(),
+                                      eps_z=util.t(case["eps_z"]).cuda())
+        outs.append((z.cpu().numpy(), o.cpu().numpy()))
+    assert np.isfinite(outs[0][0]).all()
+    assert np.array_equal(outs[0][0], outs[1][0]), f"z: max |diff| {np.abs(outs[0][0] - outs[1][0]).max()}"
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("name", ["tiny_sdp_b3", "v1_b4x128", "aishell3_b4x128"])
 def test_dds_fused_kernel_matches_the_layerwise_path(name, mode):

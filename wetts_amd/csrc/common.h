@@ -72,7 +72,12 @@ static inline bool lds_opt_in(const void* kernel, signed char* state) {
 constexpr int kConvCK = 16;  // input channels staged per LDS chunk (fixed by the packed layout)
 
 enum InAct { IN_NONE = 0, IN_LRELU = 1 };
-enum OutAct { OUT_NONE = 0, OUT_RELU = 1, OUT_GELU = 2 };  // GELU = exact erf form (F.gelu default)
+// GELU = exact erf form (F.gelu default).  GATE = the WaveNet gate (commons.py:98-105) in the epilogue of the in_layer
+// conv: the weights are packed with rows interleaved (PackedConv.gate_H: packed row 2i = tanh row i, 2i + 1 = sigmoid
+// row H + i, which the 32x32 MFMA leaves in neighbouring accumulator registers of one lane) and the launch writes
+// tanh(a_i) * sigmoid(a_{H+i}) to the H-row tensor `out`; bias / bias_b stay in the reference's row order
+enum OutAct { OUT_NONE = 0, OUT_RELU = 1, OUT_GELU = 2, OUT_GATE = 3 };
+__device__ __forceinline__ float wn_gate(float ta, float sa) { return tanhf(ta) * (1.f / (1.f + expf(-sa))); }
 
 struct ConvParams {
   // input
@@ -159,15 +164,17 @@ struct PackedConv {
   int Cout = 0;            // logical output channels (M/up for transposed)
   int k_orig = 0;
   int off_lo = 0, span = 0, nchunks = 0;
+  int gate_H = 0;          // > 0: M = 2 gate_H rows packed interleaved for OUT_GATE launches (only those)
 };
 
 // Packs a natural-layout weight into MFMA fragment order on the device.
 //  transposed == 0: w is Conv1d [Cout][Cin][k]
 //  transposed == 1: w is ConvTranspose1d [Cin][Cout][k] with stride `up`
 // rev_in: input channels in reverse order (the flow's Flip folded into the weights of `pre`)
+// gate_H: rows interleaved for the gate epilogue (see OutAct)
 int32_t pack_conv_weight(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
                          int dil, int pad, int transposed, int up, hipStream_t stream,
-                         PackedConv* out, int rev_in = 0);
+                         PackedConv* out, int rev_in = 0, int gate_H = 0);
 void free_packed(PackedConv* pc);
 
 // Launches the conv.  Fills geometry fields of `p` from `pc`; caller fills the I/O fields.

@@ -43,7 +43,7 @@ __device__ __forceinline__ float lrelu2(float x, float slope) {
 // ------------------------------------------------------------------------------------------
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ out,
                                         int M, int Cin, int Cout, int k, int ktaps, int up,
-                                        int transposed, int rev_in, int G, int64_t total) {
+                                        int transposed, int rev_in, int gate_H, int G, int64_t total) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   int s = (int)(idx & 3);
@@ -62,7 +62,8 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
   float v = 0.f;
   if (row < M && ci < Cin) {
     if (!transposed) {
-      v = w[((int64_t)row * Cin + (rev_in ? Cin - 1 - ci : ci)) * k + tap];
+      const int src = gate_H > 0 ? (row & 1) * gate_H + (row >> 1) : row;
+      v = w[((int64_t)src * Cin + (rev_in ? Cin - 1 - ci : ci)) * k + tap];
     } else {
       int co = row / up, ph = row % up;
       int kk = ph + tap * up;
@@ -74,7 +75,9 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
 
 int32_t pack_conv_weight(const float* w_dev, const float* bias_dev, int Cout, int Cin, int k,
                          int dil, int pad, int transposed, int up, hipStream_t stream,
-                         PackedConv* pc, int rev_in) {
+                         PackedConv* pc, int rev_in, int gate_H) {
+  WETTS_REQUIRE(gate_H == 0 || (!transposed && Cout == 2 * gate_H), "gate packing needs a Conv1d with 2 * gate_H rows");
+  pc->gate_H = gate_H;
   pc->Cin = Cin;
   pc->Cout = Cout;
   pc->k_orig = k;
@@ -108,7 +111,7 @@ int32_t pack_conv_weight(const float* w_dev, const float* bias_dev, int Cout, in
   int64_t blocks = (total + threads - 1) / threads;
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream,
                      w_dev, pc->wpk, pc->M, Cin, Cout, k, pc->ktaps, up > 0 ? up : 1, transposed,
-                     rev_in, G, total);
+                     rev_in, gate_H, G, total);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -123,7 +126,7 @@ void free_packed(PackedConv* pc) {
 // ------------------------------------------------------------------------------------------
 // EPI: 0 = generic epilogue (runtime activation / masks / late residual), 1 = plain
 // (acc + bias [+ per-utterance bias]), 2 = plain followed by the MRF mean division, 3 = polyphase
-// ConvTranspose1d store, 4 = plain times the output mask (the flow's pre / post convs).  MRF = name tag of the ResBlock launches (no code difference): rocprofv3
+// ConvTranspose1d store, 4 = plain times the output mask (the flow's pre / post convs), 5 = the WaveNet gate.  MRF = name tag of the ResBlock launches (no code difference): rocprofv3
 // --stats then separates bench.py's dominant-kernel class from the flow / encoder convs that share
 // the tile shape.
 // Four 32x32 accumulators per wave (64 AGPRs) plus ~105 VGPRs sat one allocation granule above the
@@ -418,6 +421,35 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, int bid) {
   const int64_t rb = (int64_t)b * p.r_bs;
   const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
   const float* omask = p.out_mask ? p.out_mask + (int64_t)b * p.out_mask_stride : nullptr;
+  if (EPI == 5) {
+    // WaveNet gate (OUT_GATE, common.h): packed rows (row, row + 1) = (tanh row, sigmoid row) of output row row / 2 sit
+    // in accumulator registers (r, r + 1) of one lane.  Its own EPI value: this code in the shared generic tail below
+    // cost every instantiation ~40 registers (the MRF kernels spilled).
+    const int gH = p.M >> 1;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const int mrow0 = mtile * MT + (wm * MB + i) * 32 + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int row = mrow0 + (r & 3) + 8 * (r >> 2);
+        if (row >= p.M) continue;
+        const int gi = row >> 1;
+        // the sums of the launch this one replaces, to the bit: whole tiles of the plain epilogue add acc + (bias +
+        // bias_b), edge tiles (the generic tail) (acc + bias) + bias_b
+        float bt = 0.f, bs = 0.f, ut = 0.f, us = 0.f;
+        if (p.bias) { bt = p.bias[gi]; bs = p.bias[gH + gi]; }
+        if (bb) { ut = bb[gi]; us = bb[gH + gi]; }
+        if (full_tile) { bt += ut; bs += us; ut = us = 0.f; }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int col = n0 + wn * (32 * NB) + j * 32 + (lane & 31);
+          if (col < N)
+            p.out[ob + (int64_t)gi * p.o_cs + col] = wn_gate((acc[i][j][r] + bt) + ut, (acc[i][j][r + 1] + bs) + us);
+        }
+      }
+    }
+    return;
+  }
   if (EPI != 0 && full_tile) {
     char* obase = reinterpret_cast<char*>(p.out + ob + (int64_t)wrow0 * p.o_cs + wcol0);
     const unsigned ocs4 = (unsigned)p.o_cs * 4u;
@@ -596,7 +628,12 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
   // epilogue specialisation: residual / running sum are folded into the accumulator init
   // whenever there is no output activation or mask, which leaves "acc + bias [/ div]"
   const bool plain = p.up == 0 && p.out_act == OUT_NONE && p.out_mask == nullptr && p.wn_skip == nullptr;
-  if (p.up > 0 && p.up_shift >= 0 && p.out_act == OUT_NONE && !p.out_mask && !p.res && !p.accum &&
+  if (p.out_act == OUT_GATE) {  // (prepare_conv has checked that nothing else is asked of the epilogue)
+    if (fast)
+      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 5, false, true>), grid, blk, lds, stream, p);
+    else
+      hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 5, false>), grid, blk, lds, stream, p);
+  } else if (p.up > 0 && p.up_shift >= 0 && p.out_act == OUT_NONE && !p.out_mask && !p.res && !p.accum &&
       !p.bias_b && p.out_div == 1.f) {
     if (fast)
       hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, WM, WN, 3, false, true>), grid, blk, lds, stream, p);
@@ -650,6 +687,9 @@ static int32_t prepare_conv(const PackedConv& pc, ConvParams& p) {
   for (int q = 0; q < 16; ++q)
     if (pc.up == (1 << q)) p.up_shift = q;
   WETTS_REQUIRE(pc.wpk != nullptr, "conv weight not packed");
+  WETTS_REQUIRE((p.out_act == OUT_GATE) == (pc.gate_H > 0), "gate epilogue and interleaved packing go together");
+  WETTS_REQUIRE(p.out_act != OUT_GATE || (!p.res && !p.accum && !p.out_mask && p.out_div == 1.f && !p.wn_skip && pc.up == 0),
+                "gate epilogue: plain store only");
   // a 1x1 conv whose output is multiplied by the SAME 0/1 mask does not need it on the input: columns with
   // mask 0 come out 0 either way, the others are untouched (and the plain input can use FAST staging)
   if (pc.ktaps == 1 && pc.up == 0 && p.in_mask && p.in_mask == p.out_mask &&

@@ -197,6 +197,15 @@ __global__ __launch_bounds__(64 * KG) void conv_small_kernel(const ConvParams p)
       if (t < 0 || t >= p.Tout) continue;
     }
     float v = fin[q];
+    if (p.out_act == OUT_GATE) {  // (tanh, sigmoid) rows of output row row / 2 in registers (r, r + 1): FPW >= 2
+      if (q & 1) continue;
+      const int gi = row >> 1, gH = p.M >> 1;
+      float sa = fin[(q + 1) % FPW];
+      if (p.bias) { v += p.bias[gi]; sa += p.bias[gH + gi]; }
+      if (bb) { v += bb[gi]; sa += bb[gH + gi]; }
+      p.out[ob + (int64_t)gi * p.o_cs + t] = wn_gate(v, sa);
+      continue;
+    }
     if (p.bias) v += p.bias[co];
     if (bb) v += bb[co];
     if (p.wn_skip) {  // WaveNet residual / skip update instead of a store (common.h)
@@ -266,6 +275,7 @@ static int32_t launch_small_cfg(const ConvParams& p, hipStream_t stream, int for
   if (NS >= ns16 && blocks * 4 <= 512) kg = 16;
   if (force_kg) kg = force_kg;
   if (kg > MAXKG) kg = MAXKG;
+  if (p.out_act == OUT_GATE && kg > 8) kg = 8;  // the gate pairs two accumulator registers of one wave's share
   while (kg > 4 && small_lds_bytes(SCH, p.span, kg) > 128 * 1024) kg >>= 1;
   if constexpr (MAXKG >= 16)
     if (kg == 16) return launch_small_kg<KT, SCH, 16>(p, stream);

@@ -120,7 +120,7 @@ struct PwLds {
 
 // acc + bias (+ per-utterance bias) -> activation -> output mask -> store; buffer addressing (one lane offset per
 // 32-column unit + a uniform row offset), bias rows by scalar loads
-template <int NBP>
+template <int NBP, bool GATE = false>
 __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[NBP], int b, int rowu, int colj0, int half) {
   // ---- epilogue -------------------------------------------------------------------------------------------------
   // bias: rows rowu + rr (+ 4 for the upper half-wave) are uniform addresses -> scalar loads, one select per row
@@ -135,6 +135,30 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[NBP
     om[j] = (io.mask && col < p.N) ? io.mask[col] : 1.f;
   }
   const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
+  if (GATE) {
+    // WaveNet gate (OUT_GATE, common.h): packed rows (2i, 2i + 1) = (tanh row i, sigmoid row H + i) sit in registers
+    // (r, r + 1) of one lane; output row i of the H-row tensor.  M = 2 H is a multiple of 128 here (conv_dma launch).
+    const int gH = p.M >> 1;
+#pragma unroll
+    for (int j = 0; j < NBP; ++j) voff[j] = (2 * half * io.o_cs + colj0 + 32 * j) * 4;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const int rr = (r & 3) + 8 * (r >> 2);  // even
+      const int ilo = (rowu + rr) >> 1, ihi = ilo + 2;  // uniform output rows of the two half-waves
+      float t0 = 0.f, t1 = 0.f, s0 = 0.f, s1 = 0.f;
+      if (p.bias) { t0 = p.bias[ilo]; t1 = p.bias[ihi]; s0 = p.bias[gH + ilo]; s1 = p.bias[gH + ihi]; }
+      if (bb) { t0 += bb[ilo]; t1 += bb[ihi]; s0 += bb[gH + ilo]; s1 += bb[gH + ihi]; }
+      const float tb = half ? t1 : t0, sb = half ? s1 : s0;
+      const int soff = __builtin_amdgcn_readfirstlane(ilo * io.o_cs * 4);
+#pragma unroll
+      for (int j = 0; j < NBP; ++j) {
+        if (colj0 + 32 * j >= p.N) continue;
+        const float v = wn_gate(acc[j][r] + tb, acc[j][r + 1] + sb);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rso, voff[j], soff, 0);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int rr = (r & 3) + 8 * (r >> 2);
@@ -314,7 +338,7 @@ struct TapLds {
   static size_t bytes(int ktaps) { return (size_t)2 * (kB + 4 * ktaps * 256) * sizeof(float); }
 };
 
-template <int NBMAX, int NBP>
+template <int NBMAX, int NBP, bool GATE>
 __device__ __forceinline__ void tap_pass(const PwParams& p, float* smem, int b, int mtile, int n0, int lane, int wave,
                                          __amdgpu_buffer_rsrc_t rsx, __amdgpu_buffer_rsrc_t rsw) {
   using L = TapLds<NBMAX>;
@@ -394,10 +418,10 @@ __device__ __forceinline__ void tap_pass(const PwParams& p, float* smem, int b, 
     }
   }
   __syncthreads();
-  pw_epilogue<NBP>(p, acc, b, rowu, colj0, half);
+  pw_epilogue<NBP, GATE>(p, acc, b, rowu, colj0, half);
 }
 
-template <int NBMAX>
+template <int NBMAX, bool GATE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void conv_dma_kernel(const PwParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -419,13 +443,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
   while (u < u1) {
     const int w = u1 - u;
     if (NBMAX >= 4 && w >= 4) {
-      tap_pass<NBMAX, (NBMAX >= 4 ? 4 : NBMAX)>(p, smem, b, mtile, u * 32, lane, wave, rsx, rsw);
+      tap_pass<NBMAX, (NBMAX >= 4 ? 4 : NBMAX), GATE>(p, smem, b, mtile, u * 32, lane, wave, rsx, rsw);
       u += 4;
     } else if (NBMAX >= 2 && w >= 2) {
-      tap_pass<NBMAX, (NBMAX >= 2 ? 2 : NBMAX)>(p, smem, b, mtile, u * 32, lane, wave, rsx, rsw);
+      tap_pass<NBMAX, (NBMAX >= 2 ? 2 : NBMAX), GATE>(p, smem, b, mtile, u * 32, lane, wave, rsx, rsw);
       u += 2;
     } else {
-      tap_pass<NBMAX, 1>(p, smem, b, mtile, u * 32, lane, wave, rsx, rsw);
+      tap_pass<NBMAX, 1, GATE>(p, smem, b, mtile, u * 32, lane, wave, rsx, rsw);
       u += 1;
     }
   }
@@ -447,7 +471,7 @@ static int device_cus() {
 bool pw_gemm_eligible(const PackedConv& pc, const ConvParams& p) {
   if (pc.ktaps != 1 || pc.up != 0 || pc.pad != 0) return false;
   if (p.in_act != IN_NONE || p.in_mask != nullptr || p.in_rev_base >= 0 || p.lens != nullptr) return false;
-  if (p.accum || p.out_div != 1.f) return false;
+  if (p.accum || p.out_div != 1.f || p.out_act == OUT_GATE) return false;
   if (p.wn_skip && ((p.wn_H % 32) != 0 || (pc.M % 32) != 0 || p.res || p.out_act != OUT_NONE || p.out_mask ||
                     p.wn_mask_stride < p.Tout))
     return false;  // WaveNet update: whole 32-row blocks on either side of wn_H, read-modify-write without row predicates
@@ -469,6 +493,7 @@ bool conv_dma_eligible(const PackedConv& pc, const ConvParams& p) {
   if (p.accum || p.out_div != 1.f || p.wn_skip != nullptr) return false;
   if (p.res && (p.out_act != OUT_NONE || p.out_mask)) return false;
   if (p.res && (pc.M % 128) != 0) return false;
+  if (p.out_act == OUT_GATE && (pc.M % 128) != 0) return false;  // whole wave blocks: no row predicates in the gate store
   if ((pc.Cin % 16) != 0 || pc.Cin < 32) return false;
   if ((p.x_cs & 3) != 0 || (p.x_bs & 3) != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0) return false;
   if (p.Tin > p.x_cs || p.x_cs < 4 || p.Tout != p.Tin || p.Tin < 8) return false;
@@ -566,12 +591,18 @@ int32_t launch_conv_dma(const PackedConv& pc, const ConvParams& cp, hipStream_t 
   // too few MFMAs per barrier and the 64x64 tiles of conv_mfma_kernel are faster (B = 16: 63 vs 78 TF/s)
   if (taken) *taken = p.upb >= 3 && blocks >= 2 * device_cus() && (pc.M % 128) == 0;
   if (taken && !*taken) return WETTS_OK;
-  static signed char opt_in[64] = {};
-  if (lds > 64 * 1024 && !lds_opt_in(reinterpret_cast<const void*>(&conv_dma_kernel<4>), opt_in)) {
+  static signed char opt_in[64] = {}, opt_in_gate[64] = {};
+  const bool gate = cp.out_act == OUT_GATE;
+  if (lds > 64 * 1024 &&
+      !(gate ? lds_opt_in(reinterpret_cast<const void*>(&conv_dma_kernel<4, true>), opt_in_gate)
+             : lds_opt_in(reinterpret_cast<const void*>(&conv_dma_kernel<4>), opt_in))) {
     set_error("conv_dma_kernel: the device refused the %zu-byte dynamic LDS opt-in", lds);
     return WETTS_E_HIP;
   }
-  hipLaunchKernelGGL((conv_dma_kernel<4>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  if (gate)
+    hipLaunchKernelGGL((conv_dma_kernel<4, true>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  else
+    hipLaunchKernelGGL((conv_dma_kernel<4>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

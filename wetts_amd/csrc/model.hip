@@ -462,6 +462,7 @@ struct wetts_model {
   // wastes at most this share of the tile (resblock2_stage16.hip; bit-identical to chain by chain); 0 = never
   int stage2_pct = 30;
   int dds_fused = 1;
+  int wn_gate = 1;      // WETTS_TUNE wn_gate: the f32 flow's gate in the in_layer conv's epilogue (0: gate_kernel on the 2H-row tensor)
   int wn_fuse = 1;      // WETTS_TUNE wn_fuse: the f32 flow's residual / skip update in the res_skip conv's epilogue (1: small launches, 2: always, 0: wn_update_kernel)
   int small_fork = 1;   // WETTS_TUNE small_fork: the chains of a small (streaming-window) stage on their own streams
   int conv_groups = 1;  // WETTS_TUNE conv_groups: independent single convs of a ResBlock1 step in one launch (0: one each)
@@ -497,11 +498,11 @@ struct Bump {
 
 static int32_t pack(wetts_model* m, const std::string& wname, const std::string& bname, int Cout,
                     int Cin, int k, int dil, int pad, int transposed, int up, hipStream_t s,
-                    PackedConv* pc, int rev_in = 0) {
+                    PackedConv* pc, int rev_in = 0, int gate_H = 0) {
   const float* w = m->T(wname);
   WETTS_REQUIRE(w != nullptr, "tensor %s missing from layout", wname.c_str());
   const float* b = bname.empty() ? nullptr : m->T(bname);
-  WETTS_TRY(pack_conv_weight(w, b, Cout, Cin, k, dil, pad, transposed, up, s, pc, rev_in));
+  WETTS_TRY(pack_conv_weight(w, b, Cout, Cin, k, dil, pad, transposed, up, s, pc, rev_in, gate_H));
   m->all_packed.push_back(pc);
   return WETTS_OK;
 }
@@ -664,8 +665,9 @@ static int32_t build_model(wetts_model* m, hipStream_t s) {
     const int fk = c->flow_kernel_size;
     for (int i = 0; i < c->flow_wn_layers; ++i) {
       // WN dilation_rate = 1 (models.py:133-138) => dilation 1**i = 1, padding (k-1)/2
+      // rows interleaved (tanh row i, sigmoid row H + i): the gate runs in the conv's epilogue (OUT_GATE, common.h)
       WETTS_TRY(pack(m, p + S(".enc.in_layers.%d.weight", i), p + S(".enc.in_layers.%d.bias", i),
-                     2 * H, H, fk, 1, (fk - 1) / 2, 0, 0, s, &fw.in_layers[i]));
+                     2 * H, H, fk, 1, (fk - 1) / 2, 0, 0, s, &fw.in_layers[i], 0, H));
       int rs = (i < c->flow_wn_layers - 1) ? 2 * H : H;
       WETTS_TRY(pack(m, p + S(".enc.res_skip_layers.%d.weight", i),
                      p + S(".enc.res_skip_layers.%d.bias", i), rs, H, 1, 1, 0, 0, 0, s,
@@ -912,7 +914,7 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     // WETTS_TUNE="name=value,name=value", names as in the table below
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {
-        {"stage2_pct", &m->stage2_pct}, {"dds_fused", &m->dds_fused}, {"wn_fuse", &m->wn_fuse}, {"mrf_streams", &m->mrf_streams},                  {"fuse32_lds", &m->fuse32_lds},
+        {"stage2_pct", &m->stage2_pct}, {"dds_fused", &m->dds_fused}, {"wn_fuse", &m->wn_fuse}, {"wn_gate", &m->wn_gate}, {"mrf_streams", &m->mrf_streams},                  {"fuse32_lds", &m->fuse32_lds},
         {"fuse32_kmax128", &m->fuse32_kmax128},   {"fuse32_maxc", &m->fuse32_maxc},
         {"fuse32_kmax", &m->fuse32_kmax},         {"fuse32_kwide", &m->fuse32_kwide},
         {"fuse2_maxc", &m->fuse2_maxc},           {"fuse2_waste_pct", &m->fuse2_waste_pct},
@@ -942,6 +944,16 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
         }
         pos = end + 1;
       }
+    }
+    if (r == WETTS_OK && !m->wn_gate) {  // A/B: the in_layers back in the reference's row order, gate_kernel behind them
+      const int H = cfg->hidden_channels, fk = cfg->flow_kernel_size;
+      for (int f = 0; f < cfg->flow_n_flows && r == WETTS_OK; ++f)
+        for (int i = 0; i < cfg->flow_wn_layers && r == WETTS_OK; ++i) {
+          const std::string p = S("flow.flows.%d.enc.in_layers.%d", flow_key_stride(cfg) * f, i);
+          free_packed(&m->flows[f].in_layers[i]);
+          r = pack_conv_weight(m->T(p + ".weight"), m->T(p + ".bias"), 2 * H, H, fk, 1, (fk - 1) / 2, 0, 0, s,
+                               &m->flows[f].in_layers[i]);
+        }
     }
     if (m->mrf_streams < 1) m->mrf_streams = 1;
     if (m->mrf_streams > cfg->n_resblock_kernels) m->mrf_streams = cfg->n_resblock_kernels;
@@ -1567,14 +1579,18 @@ int32_t wetts_flow_reverse(const wetts_model_t* m, const float* z_p_in, const fl
     } else
     for (int i = 0; i < NL; ++i) {
       {
-        ConvParams p = conv_io(h, H, Ty, xin, 2 * H, B);  // x_in = in_layer(h) (+ g_l)
+        // acts = tanh(a[:H]) * sigmoid(a[H:]),  a = in_layer(h) (+ g_l)  (modules.py:71-78, commons.py:98-105): the gate
+        // runs in the conv's epilogue (rows packed interleaved), x_in is never written
+        const bool gate = fw.in_layers[i].gate_H > 0;
+        ConvParams p = conv_io(h, H, Ty, gate ? acts : xin, gate ? H : 2 * H, B);
+        if (gate) p.out_act = OUT_GATE;
         if (use_g) {
           p.bias_b = gl + (int64_t)i * 2 * H;
           p.bias_b_stride = (int64_t)2 * H * NL;
         }
         WETTS_TRY(launch_conv(fw.in_layers[i], p, s));
+        if (!gate) WETTS_TRY(k_gate(xin, B, H, Ty, acts, s));
       }
-      WETTS_TRY(k_gate(xin, B, H, Ty, acts, s));
       const bool last = (i == NL - 1);
       ConvParams p2 = conv_io(acts, H, Ty, rs, last ? H : 2 * H, B);
       // residual / skip update in the conv's epilogue (rs never exists, one launch less per layer) where launches are
