@@ -142,6 +142,17 @@ void free_packed(PackedConv* pc) {
 // offset + one lane offset + immediates: no vector address arithmetic), aligned 16-byte loads with one
 // in-range predicate per piece, leaky-relu as mul + max, ds_write_b128.  The staged window starts at
 // the 16-byte boundary at or below its first column; `sh` shifts the B-operand columns to match.
+// LDS row stride of the FAST kernels with tiles of at most 256 columns: a compile-time constant (room for the widest
+// window the host admits, span <= 125, plus the 16-byte alignment slack), so that the row part of every B-fragment
+// address in the tap loop is an instruction immediate instead of vector address arithmetic -- the f32 matrix pipe
+// pays ~3 cycles for every VALU instruction a wave issues (profiles/r02_mfma_valu_coissue.txt) and the loop spent 20
+// of them per 32 MFMAs on row bases (12 now: the compiler still merges the reads into ds_read2_b32, whose 8-bit offsets
+// cannot span rows, and adds a literal per row; ds_read_b32 with 16-bit offsets through inline asm brings it to 1 and
+// measured no further gain).  Single convs at C >= 128: +2 ... 5 % (profiles/r04_conv_fixed_stride.txt).  512-column
+// tiles keep the run-time stride (a fixed one would halve their blocks per CU).
+constexpr int conv_fixed_stride(int nt) { return ((nt + 132 - 32 + 63) / 64) * 64 + 32; }
+constexpr bool conv_has_fixed_stride(int nt) { return nt <= 256; }
+
 template <int MB, int NB, int WM, int WN, int EPI, bool FAST>
 __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, int bid) {
   static_assert(WM * WN == 4, "4 waves per block");
@@ -175,7 +186,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, int bid) {
     N = p.up > 0 ? Tin + p.ktaps - 1 : Tout;
     if (n0 >= N) return;  // uniform per block
   }
-  const int W = FAST ? ((NT + p.span + 3 + 3) & ~3) : NT + p.span;  // LDS row stride
+  constexpr bool FIXW = FAST && conv_has_fixed_stride(NT);
+  const int W = FIXW ? conv_fixed_stride(NT) : FAST ? ((NT + p.span + 3 + 3) & ~3) : NT + p.span;  // LDS row stride
   float* buf0 = smem;
   float* buf1 = smem + CK * W;
 
@@ -623,7 +635,9 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
   WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
   // FAST staging (see the kernel): plain input, 16-byte aligned rows holding a multiple of 4 samples
   const bool fast = conv_fast_ok(p);
-  const size_t lds = (size_t)2 * kConvCK * (fast ? ((NT + p.span + 3 + 3) & ~3) : NT + p.span) * sizeof(float);
+  const size_t lds = (size_t)2 * kConvCK *
+                     (fast ? (conv_has_fixed_stride(NT) ? conv_fixed_stride(NT) : ((NT + p.span + 3 + 3) & ~3)) : NT + p.span) *
+                     sizeof(float);
   const dim3 grid((unsigned)blocks), blk(256);
   // epilogue specialisation: residual / running sum are folded into the accumulator init
   // whenever there is no output activation or mask, which leaves "acc + bias [/ div]"
@@ -720,7 +734,8 @@ static int32_t launch_group_cfg(ConvGroupParams& gp, int max_span, hipStream_t s
   }
   gp.first[gp.n] = (int)total;
   WETTS_REQUIRE(total > 0 && total < (1ll << 31), "conv group grid size");
-  const size_t lds = (size_t)2 * kConvCK * ((NT + max_span + 3 + 3) & ~3) * sizeof(float);
+  const size_t lds = (size_t)2 * kConvCK * (conv_has_fixed_stride(NT) ? conv_fixed_stride(NT) : ((NT + max_span + 3 + 3) & ~3)) *
+                     sizeof(float);
   hipLaunchKernelGGL((conv_mfma_group_kernel<MB, NB, WM, WN, 1>), dim3((unsigned)total), dim3(256), lds, stream, gp);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
