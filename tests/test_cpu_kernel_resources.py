@@ -1,0 +1,64 @@
+"""Register / scratch budget of the built kernels, read from the code objects inside libwetts_hip.so (no GPU needed).
+
+Why this is a test: the hot kernels are built around an occupancy (4 waves per SIMD = at most 128 VGPRs, 3 = 168) and the
+compiler silently trades it away -- in round 4 a tanhf / expf branch added to an epilogue tail that every instantiation of
+conv_mfma_body shares pushed the MRF kernels to 167 VGPRs + 540 bytes of scratch and cost 14 % of the headline, with every
+parity test still green (profiles/r04_wn_gate_ab.txt).  tools/kernel_resources.py prints the same table for a diff."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_resources  # noqa: E402
+from wetts_amd import _lib  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists(kernel_resources.READELF) or shutil.which("c++filt") is None,
+                                reason="needs llvm-readelf and c++filt")
+
+# kernels that are allowed to touch scratch, with a bound in bytes per lane: spills outside their MFMA loops (checked in
+# the ISA when they were admitted), or an indexed local array
+SCRATCH_ALLOWED = {
+    "void wetts::resblock_chain32_kernel<32>": 128,   # 18 dwords parked across the per-conv prologue, not in the loops
+    "void wetts::resblock_chain32_kernel<64>": 192,   # 31 dwords, same place
+    "void wetts::conv_dma_kernel<4, true>": 32,       # gate epilogue of the B >= 64 flow path
+    "wetts::spline_inverse_kernel": 128,              # bin tables indexed at run time
+}
+
+
+@pytest.fixture(scope="module")
+def table():
+    t = kernel_resources.library_table(_lib.LIB_PATH)
+    assert len(t) > 200, "kernel metadata not found in the library"
+    return t
+
+
+def test_no_unexpected_scratch(table):
+    bad = {k: v["ScratchSize"] for k, v in table.items() if v.get("ScratchSize", 0) > SCRATCH_ALLOWED.get(k, 0)}
+    assert not bad, f"kernels spilling to scratch: {bad}"
+
+
+def test_mrf_conv_kernels_keep_four_waves_per_simd(table):
+    """128-row x 128-column tiles (C >= 128 stages: 45 % of the headline step) at <= 128 VGPRs; the 64-row x 256-column tiles
+    (C = 64) at <= 168 (three waves: their LDS tile allows no more anyway)."""
+    names = [k for k in table if "conv_mfma_kernel<1, 4, 4, 1," in k or "conv_mfma_group_kernel<1, 4, 4, 1," in k]
+    assert len(names) >= 10
+    for k in names:
+        assert table[k]["VGPRs"] <= 128, (k, table[k])  # (vgpr_count of the metadata = VGPRs + AGPRs, the unified file)
+    names = [k for k in table if "conv_mfma_kernel<1, 4, 2, 2," in k or "conv_mfma_group_kernel<1, 4, 2, 2," in k]
+    assert len(names) >= 10
+    for k in names:
+        assert table[k]["VGPRs"] <= 168, (k, table[k])
+
+
+def test_pointwise_gemm_and_16bit_kernels_keep_their_occupancy(table):
+    for k, v in table.items():
+        if "pw_gemm_kernel<" in k:  # amdgpu_waves_per_eu(4, 4)
+            assert v["VGPRs"] <= 128, (k, v)
+        # three waves per SIMD (the 128 x 128-tile, 64-channel-chunk variant <4, 2, 2, 64> runs at two)
+        if "resblock_pair16_kernel<" in k or ("conv_bf16_kernel<" in k and "<4, 2, 2, 64," not in k):
+            assert v["VGPRs"] <= 168, (k, v)
+        if "rb2_stage16_kernel<" in k:  # two blocks of four waves per CU
+            assert v["VGPRs"] <= 256 and v["ScratchSize"] == 0, (k, v)
