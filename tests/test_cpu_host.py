@@ -361,3 +361,22 @@ def test_split_bf16_error_estimate_backs_the_design_claim(capsys):
     assert rows["split bf16, 6 products, f32 acc"] <= rows["f32 MFMA chain (today)"]
     assert rows["truncation alone (6 products)"] < 1e-7
     assert rows["split bf16, 3 products, f32 acc"] < 1e-4
+
+
+def test_export_prelude_of_the_reference_runs_on_the_drop_in_module():
+    """export_onnx.py:79-83 before it traces: `net_g.flow.remove_weight_norm()` (guarded by hasattr),
+    `net_g.dec.remove_weight_norm()`, `net_g.forward = net_g.export_forward`, `net_g.eval()`, then the module is CALLED.
+    Weight norm is folded at load time here, so the removals are no-ops; the call must go through the instance's
+    `forward` like nn.Module's does."""
+    from wetts_amd import SynthesizerTrn
+    net = SynthesizerTrn(50, 513, 32, n_speakers=2, **config.MODEL_CONFIGS["tiny"])
+    if hasattr(net.flow, "remove_weight_norm"):
+        net.flow.remove_weight_norm()
+    net.dec.remove_weight_norm()
+    with pytest.raises(NotImplementedError):
+        net(1, 2)  # the training forward is out of scope
+    seen = []
+    net.forward = lambda *a: seen.append(a) or "audio"
+    assert net.eval() is net and net(1, 2, 3) == "audio" and seen == [(1, 2, 3)]
+    net.forward = net.export_forward  # bound method of the instance, as the reference assigns it
+    assert net.forward.__self__ is net

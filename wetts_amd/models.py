@@ -41,6 +41,15 @@ class _Workspace:
         return self.buf
 
 
+class _FoldedPart:
+    """`net_g.dec` / `net_g.flow` as far as the reference's export prelude touches them (export_onnx.py:79-81): weight
+    norm is folded into the weights when a checkpoint is loaded (checkpoint.fold_weight_norm), so removing it is a
+    no-op here."""
+
+    def remove_weight_norm(self):
+        return None
+
+
 class SynthesizerTrn:
     """Inference-only synthesizer with the reference's constructor signature (models.py:19-51)."""
 
@@ -81,6 +90,8 @@ class SynthesizerTrn:
         self._ws_dec = _Workspace()  # the decoder's own scratch in overlap mode (see set_overlap)
         self._enc_stream = None
         self.overlap = False
+        self.dec = _FoldedPart()
+        self.flow = _FoldedPart()
         self.quiet = True      # the reference prints stage timers on every call (:273-279)
         self.last_status = 0
 
@@ -258,7 +269,10 @@ class SynthesizerTrn:
         raise NotImplementedError("SynthesizerTrn.forward (training, models.py:161-226) is out of "
                                   "scope; this is the inference hot path only")
 
-    __call__ = forward
+    def __call__(self, *a, **k):
+        # through the instance, like nn.Module: the reference's export scripts assign `net_g.forward =
+        # net_g.export_forward` (export_onnx.py:82,94,127) and then call the module
+        return self.forward(*a, **k)
 
     def voice_conversion(self, *a, **k):
         raise NotImplementedError("voice_conversion needs the posterior encoder (out of scope)")
