@@ -200,15 +200,19 @@ void resblock_chain32_kernel(const ResChain32Params p) {
   // ---- the conv loop: acc += W (*) tile, B fragments one k-step ahead ---------------------------
   // bcol: LDS address of (row = half, accumulator column wcol); a tap at offset o reads column + o
   const float* bcol = smem_c + (size_t)half * Wp + wcol + M;
-  float4 aa[2];
+  // A fragments: FOUR register sets.  Group g multiplies from set g % 4 while the load of group g + 2 lands in set
+  // (g + 2) % 4, whose last reader was group g - 2 -- no set is read and written in the same group, so nothing has to be
+  // copied out of the way (with two sets the compiler rotated them with 8 v_mov per tap, and every VALU instruction costs
+  // the f32 matrix pipe ~3 cycles).  The tap loop runs two taps = four groups per iteration so that the set indices are
+  // static; the number of (chunk, tap) steps is even because C / 16 is.
+  float4 aa[4];
   auto conv_loop = [&](f32x16 (&acc)[NB], const float4* abase, int dil, int h) {
     const float* b0 = bcol - h;  // tap 0
     float bv[2][NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) bv[0][j] = b0[32 * j];
-    auto group = [&](float4& areg, const float4* anext, const float* cur, const float* nxt) {
-      const float4 av = areg;
-      areg = *anext;
+    auto group = [&](const float4& av, float4& apref, const float4* anext, const float* cur, const float* nxt) {
+      apref = *anext;
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -223,18 +227,26 @@ void resblock_chain32_kernel(const ResChain32Params p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    int g = 0;
-    for (int chunk = 0; chunk < NCH; ++chunk) {
-      for (int tap = 0; tap < p.ktaps; ++tap) {
-        const float* r0 = b0 + (size_t)(chunk * kConvCK) * Wp + tap * dil;  // hp = 0 rows
-        const float* r1 = r0 + (size_t)8 * Wp;                              // hp = 1 rows
-        int ntap = tap + 1, nchunk = chunk;
-        if (ntap == p.ktaps) { ntap = 0; ++nchunk; }
-        const float* rn = (g + 2 < G) ? b0 + (size_t)(nchunk * kConvCK) * Wp + ntap * dil : r1;
-        group(aa[0], abase + (int64_t)(g + 2) * 64, r0, r1);
-        group(aa[1], abase + (int64_t)(g + 3) * 64, r1, rn);
-        g += 2;
-      }
+    auto rows = [&](int ch, int tp) { return b0 + (size_t)(ch * kConvCK) * Wp + tp * dil; };  // hp = 0 rows of a tap
+    auto advance = [&](int& ch, int& tp) {
+      if (++tp == p.ktaps) { tp = 0; ++ch; }
+    };
+    static_assert(NCH % 2 == 0, "an even number of (chunk, tap) steps");
+    const int nsteps = NCH * p.ktaps;
+    int g = 0, chunk = 0, tap = 0;
+    for (int t = 0; t < nsteps; t += 2) {
+      const float* r0 = rows(chunk, tap);
+      const float* r1 = r0 + (size_t)8 * Wp;  // hp = 1 rows
+      advance(chunk, tap);
+      const float* s0 = rows(chunk, tap);
+      const float* s1 = s0 + (size_t)8 * Wp;
+      advance(chunk, tap);
+      const float* rn = (t + 2 < nsteps) ? rows(chunk, tap) : s1;
+      group(aa[0], aa[2], abase + (int64_t)(g + 2) * 64, r0, r1);
+      group(aa[1], aa[3], abase + (int64_t)(g + 3) * 64, r1, s0);
+      group(aa[2], aa[0], abase + (int64_t)(g + 4) * 64, s0, s1);
+      group(aa[3], aa[1], abase + (int64_t)(g + 5) * 64, s1, rn);
+      g += 4;
     }
   };
 
