@@ -36,6 +36,8 @@ CASES = {
     "v3_b2": ("v3", 64, 2, 2, 8, [8, 6], 22, 202, (0.667, 1.0, 0.8)),
     # examples/*/configs/v2.json: upsample_initial_channel 128 -> ResBlock stages of 64 / 32 / 16 / 8 channels
     "v2_b2": ("v2", 64, 1, 2, 8, [8, 5], 25, 205, (0.667, 1.0, 0.8)),
+    # examples/baker/configs/vits2_v1.json: the VITS2 "pre_conv" flows in front of the HiFi-GAN v1 decoder
+    "vits2_v1_b2": ("vits2_v1", 64, 1, 2, 8, [8, 6], 26, 206, (0.667, 1.0, 0.8)),
     # VocosGenerator (decoders.py:251-308); iSTFT through the documented torch.istft stand-in
     "tiny_vocos_b2": ("tiny_vocos", 40, 2, 2, 10, [10, 6], 15, 105, (0.667, 1.0, 0.8)),
     "vocos_b2": ("vocos", 64, 2, 2, 8, [8, 5], 23, 203, (0.667, 1.0, 0.8)),
