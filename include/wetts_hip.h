@@ -114,6 +114,9 @@ typedef struct wetts_model wetts_model_t; /* opaque */
 /* ---- library / weight-blob layout (no GPU required) ------------------------------------- */
 
 int32_t wetts_abi_version(void);
+/* Message of the calling thread's last failed call.  The reference reports the same conditions as Python exceptions
+ * raised from inside its modules (e.g. the spline's discriminant assert, transforms.py:171; an embedding index outside
+ * its table, encoders.py:48 / models.py:239). */
 const char* wetts_last_error(void);
 
 /* The weight blob is one flat float32 array holding every inference tensor of the reference
@@ -139,6 +142,8 @@ int64_t wetts_blob_numel(const wetts_config_t* cfg);
  * + load_checkpoint (inference.py:72-80). */
 int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t blob_numel,
                      void* stream, wetts_model_t** out);
+/* Frees the packed weights and the model (the reference: garbage collection of the nn.Module built at
+ * inference.py:66-80).  Not stream-ordered: the caller synchronises the streams that used the model first. */
 void wetts_destroy(wetts_model_t* m);
 
 /* Registers the device int32 the stage calls below OR their WETTS_STATUS_* bits into (caller-owned;
@@ -147,10 +152,12 @@ void wetts_destroy(wetts_model_t* m);
 int32_t wetts_set_status_word(const wetts_model_t* m, int32_t* status_dev, void* stream);
 
 /* Seed of the model's own standard-normal stream (Philox4x32-10), used by wetts_infer() when
- * eps_w / eps_z are NULL -- the reference draws them with torch.randn under torch.manual_seed. */
+ * eps_w / eps_z are NULL -- the reference draws them with torch.randn / torch.randn_like from the global generator
+ * (duration_predictors.py:257-258, models.py:267), i.e. under the caller's torch.manual_seed. */
 int32_t wetts_set_seed(const wetts_model_t* m, uint64_t seed);
 
-/* total upsampling factor (prod upsample_rates) == hop length of the checkpoint. */
+/* total upsampling factor (prod upsample_rates, decoders.py:30-47; the iSTFT hop for Vocos, decoders.py:283) == the
+ * `hop_length` of the checkpoint's config (examples/baker/configs/v1.json:23). */
 int32_t wetts_hop_length(const wetts_model_t* m);
 
 /* Copies the model's folded float32 weights (the blob wetts_create() was given, in
@@ -159,7 +166,9 @@ int32_t wetts_hop_length(const wetts_model_t* m);
 int32_t wetts_get_blob(const wetts_model_t* m, float* out_dev, int64_t numel, void* stream);
 
 /* Scratch needed by any of the stage calls below for a batch of B utterances, Tx phonemes
- * (padded) and Ty frames (padded).  Pass Ty = 0 for the pre-length-regulation stages only. */
+ * (padded) and Ty frames (padded).  Pass Ty = 0 for the pre-length-regulation stages only.
+ * (The reference allocates every intermediate through PyTorch's caching allocator inside infer(), models.py:228-280;
+ * here no stage call allocates.) */
 int64_t wetts_workspace_bytes(const wetts_model_t* m, int32_t B, int32_t Tx, int32_t Ty);
 
 /* ---- stage entry points (stream-ordered) -------------------------------------------------- */
