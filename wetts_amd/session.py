@@ -303,7 +303,9 @@ def get_chunks(mel_len, block_size, pad_size):
 
 
 def depad_bounds(chunk_num, chunk_id, block, pad, upsample, n_samples):
-    """Sample range of a decoded window to keep (depadding, inference_onnx.py:60-76)."""
+    """Sample range of a decoded window to keep (depadding, inference_onnx.py:60-76).  Mirrored to the sample, including
+    what the reference does with block == -1 (one window): `audio[:, :block * upsample]` is then `audio[:, :-upsample]`,
+    i.e. its streaming client drops the last frame's samples in that mode (tests/test_cpu_properties.py)."""
     front = min(chunk_id * block, pad)
     if chunk_id == 0:
         return 0, min(n_samples, block * upsample)
