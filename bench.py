@@ -410,6 +410,11 @@ class HipBackend:
                             "read_mrf_timing")
         return ms.value, nl.value
 
+    def read_mrf_bytes(self, net):
+        by = C.c_double()
+        self._lib_mod.check(self.lib.wetts_read_mrf_bytes(net._handle, C.byref(by)), "read_mrf_bytes")
+        return by.value
+
     def hifigan_cost(self, cfg):
         fl, by, mfl, mby = C.c_double(), C.c_double(), C.c_double(), C.c_double()
         self.lib.wetts_hifigan_cost(C.byref(cfg), C.byref(fl), C.byref(by), C.byref(mfl), C.byref(mby))
@@ -498,15 +503,50 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))  # the ranks inherit this process's stdout untouched
     json_out()
-    from wetts_amd import batching, checkpoint, config, sharding, synth
+    from wetts_amd import sharding
 
     rank, local_rank, world = sharding.env_world()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    def partial_line(phase, seen, why):
+        """A multi-rank job that cannot finish (a rank that never came up, a hung collective, a rank that crashed) still
+        prints ONE line from rank 0 -- no value, `partial`, the phase, and how many ranks were seen -- and exits with
+        code 4, instead of hanging until the launcher gives up."""
+        if rank != 0:
+            return
+        print(json.dumps({
+            "metric": "audio samples/sec + RTF @22.05 kHz, VITS-Baker, 1/2/4/8 MI355X", "value": None,
+            "unit": "samples/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "partial": True, "ranks_seen": seen if seen is not None else 1, "failed_phase": phase, "error": why,
+            "config": {"workload": f"{args.config}: did not complete"}}), file=json_out(), flush=True)
+
+    mon = sharding.PhaseMonitor(rank, world, on_expire=partial_line)
+    try:
+        _bench(args, rank, local_rank, world, mon)
+    except SystemExit:
+        raise
+    except BaseException as e:  # an exception out of a collective (timeout, a peer that went away): same exit path
+        if world > 1:
+            mon.expire_now(f"{type(e).__name__}: {str(e)[:400]}")
+        raise
+    finally:
+        mon.done()
+
+
+def _bench(args, rank, local_rank, world, mon):
+    from wetts_amd import batching, checkpoint, config, sharding, synth
+    # phase deadlines (s): the collective phases stay below the process-group timeout (sharding.DEFAULT_TIMEOUT_S) so
+    # that the monitor -- which can still print the partial line -- fires before c10d's watchdog aborts the process
+    mon.enter("device", 100)
     be = load_backend(rank, local_rank)
     dev = be.device
     single_dev = getattr(be, "single_dev", False)
+    mon.enter("rendezvous", 100)
     sharding.init_process_group()
+    mon.attach_store()
+    mon.enter("weights", 100)
 
     pre = PRESETS[args.config]
     mname = args.model or pre["model"]
@@ -556,6 +596,7 @@ def main():
         ranks_seen = int(one.item())
         if not blob_ok:  # never time a rank that decodes with other weights
             raise SystemExit(f"rank {rank}: weight blob differs across ranks after the broadcast")
+    mon.enter("setup", 300)
     net.load_blob(blob)
     if args.overlap and hasattr(net, "set_overlap"):
         net.set_overlap(True)
@@ -603,6 +644,7 @@ def main():
     for _ in range(args.warmup):
         step()
     be.sync()
+    mon.enter("timed", 100 + 2.0 * args.steps)
     if world > 1:
         dist.barrier()
     be.set_mrf_timing(net, True)
@@ -620,6 +662,7 @@ def main():
     elapsed = time.perf_counter() - t0
     for ym in masks:
         frames += float(ym.sum().item())
+    mrf_launched_bytes = be.read_mrf_bytes(net)  # (before the set(.., False) below resets the counters)
     mrf_ms, mrf_launches = be.read_mrf_timing(net)
     be.set_mrf_timing(net, False)
     padded_frames = float(sum(ym.numel() for ym in masks))  # B*Ty: what a padded decode computes
@@ -636,10 +679,11 @@ def main():
             _, yms = step()
             iso_frames += float(sum((ym.sum().item() if decode == "ragged" else ym.numel()) for ym in yms))
         be.sync()
+        iso_bytes = be.read_mrf_bytes(net)
         iso_ms, iso_launches = be.read_mrf_timing(net)
         be.set_mrf_timing(net, False)
         net.set_overlap(True)
-        iso = (iso_ms, iso_launches, iso_frames)
+        iso = (iso_ms, iso_launches, iso_frames, iso_bytes)
 
     # PCIe-inclusive variant (SURVEY 8d's wall: H2D of the ids, D2H of the audio; the driver contract
     # says inputs are resident when the timed region starts, so this is reported beside `value`,
@@ -652,6 +696,7 @@ def main():
     pcie_pipe_rate = be.pcie_pass(net, pinned, n_pipe, True, infer_kw)
 
     # ---- reduce over ranks: time = max, work = sum; every rank's own loop time is gathered for `rank_ms`
+    mon.enter("reduce", 100)
     stat = torch.tensor([elapsed, frames, decoded_frames, mrf_ms, float(mrf_launches), pcie_rate, pcie_pipe_rate],
                         dtype=torch.float64, device=dev)
     rank_ms = [my_elapsed / args.steps * 1e3]
@@ -665,9 +710,10 @@ def main():
         allt = [torch.zeros_like(mine_t) for _ in range(world)]
         dist.all_gather(allt, mine_t)
         rank_ms = [float(t.item()) for t in allt]
+    if world > 1:
+        dist.barrier()  # the last collective: rank 0 formats the line (and, if asked, times the CPU baseline) alone
+    mon.done()
     if rank != 0:
-        if world > 1:
-            dist.barrier()
         return
 
     samples = frames * hop
@@ -681,18 +727,37 @@ def main():
     nl_ = max(1, mrf_launches)
     default_shape = not (args.model or args.batch or args.phonemes or args.buckets or args.speakers)
 
+    def lib_digest():
+        try:
+            return open(os.path.join(ROOT, "wetts_amd", "lib", "build.sha256")).read().strip()[:16]
+        except OSError:
+            return None
+
     def pmc_traffic(key):
-        """Committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command (profiles/)."""
+        """Committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command (profiles/): (bytes per launch,
+        file, digest of the library sources the counter pass ran on).  The driver cannot refresh it, so the line says
+        whether it is current (`traffic_current`: that digest == the digest of the library that just ran)."""
         try:
             import glob
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
             for f in reversed(files):
                 d = json.load(open(f))
                 if key in d and (default_shape or key == "pw_" + str(args.model)):
-                    return d[key]["hbm_bytes_per_launch"], os.path.basename(f)
+                    return d[key]["hbm_bytes_per_launch"], os.path.basename(f), d[key].get("lib_digest", d.get("lib_digest"))
         except Exception:
             pass
-        return None, None
+        return None, None, None
+
+    def stamp_traffic(roof, src, dig):
+        roof["traffic_source"] = src
+        roof["traffic_head"] = dig  # sources digest (wetts_amd/lib/build.sha256) of the library the PMC pass ran on
+        roof["traffic_current"] = bool(dig) and dig == lib_digest()
+
+    # algorithmic bytes of the class at the granularity it was launched with (wetts_read_mrf_bytes), over the timed
+    # steps; a ragged decode computes lens[b] of the dense rows the library counted
+    dense_frac = decoded_frames / padded_frames if padded_frames > 0 else 1.0
+    launched_bytes = mrf_launched_bytes * dense_frac
+    launched_gbs = launched_bytes / (mrf_ms * 1e-3) / 1e9 if mrf_ms > 0 else 0.0
 
     if ddtype == "uint8":
         # the dynamically quantised graph keeps f32 tensors between its nodes (DynamicQuantizeLinear in, Cast * scale
@@ -700,44 +765,54 @@ def main():
         roofline = {
             "kernel": "the quantised Conv nodes of the MRF ResBlocks: qminmax + qquantize + qconv_i8_kernel "
                       "(v_mfma_i32_32x32x32_i8) per node; ConvTranspose1d stays f32 (conv_mfma_kernel)",
-            "bound": "hbm", "achieved": mrf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": mrf_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("mrf_uint8")[0],
+            "bound": "hbm", "achieved": launched_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": launched_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("mrf_uint8")[0],
             "traffic_unit": "HBM bytes per Conv node (its quantise + integer-conv kernels), PMC",
             "launches": int(mrf_launches), "avg_launch_ms": mrf_ms / nl_,
             "launches_note": "one 'launch' = one Conv node = three kernels (range, quantise, integer conv)",
-            "bytes_per_launch": mby * decoded_frames / nl_,
+            "bytes_per_launch": launched_bytes / nl_,
+            "bytes_note": "f32 planes each Conv node reads / writes once (nothing is fused across nodes: = SURVEY 8d's "
+                          "per-conv figure)",
             "mrf_share_of_step": mrf_ms / (elapsed * 1e3),
         }
+        stamp_traffic(roofline, *pmc_traffic("mrf_uint8")[1:])
     elif ddtype != "f32":
-        # 16-bit activations: per-conv algorithmic bytes (SURVEY 8d accounting: every conv reads its
-        # input and writes its output once, each residual add reads x once more) are half the f32
-        # figure.  The fused ResBlock kernels move fewer bytes than that through HBM (intermediates stay
-        # on the CU), which is how `achieved` can approach the roofline; k=3 blocks are HBM/latency-bound,
-        # k=11 blocks MFMA-bound -- both views are reported.
+        # 16-bit activations.  `achieved` = the algorithmic bytes of the launches AS LAUNCHED (a fused ResBlock1 pair:
+        # x in, x' out; a whole ResBlock2 stage: x in, mean out -- SURVEY 8d's "resblock-fused" accounting, counted by
+        # the library per launch) / live device time: a fraction of something the kernels do, <= 1 by construction.
+        # SURVEY 8d's per-conv figure (every conv reads its input and writes its output, every residual add reads x once
+        # more) counts planes the fused kernels never move; it is kept as the labelled side view `perconv_view`, an
+        # accounting rate that can exceed the peak.  k = 3 blocks are HBM / latency-bound, k = 11 blocks MFMA-bound --
+        # both views are reported.
         gbs = 0.5 * mrf_gbs
-        traffic, traffic_src = pmc_traffic(f"mrf16_{args.config}")
+        traffic, traffic_src, traffic_dig = pmc_traffic(f"mrf16_{args.config}")
         roofline = {
             "kernel": "the 16-bit MRF ResBlock class: rb2_stage16_kernel / resblock_pair16_kernel / conv_bf16_kernel "
                       f"({ddtype} channel-last)",
-            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "bound": "hbm", "achieved": launched_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": launched_gbs / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_unit": "HBM bytes per MRF launch (2*FETCH_SIZE+WRITE_SIZE)*1024, PMC",
-            "traffic_source": traffic_src,
             "launches": int(mrf_launches), "avg_launch_ms": mrf_ms / nl_,
-            "bytes_per_launch": 0.5 * mby * decoded_frames / nl_,
+            "bytes_per_launch": launched_bytes / nl_,
+            "bytes_note": "algorithmic bytes at launch granularity (wetts_read_mrf_bytes): per launch, every 16-bit "
+                          "[B][C][T] plane it must read or write once",
+            "perconv_view": {"accounting_rate": gbs, "unit": "GB/s", "ratio_to_hbm_peak": gbs / HBM_PEAK_GBS,
+                             "bytes_per_launch": 0.5 * mby * decoded_frames / nl_,
+                             "note": "SURVEY 8(d) per-conv bytes / the same time: NOT a bandwidth (the fused kernels do "
+                                     "not move these bytes); shown for continuity with rounds 1-4"},
             "mfma_view": {"achieved": mrf_tflops, "peak": 2500.0, "unit": "TFLOP/s",
                           "frac": mrf_tflops / 2500.0},
             "mrf_share_of_step": mrf_ms / (elapsed * 1e3),
         }
-        # `achieved` counts SURVEY 8(d)'s per-conv algorithmic bytes; the fused kernels move fewer through HBM, so the
-        # figure is an accounting rate and can exceed what a copy reaches.  The bandwidth the class really drew:
+        stamp_traffic(roofline, traffic_src, traffic_dig)
+        # the bandwidth the class really drew (PMC bytes per launch of the committed counter pass / live duration):
         if traffic and mrf_ms > 0:
             real = traffic / (mrf_ms / nl_ * 1e-3) / 1e9
             roofline["hbm_real"] = {"achieved": real, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": real / HBM_PEAK_GBS,
                                     "note": "PMC bytes per launch / live launch duration"}
     else:
-        traffic, traffic_src = pmc_traffic("pw_" + mname if "vocos" in mname else
-                                           "dominant_conv_mfma" if args.config == "baker" else "none")
+        traffic, traffic_src, traffic_dig = pmc_traffic("pw_" + mname if "vocos" in mname else
+                                                        "dominant_conv_mfma" if args.config == "baker" else "none")
         roofline = {
             "kernel": ("pw_gemm_kernel (Vocos ConvNeXt pointwise GEMMs 512<->1536, LDS-DMA GEMM of gemm_pw.hip)"
                        if "vocos" in mname else
@@ -746,18 +821,19 @@ def main():
             "bound": "mfma", "achieved": mrf_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": mrf_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
             "traffic_unit": "HBM bytes per MRF launch (2*FETCH_SIZE+WRITE_SIZE)*1024, PMC",
-            "traffic_source": traffic_src,
             "launches": int(mrf_launches), "avg_launch_ms": mrf_ms / nl_,
             "flops_per_launch": mrf_flops / nl_,
-            "hbm_view": {"achieved": mrf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": mrf_gbs / HBM_PEAK_GBS,
-                         "note": "per-conv algorithmic bytes (SURVEY 8d); fp32 convs are compute-bound (AI "
-                                 f"{(mfl / mby) if mby > 0 else 0.0:.0f} flop/B from wetts_hifigan_cost > ridge ~20)"},
+            "hbm_view": {"achieved": launched_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": launched_gbs / HBM_PEAK_GBS, "bytes_per_launch": launched_bytes / nl_,
+                         "note": "algorithmic bytes at launch granularity (wetts_read_mrf_bytes); fp32 convs are "
+                                 f"compute-bound (per-conv AI {(mfl / mby) if mby > 0 else 0.0:.0f} flop/B from "
+                                 "wetts_hifigan_cost > ridge ~20)"},
             "mrf_share_of_step": mrf_ms / (elapsed * 1e3),
         }
+        stamp_traffic(roofline, traffic_src, traffic_dig)
     if iso and iso[0] > 0 and roofline.get("unit") in ("TFLOP/s", "GB/s"):
-        iso_ms, iso_launches, iso_frames = iso
-        per = (mfl if roofline["unit"] == "TFLOP/s" else (0.5 if ddtype in ("bf16", "f16") else 1.0) * mby) * iso_frames
+        iso_ms, iso_launches, iso_frames, iso_bytes = iso
+        per = mfl * iso_frames if roofline["unit"] == "TFLOP/s" else iso_bytes * dense_frac
         ach = per / (iso_ms * 1e-3) / (1e12 if roofline["unit"] == "TFLOP/s" else 1e9)
         roofline["isolated"] = {
             "achieved": ach, "frac": ach / roofline["peak"], "avg_launch_ms": iso_ms / max(1, iso_launches),
@@ -827,8 +903,6 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg, sd, x, lens, sid, min(args.cpu_sample, total), sr, hop,
                                            args.length_scale, n_fixture=min(args.cpu_fixture, total))
     print(json.dumps(out), file=json_out(), flush=True)
-    if world > 1:
-        dist.barrier()
 
 
 if __name__ == "__main__":

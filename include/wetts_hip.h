@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define WETTS_ABI_VERSION 7
+#define WETTS_ABI_VERSION 8
 
 #define WETTS_OK 0
 #define WETTS_E_INVALID (-1)   /* bad argument / unsupported configuration */
@@ -349,6 +349,11 @@ int32_t wetts_hifigan_cost(const wetts_config_t* cfg, double* flops_per_frame,
 int32_t wetts_set_mrf_timing(const wetts_model_t* m, int32_t enable);
 int32_t wetts_read_mrf_timing(const wetts_model_t* m, double* mrf_ms, int64_t* conv_launches,
                               int32_t* hifigan_calls);
+/* Algorithmic HBM bytes of the same launches AT THE GRANULARITY THEY WERE LAUNCHED WITH, summed since enabling: per
+ * launch every [B][C][T] plane it has to read or write once (a fused ResBlock / stage: x in, running sum in and out; a
+ * single conv: input, residual, output).  SURVEY.md 8(d)'s per-conv figure (wetts_hifigan_cost) counts planes a fused
+ * launch never moves through HBM, so a bandwidth fraction priced with it can exceed 1; this one cannot. */
+int32_t wetts_read_mrf_bytes(const wetts_model_t* m, double* launched_bytes);
 
 /* Times `iters` launches of the dominant MRF conv kernel class (all ResBlock convs of the
  * decoder) with HIP events on `stream`; returns total ms and the number of conv launches.

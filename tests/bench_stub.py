@@ -19,16 +19,32 @@ class StubNet:
         self.calls = 0
         self.mrf_ms = 0.0
         self.mrf_launches = 0
+        self.mrf_bytes = 0.0
         self.timing = False
         self._last = None
 
+    def _cost(self):
+        import ctypes as C
+        from wetts_amd import _lib
+        fl, by, mfl, mby = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        assert _lib.load().wetts_hifigan_cost(C.byref(self.cfg), C.byref(fl), C.byref(by), C.byref(mfl), C.byref(mby)) == 0
+        return mfl.value, mby.value
+
     def load_blob(self, blob):
         from wetts_amd import checkpoint
+        if os.environ.get("WETTS_STUB_HANG_RANK") == os.environ.get("RANK") and os.environ.get("WETTS_STUB_HANG_AT") == "load":
+            time.sleep(3600)  # a rank whose GPU hangs after the rendezvous
+        if os.environ.get("WETTS_STUB_CRASH_RANK") == os.environ.get("RANK"):
+            raise RuntimeError("stub: this rank dies while loading its weights")
         assert blob.dtype == torch.float32 and blob.numel() == checkpoint.blob_numel(self.cfg)
         self.blob_sum = float(blob.double().sum())
         return self
 
     def set_decoder_dtype(self, d):
+        self.ddtype = d
+        return self
+
+    def set_overlap(self, on):  # (bench.py's `roofline.isolated` pass switches it off and on again)
         return self
 
     def set_flow_dtype(self, d):
@@ -44,7 +60,18 @@ class StubNet:
         time.sleep(2e-6 * x.shape[0] * Ty)
         self.calls += 1
         if self.timing:
-            self.mrf_ms += 1e-3 * x.shape[0] * Ty
+            # a FUSED class, as the 16-bit kernels are: the launches move a quarter of SURVEY 8(d)'s per-conv bytes and
+            # finish in the time a copy of 1.2x the per-conv bytes would take at the HBM peak -- so a roofline priced
+            # with the per-conv figure reads 1.2 (the round-4 defect), one priced with the launched bytes 0.3
+            # (the f32 class is compute-bound: half the f32 MFMA peak)
+            frames = float(x.shape[0] * Ty)
+            mfl, mby = self._cost()
+            perconv = 0.5 * mby * frames
+            if getattr(self, "ddtype", "f32") == "f32":
+                self.mrf_ms += mfl * frames / (0.5 * 157.3e12) * 1e3
+            else:
+                self.mrf_ms += perconv / (1.2 * 8.0e12) * 1e3
+            self.mrf_bytes += 0.25 * perconv
             self.mrf_launches += 3
         self._last = {"y_lengths_host": yl}
         return o, None, y_mask, None
@@ -56,6 +83,8 @@ class StubBackend:
     def __init__(self, rank, local_rank):
         self.device = torch.device("cpu")
         self.rank = rank
+        if os.environ.get("WETTS_STUB_HANG_RANK") == str(rank) and os.environ.get("WETTS_STUB_HANG_AT") == "device":
+            time.sleep(3600)  # a rank that never gets its device: it never reaches the rendezvous
         if os.environ.get("WETTS_STUB_CORRUPT_RANK") == str(rank):
             from wetts_amd import sharding
             real = sharding.broadcast_blob
@@ -77,8 +106,11 @@ class StubBackend:
 
     def read_mrf_timing(self, net):
         ms, nl = net.mrf_ms, net.mrf_launches
-        net.mrf_ms, net.mrf_launches = 0.0, 0
+        net.mrf_ms, net.mrf_launches, net.mrf_bytes = 0.0, 0, 0.0
         return ms, nl
+
+    def read_mrf_bytes(self, net):
+        return net.mrf_bytes
 
     def hifigan_cost(self, cfg):
         import ctypes as C

@@ -69,6 +69,12 @@ BIG_CASES = {
     "aishell3_b4x128": ("v1", 256, 218, 4, 128, [128, 57, 100, 33], 35, 305, (0.667, 1.0, 0.8), [0, 57, 217, 3]),
     # mono-layer flows at 64 phonemes (~380 frames): the flash attention kernel inside the flow's Encoder
     "tiny_mono_post_b2x64": ("tiny_mono_post", 64, 2, 2, 64, [64, 41], 36, 326, (0.667, 1.0, 0.8)),
+    # examples/*/configs/v2.json at BASELINE phoneme counts: the 64 / 32 / 16 / 8-channel ResBlock1 stages on the
+    # 128-row tile selection, the chain kernels and the grouped launches (v2_b2's 8 phonemes never reach those)
+    "v2_b4x128": ("v2", 256, 1, 4, 128, [128, 97, 113, 128], 37, 307, (0.667, 1.0, 0.8)),
+    # BASELINE.json configs[4] (SURVEY 8d "cfg 5": hop 512 = [8,8,4,2] / [16,16,8,4], 48 kHz): the f32 generator of
+    # the stress config against the live reference (the 16-bit modes are held against this f32 path)
+    "stress48k_b2": ("stress48k", 256, 1, 2, 48, [48, 31], 38, 308, (0.667, 1.0, 0.8)),
 }
 ONLY = os.environ.get("WETTS_GOLDEN_ONLY")  # comma-separated case names (default: all)
 

@@ -63,6 +63,45 @@ def test_bench_two_ranks_control_flow_and_reductions():
     assert d["roofline"]["launches"] > 0 and d["roofline"]["frac"] > 0
 
 
+def _fracs(node, path=""):
+    """Every value stored under a key named `frac`, anywhere in the line."""
+    if isinstance(node, dict):
+        for k, v in node.items():
+            if k == "frac":
+                yield path + "/frac", v
+            else:
+                yield from _fracs(v, path + "/" + k)
+
+
+def test_roofline_fractions_are_fractions_of_what_the_launches_move():
+    """Round 4 printed roofline.frac 0.98 / isolated.frac 1.08 for the fused 16-bit class: SURVEY 8(d)'s per-conv bytes
+    divided by the time of kernels that fuse a whole ResBlock stage.  The stub models exactly that class (per-conv
+    accounting 1.2x the HBM peak, launched bytes a quarter of it): every `frac` of the line must be a fraction of the
+    bytes the launches move (<= 1), the per-conv rate must survive only as the labelled side view."""
+    for extra in (["--config", "multilingual", "--model", "v3"], ["--decoder-dtype", "bf16"], ["--decoder-dtype", "uint8"], []):
+        env = dict(os.environ)
+        env.pop("WORLD_SIZE", None)
+        env.pop("RANK", None)
+        env.update(WETTS_BENCH_TEST_BACKEND="tests.bench_stub:StubBackend", PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--phonemes", "16",
+               "--presteps-s", "0.02", "--no-cpu-baseline"] + extra
+        p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+        r = d["roofline"]
+        fr = dict(_fracs(r))
+        assert "/frac" in fr and fr["/frac"] > 0
+        if r["bound"] == "mfma":
+            assert abs(fr["/frac"] - 0.5) < 1e-6
+        if r["bound"] == "hbm" and "uint8" not in extra:
+            assert abs(fr["/frac"] - 0.3) < 1e-6 and abs(r["isolated"]["frac"] - 0.3) < 1e-6, (extra, fr)
+            assert "traffic_head" in r and "traffic_current" in r
+        if "perconv_view" in r:  # the accounting rate is there, labelled, and is not called a fraction
+            assert abs(r["perconv_view"]["ratio_to_hbm_peak"] - 1.2) < 1e-6 and "frac" not in r["perconv_view"]
+        bad = {k: v for k, v in fr.items() if v is not None and not (0 <= v <= 1.0)}
+        assert not bad, (extra, bad)
+
+
 def test_bench_eight_ranks_aishell3_preset_plan_and_imbalance():
     """BASELINE.json configs[3] as the driver will launch it on an 8-GPU node -- `bench.py --gpus 8 --config aishell3`:
     512 ragged utterances (64 per rank), LPT deal, per-rank ragged plans -- through the same spawn / gloo / broadcast /
@@ -86,6 +125,49 @@ def test_bench_eight_ranks_aishell3_preset_plan_and_imbalance():
     assert abs(d["plan_slot_imbalance"] - pl.stats["imbalance"]) < 1e-9 and pl.stats["imbalance"] < 0.05
     assert d["config"]["sub_batch_plan"]["sizes_rank0"] == [len(b) for b in pl.buckets[0]]
     assert "not a BASELINE.json config" in d["config"]["workload"]  # --model tiny is an override and is named as one
+
+
+def _partial(p):
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (p.stdout, p.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["partial"] is True and d["value"] is None
+    return d
+
+
+def test_bench_eight_ranks_one_hangs_after_the_rendezvous_partial_line_not_a_hang():
+    """A rank whose device hangs after start-up: the other seven reach the barrier in front of the timed region and
+    would wait for c10d's watchdog.  The phase monitor's deadline fires first: rank 0 prints ONE partial line
+    (`ranks_seen` 7 of 8 from the roll call on the rendezvous store, the phase, no value), every waiting rank exits
+    with code 4, and the launcher comes back in seconds."""
+    import time
+    t0 = time.time()
+    p = _run({"WETTS_STUB_HANG_RANK": "5", "WETTS_STUB_HANG_AT": "load", "WETTS_BENCH_PHASE_DEADLINE_S": "6",
+              "WETTS_DIST_TIMEOUT_S": "60"}, gpus=8, batch=2)
+    assert p.returncode != 0
+    d = _partial(p)
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 7 and d["failed_phase"] == "timed"
+    assert "deadline" in d["error"] or "SIGTERM" in d["error"]
+    assert time.time() - t0 < 120
+    assert "ranks that reached it: 7 of 8" in p.stderr and "[wetts rank 0/8] gloo on" in p.stderr
+
+
+def test_bench_two_ranks_one_never_reaches_the_rendezvous():
+    p = _run({"WETTS_STUB_HANG_RANK": "1", "WETTS_STUB_HANG_AT": "device", "WETTS_BENCH_PHASE_DEADLINE_S": "5",
+              "WETTS_DIST_TIMEOUT_S": "60"})
+    assert p.returncode != 0
+    d = _partial(p)
+    assert d["ranks_seen"] == 1 and d["failed_phase"] == "rendezvous"
+
+
+def test_bench_two_ranks_one_crashes_partial_line_on_the_launchers_sigterm():
+    """A rank that dies: torchrun sends SIGTERM to the survivors, rank 0 -- blocked inside a collective -- still
+    prints the partial line (the monitor thread reads the signal from the wake-up fd)."""
+    p = _run({"WETTS_STUB_CRASH_RANK": "1", "WETTS_DIST_TIMEOUT_S": "60"})
+    assert p.returncode != 0
+    d = _partial(p)
+    assert d["ranks_seen"] <= 2 and ("SIGTERM" in d["error"] or "Error" in d["error"] or "deadline" in d["error"])
+    assert "this rank dies while loading its weights" in p.stderr
 
 
 def test_bench_refuses_a_corrupted_broadcast():

@@ -34,10 +34,7 @@ def _report(name, rows):
         json.dump(rows, f, indent=1)
 
 
-# WETTS_EXTRA_CASES=1 adds the goldens that have only met the oracle so far (util.ORACLE_ONLY_CASES): the first GPU call
-# that has minutes for them runs `WETTS_EXTRA_CASES=1 pytest tests/test_gpu_parity.py -k "v2_b2 or vits2_v1_b2"` and
-# then moves them into INFER_CASES
-_GOLDEN_CASES = util.INFER_CASES + (util.ORACLE_ONLY_CASES if os.environ.get("WETTS_EXTRA_CASES") else [])
+_GOLDEN_CASES = util.INFER_CASES  # every committed reference golden
 
 
 @pytest.mark.parametrize("name", _GOLDEN_CASES)

@@ -24,3 +24,7 @@ def test_rccl_world_size_one_broadcast_and_fingerprint():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["ok"] and d["backend"] == "nccl" and d["gathered"][0]["samples"] > 0
+    # the process group is bound to its device at init (sharding.init_process_group passes device_id): c10d must not
+    # have had to guess it -- with 8 ranks that guess is "can cause a hang if rank to GPU mapping is heterogeneous"
+    assert "Guessing device ID" not in r.stderr and "using the device under current context" not in r.stderr, r.stderr[-3000:]
+    assert "[wetts rank 0/1] nccl on cuda:0" in r.stderr

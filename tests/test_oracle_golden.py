@@ -9,7 +9,7 @@ from oracle import vits_oracle as vo
 from tests import util
 
 
-@pytest.mark.parametrize("name", util.INFER_CASES + util.ORACLE_ONLY_CASES)
+@pytest.mark.parametrize("name", util.INFER_CASES)
 def test_infer_matches_reference(name):
     case = util.load_case(name)
     cfg, _, W, _ = util.case_model(case)

@@ -18,13 +18,15 @@ INFER_CASES = ["tiny_sdp_b3", "tiny_dp_b2", "tiny_sdp_nonoise", "tiny_sdp_single
                # 128x128 and 64x256 conv tiles and fused ResBlock launches with >= 128 time tiles
                "v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64",
                "aishell3_b4x128",  # configs[3]: 218-row speaker table, ragged, sids at both ends
-               "tiny_mono_post_b2x64"]  # mono-layer flows with the flash attention kernel (~400 frames)
-# Golden cases held against the ORACLE only so far (tests/test_oracle_golden.py); they join INFER_CASES -- the GPU
-# parity list -- with the first GPU call that can run them.  v2_b2: examples/*/configs/v2.json (ResBlock stages of
-# 64 / 32 / 16 / 8 channels) and vits2_v1_b2 (vits2_v1.json: pre_conv flows + HiFi-GAN; the GPU suite holds that config
-# against the oracle at full size), added at the end of round 4 after the GPU budget of the round was spent.
-ORACLE_ONLY_CASES = ["v2_b2", "vits2_v1_b2"]
-BIG_CASES = ["v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64", "aishell3_b4x128", "tiny_mono_post_b2x64"]
+               "tiny_mono_post_b2x64",  # mono-layer flows with the flash attention kernel (~400 frames)
+               # examples/*/configs/v2.json (ResBlock1 stages of 64 / 32 / 16 / 8 channels) at 8 and at 128 phonemes
+               "v2_b2", "v2_b4x128",
+               "vits2_v1_b2",  # examples/baker/configs/vits2_v1.json: pre_conv flows + HiFi-GAN v1
+               "stress48k_b2"]  # BASELINE configs[4] generator (hop 512, [8,8,4,2]) at f32 vs the live reference
+# every committed golden is a GPU parity case (round 5): nothing is held against the oracle only
+ORACLE_ONLY_CASES = []
+BIG_CASES = ["v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64", "aishell3_b4x128", "tiny_mono_post_b2x64", "v2_b4x128",
+             "stress48k_b2"]
 
 
 def big_case_noise(seed, shape, which):

@@ -22,7 +22,7 @@ class WettsError(RuntimeError):
     pass
 
 
-ABI_VERSION = 7  # WETTS_ABI_VERSION of include/wetts_hip.h this binding was written against
+ABI_VERSION = 8  # WETTS_ABI_VERSION of include/wetts_hip.h this binding was written against
 
 
 class Config(C.Structure):
@@ -112,6 +112,7 @@ SIGNATURES = {
                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "wetts_set_mrf_timing": (_I32, [_P, _I32]),
     "wetts_read_mrf_timing": (_I32, [_P, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I32)]),
+    "wetts_read_mrf_bytes": (_I32, [_P, C.POINTER(C.c_double)]),
     "wetts_profile_hifigan": (_I32, [_P, _P, _I64, _I64, _P, _I32, _I32, _P, _P, _I64, _P,
                                      C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(_I32)]),

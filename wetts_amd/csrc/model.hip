@@ -411,6 +411,11 @@ struct wetts_model {
   mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> mrf_events;
   mutable int64_t mrf_launches = 0;
   mutable int32_t mrf_calls = 0;
+  // algorithmic HBM bytes of the class AT THE GRANULARITY IT WAS LAUNCHED WITH (wetts_read_mrf_bytes): per launch, every
+  // [B][C][T] plane it has to read or write once (a fused ResBlock: x in, sum in / out; a single conv: input, residual,
+  // output) -- what bench.py prices the HBM roofline of the fused 16-bit classes with, instead of SURVEY 8(d)'s
+  // per-conv figure, which counts planes a fused launch never moves
+  mutable double mrf_bytes = 0;
   // MRF chains: the n_k ResBlocks of a stage are independent until their sum, so they run on
   // separate HIP streams (forked from / joined to the caller's stream with events); one chain's
   // launch tail and prologue/epilogue phases overlap another chain's MFMA work.
@@ -1637,6 +1642,13 @@ struct DecTiming {
   bool on = false;
 };
 
+// one MRF launch group for the live counters: `n` kernels, `planes` [B][ch][len] tensors of `esz`-byte elements moved once
+static inline void mrf_count(const wetts_model* m, int n, double planes, int ch, int64_t len, int B, int esz) {
+  if (!m->mrf_timing) return;
+  m->mrf_launches += n;
+  m->mrf_bytes += planes * (double)ch * (double)len * (double)B * (double)esz;
+}
+
 // VocosGenerator.forward (decoders.py:286-305) on (z * y_mask)[:, :, :L]:
 //   pad -> in_conv (+ cond(g)) -> LN -> 8 x ConvNeXt -> LN -> out_conv -> exp/clamp, cos/sin
 //   -> iSTFT (n_fft, hop, hann, center) = windowed inverse-rDFT GEMM + overlap-add / envelope
@@ -1707,7 +1719,8 @@ static int32_t run_vocos(const wetts_model* m, const float* z, int64_t z_bs, int
   if (m->mrf_timing) {
     WETTS_HIP_CHECK(hipEventRecord(lv1, s));
     m->mrf_events.emplace_back(lv0, lv1);
-    m->mrf_launches += 2 * (int64_t)m->v_layers.size();  // the two pointwise GEMMs per layer
+    // the two pointwise GEMMs per layer: pw1 reads t2 [VC], writes u [VH]; pw2 reads u [VH] + the residual h [VC], writes [VC]
+    mrf_count(m, 2 * (int)m->v_layers.size(), (double)m->v_layers.size() * (3.0 * VC + 2.0 * VH), 1, Fs, B, 4);
     m->mrf_calls += 1;
   }
   WETTS_TRY(k_layernorm(h, nullptr, m->v_npost_g, m->v_npost_b, nullptr, nullptr, 0, B, VC, Fs, t2, s));
@@ -1745,9 +1758,9 @@ static int32_t run_stage_rb1_grouped(const wetts_model* m, int i, const float* x
   const wetts_config_t* c = &m->cfg;
   const int nk = c->n_resblock_kernels, nd = c->n_resblock_dilations;
   const bool chain_addr_ok = (int64_t)ch * len * 4 < (int64_t)INT32_MAX;
-  auto count = [&](int n) {
+  auto count = [&](int n, double planes) {
     if (tm && tm->on) tm->launches += n;
-    if (m->mrf_timing) m->mrf_launches += n;
+    mrf_count(m, n, planes, ch, len, B, 4);
   };
   // which chains run as ONE launch (the whole ResBlock1 on the chain kernel)
   bool whole[WETTS_MAX_RB_KERNELS];
@@ -1802,11 +1815,11 @@ static int32_t run_stage_rb1_grouped(const wetts_model* m, int i, const float* x
     if (n1 > 0) {
       if (m->dec_unfused) {  // the diagnostic form: every conv its own launch
         for (int q = 0; q < n1; ++q) WETTS_TRY(launch_conv(*g1[q], p1s[q], s));
-        count(n1);
+        count(n1, 2.0 * n1);
       } else {
         int nl = 0;
         WETTS_TRY(launch_conv_group(g1, p1s, n1, s, &nl));
-        count(nl);
+        count(nl, (d == 0 ? 1 : n1) + n1);  // step 0: every chain's c1 reads the one upsampled x
       }
     }
     // the second half of the step.  Not the last dilation: the chains are still independent -- fused pairs go out as
@@ -1833,7 +1846,7 @@ static int32_t run_stage_rb1_grouped(const wetts_model* m, int i, const float* x
         cp.lens = lens;
         cp.len_mul = spf;
         WETTS_TRY(launch_resblock_chain32(rb.c1.data(), rb.c2.data(), nd, cp, s));
-        count(1);
+        count(1, 2 + (j > 0 ? 1 : 0));
         continue;
       }
       if (kind[j] == K_CHAIN1) {
@@ -1849,7 +1862,7 @@ static int32_t run_stage_rb1_grouped(const wetts_model* m, int i, const float* x
         cp.lens = lens;
         cp.len_mul = spf;
         WETTS_TRY(launch_resblock_chain32(&rb.c1[d], &rb.c2[d], 1, cp, s));
-        count(1);
+        count(1, 2 + accum);
       } else if (kind[j] == K_FUSE32) {
         ResPair32Params pp;
         memset(&pp, 0, sizeof(pp));
@@ -1861,7 +1874,7 @@ static int32_t run_stage_rb1_grouped(const wetts_model* m, int i, const float* x
         pp.out_div = odiv;
         pp.slope = 0.1f;
         WETTS_TRY(launch_resblock_pair32(rb.c1[d], rb.c2[d], pp, s));
-        count(1);
+        count(1, 2 + accum);
       } else {  // x = c2(lrelu(xt)) + x
         ConvParams p2 = conv_io(chain_buf[j][2], ch, len, outp[j], ch, B);
         p2.in_act = IN_LRELU;
@@ -1876,7 +1889,7 @@ static int32_t run_stage_rb1_grouped(const wetts_model* m, int i, const float* x
         p2.len_mul = spf;
         if (last_d || m->dec_unfused) {
           WETTS_TRY(launch_conv(rb.c2[d], p2, s));
-          count(1);
+          count(1, 3 + accum);
         } else {
           g2[n2] = &rb.c2[d];
           p2s[n2++] = p2;
@@ -1887,7 +1900,7 @@ static int32_t run_stage_rb1_grouped(const wetts_model* m, int i, const float* x
     if (n2 > 0) {
       int nl = 0;
       WETTS_TRY(launch_conv_group(g2, p2s, n2, s, &nl));
-      count(nl);
+      count(nl, 3.0 * n2);
     }
   }
   return WETTS_OK;
@@ -2006,7 +2019,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           cp.len_mul = spf;
           WETTS_TRY(launch_resblock_chain32(rb.c1.data(), rb.c2.data(), nd, cp, sj));
           if (tm && tm->on) tm->launches += 1;
-          if (m->mrf_timing) m->mrf_launches += 1;
+          mrf_count(m, 1, 2 + (j > 0 ? 1 : 0), ch, len, B, 4);
           continue;
         }
       }
@@ -2040,7 +2053,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           pp.slope = 0.1f;
           WETTS_TRY(launch_resblock2_chain32(rb.c1[0], rb.c1[1], pp, sj));
           if (tm && tm->on) tm->launches += 1;
-          if (m->mrf_timing) m->mrf_launches += 1;
+          mrf_count(m, 1, 2 + (j > 0 ? 1 : 0), ch, len, B, 4);
           rx = xsum;
           break;
         }
@@ -2071,7 +2084,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           cp.len_mul = spf;
           WETTS_TRY(launch_resblock_chain32(&rb.c1[d], &rb.c2[d], 1, cp, sj));
           if (tm && tm->on) tm->launches += 1;
-          if (m->mrf_timing) m->mrf_launches += 1;
+          mrf_count(m, 1, 2 + accum, ch, len, B, 4);
           rx = outp;
           continue;
         }
@@ -2095,7 +2108,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           pp.slope = 0.1f;
           WETTS_TRY(launch_resblock_pair32(rb.c1[d], rb.c2[d], pp, sj));
           if (tm && tm->on) tm->launches += 1;
-          if (m->mrf_timing) m->mrf_launches += 1;
+          mrf_count(m, 1, 2 + accum, ch, len, B, 4);
         } else if (c->resblock == 1) {
           // xt = c1(lrelu(x)); x = c2(lrelu(xt)) + x
           ConvParams p1 = conv_io(rx, ch, len, ft, ch, B);
@@ -2120,7 +2133,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           p2.len_mul = spf;
           WETTS_TRY(launch_conv(rb.c2[d], p2, sj));
           if (tm && tm->on) tm->launches += 2;
-          if (m->mrf_timing) m->mrf_launches += 2;
+          mrf_count(m, 2, 5 + accum, ch, len, B, 4);
         } else {
           // x = c(lrelu(x)) + x
           if (forked && last_d && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
@@ -2135,7 +2148,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           p1.tag = 1;
           WETTS_TRY(launch_conv(rb.c1[d], p1, sj));
           if (tm && tm->on) tm->launches += 1;
-          if (m->mrf_timing) m->mrf_launches += 1;
+          mrf_count(m, 1, 2 + accum, ch, len, B, 4);  // (input and residual are one tensor)
         }
         rx = outp;
       }
@@ -2330,7 +2343,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           sp.out_div = (float)nk;
           sp.slope = 0.1f;
           WETTS_TRY(launch_resblock2_stage16(c1s, c2s, nk, sp, s));
-          if (m->mrf_timing) m->mrf_launches += 1;
+          mrf_count(m, 1, 2, ch, len, B, 2);
           stage_done = true;
           break;  // every chain of the stage is done (on the caller's stream: nothing to join)
         }
@@ -2356,7 +2369,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           pp.out_div = (j == nk - 1) ? (float)nk : 1.f;
           pp.slope = 0.1f;
           WETTS_TRY(launch_resblock2_chain16(m->b_c1[n][0], m->b_c1[n][1], pp, s));
-          if (m->mrf_timing) m->mrf_launches += 1;
+          mrf_count(m, 1, 2 + (j > 0 ? 1 : 0), ch, len, B, 2);
           rx = xsum;
           break;
         }
@@ -2373,7 +2386,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           pp.out_div = odiv;
           pp.slope = 0.1f;
           WETTS_TRY(launch_resblock_pair16(m->b_c1[n][d], m->b_c2[n][d], pp, sj));
-          if (m->mrf_timing) m->mrf_launches += 1;
+          mrf_count(m, 1, 2 + accum, ch, len, B, 2);
         } else if (c->resblock == 1) {
           ConvBParams p1 = convb_io(rx, ch, len, ft, ch, len, B);
           p1.basic = m->dec_unfused;
@@ -2387,7 +2400,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           p2.accum = accum;
           p2.out_div = odiv;
           WETTS_TRY(launch_conv_bf16(m->b_c2[n][d], p2, sj));
-          if (m->mrf_timing) m->mrf_launches += 2;
+          mrf_count(m, 2, 5 + accum, ch, len, B, 2);
         } else {
           ConvBParams p1 = convb_io(rx, ch, len, outp, ch, len, B);
           p1.res = rx;
@@ -2396,7 +2409,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
           p1.out_div = odiv;
           p1.tag = 1;
           WETTS_TRY(launch_conv_bf16(m->b_c1[n][d], p1, s));
-          if (m->mrf_timing) m->mrf_launches += 1;
+          mrf_count(m, 1, 2 + accum, ch, len, B, 2);
         }
         rx = outp;
       }
@@ -2574,7 +2587,7 @@ static int32_t run_hifigan_u8(const wetts_model* m, const float* z, int64_t z_bs
         const QuantStats* cin_stats = rx_stats;
         QuantStats* s_ft = sl + 1 + (size_t)(j * nd + d) * 2;
         QuantStats* s_out = s_ft + 1;
-        if (m->mrf_timing) m->mrf_launches += (c->resblock == 1) ? 2 : 1;
+        mrf_count(m, (c->resblock == 1) ? 2 : 1, ((c->resblock == 1) ? 5 : 2) + ((last_d && j > 0) ? 1 : 0), ch, len, B, 4);  // f32 tensors between the nodes
         if (c->resblock == 1) {
           QConvIO i1 = qio(rx, ch, len, ft, ch, B);
           i1.in_act = 1;
@@ -2754,6 +2767,7 @@ int32_t wetts_set_mrf_timing(const wetts_model_t* m, int32_t enable) {
   m->mrf_events.clear();
   m->mrf_launches = 0;
   m->mrf_calls = 0;
+  m->mrf_bytes = 0;
   m->mrf_timing = enable != 0;
   return WETTS_OK;
 }
@@ -2774,6 +2788,11 @@ int32_t wetts_read_mrf_timing(const wetts_model_t* m, double* mrf_ms, int64_t* c
   return WETTS_OK;
 }
 
+int32_t wetts_read_mrf_bytes(const wetts_model_t* m, double* launched_bytes) {
+  WETTS_REQUIRE(m && launched_bytes, "null argument");
+  *launched_bytes = m->mrf_bytes;
+  return WETTS_OK;
+}
 
 int32_t wetts_mas(const float* neg_cent, const int32_t* t_ys, const int32_t* t_xs, int32_t B,
                   int32_t Ty, int32_t Tx, int32_t* path, void* workspace, int64_t workspace_bytes,

@@ -18,16 +18,175 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(backend=None):
-    """Initialises torch.distributed from MASTER_ADDR/MASTER_PORT/RANK/WORLD_SIZE if needed."""
+DEFAULT_TIMEOUT_S = 120.0  # process-group timeout (c10d's own default is 10-30 minutes: far too long for a bench)
+
+
+def describe_device(local_rank=None):
+    """One line naming the HIP device this rank is bound to (index, name, PCI address where torch exposes it): what a
+    failed multi-GPU start-up needs on stderr to tell WHICH GPU did not come up."""
+    if not torch.cuda.is_available():
+        return "no HIP device (CPU)"
+    i = torch.cuda.current_device() if local_rank is None else local_rank
+    try:
+        pr = torch.cuda.get_device_properties(i)
+        pci = ":".join(f"{int(getattr(pr, k)):02x}" for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")
+                       if hasattr(pr, k))
+        return f"cuda:{i} {pr.name} pci {pci or 'n/a'} {pr.total_memory >> 30} GiB"
+    except Exception as e:  # never let the diagnostics be the failure
+        return f"cuda:{i} (properties unavailable: {e})"
+
+
+def init_process_group(backend=None, timeout_s=None, force=False):
+    """Initialises torch.distributed from MASTER_ADDR/MASTER_PORT/RANK/WORLD_SIZE if needed.
+
+    `nccl` (= RCCL): the process group is BOUND to this rank's current device (`device_id`) -- c10d otherwise guesses
+    the device from the global rank ("can cause a hang if rank to GPU mapping is heterogeneous") and creates the
+    communicator lazily inside the first collective; with `device_id` it is created here, eagerly, under `timeout_s`
+    (default 120 s; WETTS_DIST_TIMEOUT_S overrides).  NCCL_DEBUG defaults to WARN so that a failing rank explains
+    itself on stderr; every rank names its device there first.  `force`: also at world size 1 (the RCCL start-up test
+    of a 1-GPU box)."""
+    import datetime
+    import sys
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("WETTS_DIST_BACKEND") or \
                 ("nccl" if torch.cuda.is_available() else "gloo")
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("WETTS_DIST_TIMEOUT_S", DEFAULT_TIMEOUT_S))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # see launch_ranks
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        sys.stderr.write(f"[wetts rank {rank}/{world}] {backend} on {describe_device()} "
+                         f"(timeout {timeout_s:.0f} s, NCCL_DEBUG={os.environ['NCCL_DEBUG']})\n")
+        sys.stderr.flush()
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return rank, local_rank, world
+
+
+class PhaseMonitor:
+    """Deadline watchdog of a multi-rank job that nobody can rehearse (no multi-GPU node before the driver's run).
+
+    The job moves through named phases (rendezvous, broadcast, warm-up, timed loop, reductions).  Entering a phase
+    (a) counts this rank in on the rendezvous store (`wetts/at/<phase>`, a TCPStore counter: no collective, no device)
+    and (b) arms a deadline.  A daemon thread watches the deadline: when a phase overruns -- a rank that never came up,
+    a hung collective, a hung GPU -- it reads how many ranks reached the phase, calls `on_expire(phase, ranks_seen)`
+    (rank 0 prints its partial result line there) and ends the process with exit code 4, instead of leaving the
+    launcher to wait for c10d's watchdog or for ever.  The deadlines of the collective phases are kept BELOW the
+    process-group timeout so that this monitor, which can still report, fires before NCCL's abort."""
+
+    EXIT_CODE = 4
+
+    def __init__(self, rank, world, on_expire=None, default_deadline_s=None):
+        import threading
+        self.rank, self.world = rank, world
+        self.on_expire = on_expire
+        env = os.environ.get("WETTS_BENCH_PHASE_DEADLINE_S")
+        self.override = float(env) if env else default_deadline_s
+        self.phase, self.deadline = None, None
+        self.store = None
+        self._lock = threading.Lock()
+        self._stop = threading.Event()
+        self._thr = None
+        self._sig_r = None
+        if world > 1:
+            self._watch_sigterm()
+            self._thr = threading.Thread(target=self._watch, name="wetts-phase-monitor", daemon=True)
+            self._thr.start()
+
+    def _watch_sigterm(self):
+        """torchrun answers one rank's crash by sending SIGTERM to the others.  A Python-level handler would only run
+        once the main thread returns from the collective it is blocked in (never, then); the wake-up fd is written by
+        the C-level handler at once, and the monitor thread reads it."""
+        import signal
+        import threading
+        if threading.current_thread() is not threading.main_thread():
+            return
+        try:
+            r, w = os.pipe()
+            os.set_blocking(w, False)
+            os.set_blocking(r, False)
+            signal.signal(signal.SIGTERM, lambda *_: None)
+            signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+            self._sig_r = r
+        except (OSError, ValueError):
+            self._sig_r = None
+
+    def attach_store(self):
+        """After init_process_group: the default rendezvous store carries the roll call."""
+        if dist.is_initialized():
+            try:
+                self.store = dist.distributed_c10d._get_default_store()
+            except Exception:
+                self.store = None
+        return self
+
+    def enter(self, phase, deadline_s):
+        import time
+        with self._lock:
+            self.phase = phase
+            # (the reporting rank fires first: a non-zero rank that left earlier would only make the launcher tear rank 0 down)
+            self.deadline = time.monotonic() + (self.override if self.override else deadline_s) + (0.0 if self.rank == 0 else 3.0)
+        if self.store is not None:
+            try:
+                self.store.add("wetts/at/" + phase, 1)
+            except Exception:
+                pass
+
+    def ranks_at(self, phase):
+        """How many ranks have entered `phase` (None when the store cannot be asked)."""
+        if self.store is None:
+            return None
+        try:
+            return int(self.store.add("wetts/at/" + phase, 0))
+        except Exception:
+            return None
+
+    def done(self):
+        self._stop.set()
+
+    def expire_now(self, why):
+        """The same exit path for a failure the main thread caught itself (an exception out of a collective)."""
+        self._fire(self.phase or "start-up", why)
+
+    def _fire(self, phase, why):
+        import sys
+        seen = self.ranks_at(phase)
+        sys.stderr.write(f"[wetts rank {self.rank}/{self.world}] {why} in phase '{phase}' on {describe_device()}; "
+                         f"ranks that reached it: {seen if seen is not None else 'unknown'} of {self.world}\n")
+        sys.stderr.flush()
+        try:
+            if self.on_expire is not None:
+                self.on_expire(phase, seen, why)
+        finally:
+            sys.stdout.flush()
+            os._exit(self.EXIT_CODE)
+
+    def _watch(self):
+        import select
+        import signal
+        import time
+        while not self._stop.is_set():
+            if self._sig_r is not None:
+                rd, _, _ = select.select([self._sig_r], [], [], 0.25)
+                if rd:
+                    try:
+                        got = os.read(self._sig_r, 64)
+                    except OSError:
+                        got = b""
+                    if bytes([signal.SIGTERM]) in got and not self._stop.is_set():
+                        self._fire(self.phase or "start-up", "SIGTERM (the launcher is tearing the job down: another "
+                                                             "rank failed)")
+            else:
+                self._stop.wait(0.25)
+            with self._lock:
+                phase, deadline = self.phase, self.deadline
+            if deadline is not None and time.monotonic() > deadline and not self._stop.is_set():
+                self._fire(phase, "deadline passed")
 
 
 def launch_ranks(n, script, argv, require_gpus=True):
@@ -56,6 +215,7 @@ def launch_ranks(n, script, argv, require_gpus=True):
     # it RCCL fails in hipIpcGetMemHandle); a child environment built here must carry the same setting, and an
     # operator's own value wins
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("NCCL_DEBUG", "WARN")  # a rank that fails explains itself on stderr
     return subprocess.call(cmd + list(argv), env=env)
 
 
