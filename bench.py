@@ -174,7 +174,7 @@ def stream_bench(args):
     w0, wm = wins[0], wins[min(1, len(wins) - 1)]
     res["encoder_ms"] = med(lambda: enc.run(None, feeds), args.stream_reps)
     res["encoder_ms_graph"] = med(lambda: encg.run(None, feeds), args.stream_reps)
-    res["encoder_graph_entries"] = [len(encg._graphed._pre), len(encg._graphed._post)]
+    res["encoder_graph_entries"] = [len(encg._graphed._pre), sum(len(e["post"]) for e in encg._graphed._pre.values())]
     for name, d in (("plain", dec), ("graph", decg)):
         res[f"first_window_ms_{name}"] = med(
             lambda: d.run(None, {"z": z[:, w0[0]:w0[1]], "sid": sid}), args.stream_reps)

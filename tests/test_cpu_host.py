@@ -163,6 +163,8 @@ def test_triton_min_chunk_helpers_match_the_references_own_functions():
         elif n == 1 and pad_end > 0:  # reference keeps audio of reflected frames; here clipped to real frames
             seen_single += 1
             assert (lo, hi) == (0, min(block, wlen) * hop) and g == (0, L * hop)
+            # ... and strict_reference=True reproduces the reference client's range sample for sample
+            assert depad_bounds_min(n, i, block, pad, hop, wlen * hop, last_pad or None, strict_reference=True) == (lo, hi)
         else:
             assert g == (lo, hi), (L, block, pad, i, g, (lo, hi))
     assert seen_pad > 10 and seen_raise > 0 and seen_single > 0
@@ -380,3 +382,19 @@ def test_export_prelude_of_the_reference_runs_on_the_drop_in_module():
     assert net.eval() is net and net(1, 2, 3) == "audio" and seen == [(1, 2, 3)]
     net.forward = net.export_forward  # bound method of the instance, as the reference assigns it
     assert net.forward.__self__ is net
+
+
+def test_mrf_mean_quotient_is_the_ieee_division_for_every_float(tmp_path):
+    """common.h: div_small_const -- the 3-operation form of xs / num_kernels (decoders.py:77) in every decoder epilogue --
+    equals the IEEE division bit for bit for ALL 2^32 float inputs at the divisors it is used for (2 and 3), except the
+    sign of the zero it returns for v = -0.0 (exhaustive host run of tests/native/div_small_const_check.c, ~2 s each)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "div_small_const_check.c")
+    exe = str(tmp_path / "divchk")
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-mfma", "-ffp-contract=off", src, "-o", exe, "-lm"])
+    for d in ("3", "2"):
+        bad, zsign = (int(v) for v in subprocess.check_output([exe, d], timeout=600).split())
+        assert bad == 0 and zsign == 1, (d, bad, zsign)

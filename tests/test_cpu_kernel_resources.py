@@ -15,8 +15,31 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import kernel_resources  # noqa: E402
 from wetts_amd import _lib  # noqa: E402
 
-pytestmark = pytest.mark.skipif(not os.path.exists(kernel_resources.READELF) or shutil.which("c++filt") is None,
-                                reason="needs llvm-readelf and c++filt")
+pytestmark = pytest.mark.skipif(not os.path.exists(kernel_resources.READELF) or shutil.which("c++filt") is None or
+                                not os.path.exists(_lib.LIB_PATH),
+                                reason="needs llvm-readelf, c++filt and a built wetts_amd/lib/libwetts_hip.so "
+                                       "(the library is git-ignored: run __graft_entry__.build() first)")
+
+# The budgets below are properties of (sources, compiler): they were measured with this hipcc.  Another compiler may
+# allocate registers differently without anything being wrong in the sources, so a budget miss under a different
+# compiler is reported as an expected failure (re-measure with tools/kernel_resources.py and update both).
+BUDGETS_MEASURED_WITH = "HIP version: 7.2"
+
+
+def _compiler_matches():
+    import subprocess
+    try:
+        out = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True, timeout=60).stdout
+    except (OSError, subprocess.SubprocessError):
+        return False
+    return BUDGETS_MEASURED_WITH in out
+
+
+@pytest.fixture(autouse=True)
+def _other_compiler_is_xfail(request):
+    if not _compiler_matches():
+        request.node.add_marker(pytest.mark.xfail(reason="register budgets were measured with " + BUDGETS_MEASURED_WITH,
+                                                  strict=False))
 
 # kernels that are allowed to touch scratch, with a bound in bytes per lane: spills outside their MFMA loops (checked in
 # the ISA when they were admitted), or an indexed local array

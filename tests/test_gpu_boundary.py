@@ -496,13 +496,79 @@ def test_graphed_encoder_matches_plain_and_keeps_the_noise_stream():
         assert a.shape == b.shape, (a.shape, b.shape)  # same frame count: the durations saw the same noise
         assert util.rel_rms(b, a) < 1e-5, (rep, util.rel_rms(b, a))
         assert np.array_equal(b == 0, a == 0)  # the same frames are masked
-    assert len(graphed._graphed._pre) == 1 and 1 <= len(graphed._graphed._post) <= 4
+    ge = graphed._graphed
+    assert len(ge._pre) == 1 and 1 <= len(next(iter(ge._pre.values()))["post"]) <= 4
     bad = dict(feeds, input=np.full_like(case["x"], int(case["n_vocab"]) + 5))
     with pytest.raises(IndexError):
         graphed.run(None, bad)
     torch.manual_seed(3)
     ok = graphed.run(None, feeds)[0]  # and the entry still works afterwards
     assert np.isfinite(ok).all()
+
+
+def test_graphed_encoder_caches_are_bounded_and_bucket_the_phoneme_count():
+    """A serving loop sees a new phoneme count with almost every request.  The phoneme count is bucketed (ids padded with
+    zeros, x_lengths masks them: a shorter utterance in a padded batch), so requests of 9 ... 16 phonemes replay ONE
+    first-half graph; and both caches are LRU-bounded, so 40 distinct lengths leave at most `max_shapes` entries (each
+    with at most `max_buckets` second-half graphs) instead of 40 graphs + 40 private workspaces.  Results stay those of
+    the plain call (same seed => same durations, z to round-off), also for an entry that was evicted and re-captured."""
+    from wetts_amd.session import EncoderSession
+    net, case, cfg, sd, W = _model("tiny_sdp_b3")
+    plain = EncoderSession(net)
+    graphed = EncoderSession(net, use_graph=True, frame_bucket=16, phoneme_bucket=8, max_shapes=3, max_buckets=2)
+    ge = graphed._graphed
+    g = np.random.default_rng(1)
+
+    def one(Tx, seed):
+        x = g.integers(0, int(case["n_vocab"]), size=(2, Tx))
+        feeds = {"input": x, "input_lengths": np.array([Tx, max(1, Tx - 3)]), "scales": np.tile(np.array([[0.667, 1.0, 0.8]], np.float32), (2, 1)),
+                 "sid": np.array([0, 2])}
+        torch.manual_seed(seed)
+        a = plain.run(None, feeds)[0]
+        torch.manual_seed(seed)
+        b = graphed.run(None, feeds)[0]
+        assert a.shape == b.shape, (Tx, a.shape, b.shape)
+        assert util.rel_rms(b, a) < 1e-5 and np.array_equal(b == 0, a == 0), (Tx, util.rel_rms(b, a))
+
+    for Tx in range(9, 17):  # one phoneme bucket (16): a single first-half graph
+        one(Tx, 100 + Tx)
+    assert len(ge._pre) == 1
+    for Tx in range(1, 41):  # five buckets through a cache of three
+        one(Tx, 200 + Tx)
+    assert len(ge._pre) <= 3 and all(len(e["post"]) <= 2 for e in ge._pre.values())
+    before = ge.captures
+    one(40, 7)  # most recent bucket: a replay, nothing captured
+    assert ge.captures <= before + 1  # (at most a new frame bucket)
+    one(3, 8)  # evicted long ago: captured again, still right
+    assert ge.captures > before and len(ge._pre) <= 3
+
+
+def test_overlap_debug_mode_catches_an_unmaterialised_input():
+    """WETTS_DEBUG_OVERLAP: with overlap on, a call whose ids are still being produced by a device op on the caller's
+    stream is a race (the side stream does not wait for it); the debug mode turns it into an exception, and leaves a
+    correct call alone."""
+    net, case, cfg, sd, W = _model("tiny_sdp_b3")
+    x, xl, sid = (util.t(case[k]).cuda() for k in ("x", "x_lengths", "sid"))
+    net.set_overlap(True)
+    net._debug_overlap = True
+    try:
+        torch.manual_seed(5)
+        o1, *_ = net.infer(x, xl, sid=sid, noise_scale=0.667, noise_scale_w=0.8)  # materialised inputs: fine
+        torch.cuda.synchronize()
+        big = torch.zeros(64 << 20, device="cuda")
+        x2 = torch.full_like(x, 1)
+        for _ in range(100):  # keep the caller's stream busy, then produce the ids behind that work
+            big.add_(1.0)
+        x2.copy_(x, non_blocking=True)
+        with pytest.raises(RuntimeError, match="overlap mode"):
+            net.infer(x2, xl, sid=sid, noise_scale=0.667, noise_scale_w=0.8)
+        torch.cuda.synchronize()
+        torch.manual_seed(5)
+        o3, *_ = net.infer(x2, xl, sid=sid, noise_scale=0.667, noise_scale_w=0.8)  # now materialised
+        assert torch.equal(o1, o3)
+    finally:
+        net._debug_overlap = False
+        net.set_overlap(False)
 
 
 def test_overlap_mode_pipelines_calls_without_changing_results():

@@ -79,6 +79,23 @@ enum InAct { IN_NONE = 0, IN_LRELU = 1 };
 enum OutAct { OUT_NONE = 0, OUT_RELU = 1, OUT_GELU = 2, OUT_GATE = 3 };
 __device__ __forceinline__ float wn_gate(float ta, float sa) { return tanhf(ta) * (1.f / (1.f + expf(-sa))); }
 
+// v / d for d in {2, 3}: q = RN(v * c), r = fma(-d, q, v) (exact), q + r * c -- the correctly rounded quotient for EVERY
+// finite float (exhaustive check of all 2^32 bit patterns on the host; the one difference is the sign of a zero
+// result), in 3 VALU operations where the IEEE division sequence (v_div_scale / fmas / fixup) is ~10.  c = RN(1 / d).
+__device__ __forceinline__ float div_small_const(float v, float d, float c) {
+  const float q = v * c;
+  const float r = __builtin_fmaf(-d, q, v);
+  return __builtin_fmaf(r, c, q);
+}
+
+// the MRF mean  xs / num_kernels  (decoders.py:77) in every decoder epilogue: the 3-operation form for the divisors the
+// recipes use (uniform branch), the IEEE division otherwise.  EVERY path (single convs, fused pairs, chains, stage kernel,
+// 16 bit) goes through this one function, so fused and unfused launches stay bit-identical to each other.
+__device__ __forceinline__ bool mrf_div_fast(float d) { return d == 3.f || d == 2.f; }
+__device__ __forceinline__ float mrf_div(float v, float d, float dinv, bool fast) {
+  return fast ? div_small_const(v, d, dinv) : v / d;
+}
+
 struct ConvParams {
   // input
   const float* x;

@@ -66,15 +66,6 @@ __device__ __forceinline__ unsigned lrelu_pk(unsigned w, float slope) {
   const float a = lrelu_max(lo16<F16>(w), slope), c = lrelu_max(hi16<F16>(w), slope);
   return pk2<F16>(a, c);
 }
-// v / d for d in {2, 3}: q = RN(v * c), r = fma(-d, q, v) (exact), q + r * c -- the correctly rounded quotient for EVERY
-// finite float (exhaustive check of all 2^32 bit patterns on the host; the one difference is the sign of a zero
-// result), in 3 VALU operations where the IEEE division sequence (v_div_scale / fmas / fixup) is ~10.  c = RN(1 / d).
-__device__ __forceinline__ float div_small_const(float v, float d, float c) {
-  const float q = v * c;
-  const float r = __builtin_fmaf(-d, q, v);
-  return __builtin_fmaf(r, c, q);
-}
-
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c) {
   if (F16)

@@ -402,29 +402,32 @@ void conv_bf16_kernel(const ConvBParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) bia[r] += bb[co_blk + 16 * (r >> 3) + 8 * half + (r & 7)];
   }
+  auto store_all = [&](auto fin) {
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int col = wcol0 + 32 * j + (lane & 31);
-    if (col >= p.N) continue;
-    int t = col;
-    if (p.up > 0) {
-      t = col * p.up + ph - p.up_pad;
-      if (t < 0 || t >= p.Tout) continue;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] = acc[j][8 * i + e] + bia[8 * i + e];
-        if (dodiv) v[e] = v[e] / p.out_div;
+    for (int j = 0; j < NB; ++j) {
+      const int col = wcol0 + 32 * j + (lane & 31);
+      if (col >= p.N) continue;
+      int t = col;
+      if (p.up > 0) {
+        t = col * p.up + ph - p.up_pad;
+        if (t < 0 || t >= p.Tout) continue;
       }
-      uint4 o;
-      o.x = pk2<F16>(v[0], v[1]); o.y = pk2<F16>(v[2], v[3]);
-      o.z = pk2<F16>(v[4], v[5]); o.w = pk2<F16>(v[6], v[7]);
-      *reinterpret_cast<uint4*>(ob + (int64_t)t * p.cout + co_blk + 16 * i + 8 * half) = o;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fin(acc[j][8 * i + e] + bia[8 * i + e]);
+        uint4 o;
+        o.x = pk2<F16>(v[0], v[1]); o.y = pk2<F16>(v[2], v[3]);
+        o.z = pk2<F16>(v[4], v[5]); o.w = pk2<F16>(v[6], v[7]);
+        *reinterpret_cast<uint4*>(ob + (int64_t)t * p.cout + co_blk + 16 * i + 8 * half) = o;
+      }
     }
-  }
+  };
+  const float dv = p.out_div, dinv = 1.f / p.out_div;  // the MRF mean (common.h: mrf_div), uniform choice
+  if (!dodiv) store_all([](float v) { return v; });
+  else if (mrf_div_fast(dv)) store_all([=](float v) { return div_small_const(v, dv, dinv); });
+  else store_all([=](float v) { return v / dv; });
 }
 
 template <int NB, int WM, int WN, int CKB>

@@ -489,20 +489,28 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, int bid) {
     float om[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) om[j] = EPI == 4 ? omask[wcol0 + 32 * j + (lane & 31)] : 1.f;
+    auto store_all = [&](auto fin) {
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
+      for (int i = 0; i < MB; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rloc = i * 32 + (r & 3) + 8 * (r >> 2);
-        const unsigned roff = (unsigned)rloc * ocs4 + olane;
+        for (int r = 0; r < 16; ++r) {
+          const int rloc = i * 32 + (r & 3) + 8 * (r >> 2);
+          const unsigned roff = (unsigned)rloc * ocs4 + olane;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          float v = acc[i][j][r] + bia[i][r];
-          if (EPI == 2) v = v / p.out_div;
-          if (EPI == 4) v *= om[j];
-          *reinterpret_cast<float*>(obase + (roff + 128u * j)) = v;
+          for (int j = 0; j < NB; ++j) {
+            float v = fin(acc[i][j][r] + bia[i][r]);
+            if (EPI == 4) v *= om[j];
+            *reinterpret_cast<float*>(obase + (roff + 128u * j)) = v;
+          }
         }
       }
+    };
+    if (EPI == 2) {  // the MRF mean (common.h: mrf_div): uniform choice of the quotient form, straight-line code each
+      const float dv = p.out_div, dinv = 1.f / p.out_div;
+      if (mrf_div_fast(dv)) store_all([=](float v) { return div_small_const(v, dv, dinv); });
+      else store_all([=](float v) { return v / dv; });
+    } else {
+      store_all([](float v) { return v; });
     }
     return;
   }
@@ -577,7 +585,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, int bid) {
           if (p.res) v += p.res[rb + (int64_t)co * p.r_cs + t];
           if (p.accum) v += *dst;
         }
-        if (p.out_div != 1.f) v = v / p.out_div;
+        if (p.out_div != 1.f) v = mrf_div(v, p.out_div, 1.f / p.out_div, mrf_div_fast(p.out_div));
         *dst = v;
       }
     }

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64 * KG) void conv_small_kernel(const ConvParams p)
     float* dst = p.out + ob + (int64_t)co * p.o_cs + t;
     if (p.res) v += p.res[rb + (int64_t)co * p.r_cs + t];
     if (p.accum) v += *dst;
-    if (p.out_div != 1.f) v = v / p.out_div;
+    if (p.out_div != 1.f) v = mrf_div(v, p.out_div, 1.f / p.out_div, mrf_div_fast(p.out_div));
     *dst = v;
   }
 }

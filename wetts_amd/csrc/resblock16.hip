@@ -358,29 +358,31 @@ void resblock_pair16_kernel(const ResPairParams p) {
   for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
     for (int r = 0; r < 16; ++r) bia[mi][r] = p.bias2[co_blk + 32 * mi + 16 * (r >> 3) + 8 * half + (r & 7)];
-  const bool dodiv = p.out_div != 1.f;
+  auto store_all = [&](auto fin) {
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int col = wcol + 32 * j;
-    const int t = RB2 ? n0 - h2 + col : n0 + col;
-    if (RB2 ? (col < h2 || col >= NTC - h2 || t < 0) : col >= NTO) continue;
-    if (t >= p.T) continue;
+    for (int j = 0; j < NB; ++j) {
+      const int col = wcol + 32 * j;
+      const int t = RB2 ? n0 - h2 + col : n0 + col;
+      if (RB2 ? (col < h2 || col >= NTC - h2 || t < 0) : col >= NTO) continue;
+      if (t >= p.T) continue;
 #pragma unroll
-    for (int mi = 0; mi < MB; ++mi)
+      for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float v[8];
+        for (int i = 0; i < 2; ++i) {
+          float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] = acc[mi][j][8 * i + e] + bia[mi][8 * i + e];
-          if (dodiv) v[e] = v[e] / p.out_div;
+          for (int e = 0; e < 8; ++e) v[e] = fin(acc[mi][j][8 * i + e] + bia[mi][8 * i + e]);
+          uint4 o;
+          o.x = pk2<F16>(v[0], v[1]); o.y = pk2<F16>(v[2], v[3]);
+          o.z = pk2<F16>(v[4], v[5]); o.w = pk2<F16>(v[6], v[7]);
+          *reinterpret_cast<uint4*>(ob + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half) = o;
         }
-        uint4 o;
-        o.x = pk2<F16>(v[0], v[1]); o.y = pk2<F16>(v[2], v[3]);
-        o.z = pk2<F16>(v[4], v[5]); o.w = pk2<F16>(v[6], v[7]);
-        *reinterpret_cast<uint4*>(ob + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half) = o;
-      }
-  }
+    }
+  };
+  const float dv = p.out_div, dinv = 1.f / p.out_div;  // the MRF mean (common.h: mrf_div), uniform choice
+  if (dv == 1.f) store_all([](float v) { return v; });
+  else if (mrf_div_fast(dv)) store_all([=](float v) { return div_small_const(v, dv, dinv); });
+  else store_all([=](float v) { return v / dv; });
 }
 
 template <int C, int NR, int OCC, bool RB2, int MB>

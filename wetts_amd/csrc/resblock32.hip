@@ -255,20 +255,22 @@ void resblock_pair32_kernel(const ResPair32Params p) {
   float bia[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) bia[r] = p.bias2[co_blk + (r & 3) + 8 * (r >> 2) + 4 * half];
-  const bool dodiv = p.out_div != 1.f;
+  auto store_all = [&](auto fin) {
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int col = wcol + 32 * j;
-    const int t = RB2 ? n0 - h2 + col : n0 + col;
-    if (RB2 ? (col < h2 || col >= NTC - h2 || t < 0) : col >= NTO) continue;
-    if (t >= p.T) continue;
+    for (int j = 0; j < NB; ++j) {
+      const int col = wcol + 32 * j;
+      const int t = RB2 ? n0 - h2 + col : n0 + col;
+      if (RB2 ? (col < h2 || col >= NTC - h2 || t < 0) : col >= NTO) continue;
+      if (t >= p.T) continue;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = acc[j][r] + bia[r];
-      if (dodiv) v = v / p.out_div;
-      ob[(int64_t)(co_blk + (r & 3) + 8 * (r >> 2) + 4 * half) * p.T + t] = v;
+      for (int r = 0; r < 16; ++r)
+        ob[(int64_t)(co_blk + (r & 3) + 8 * (r >> 2) + 4 * half) * p.T + t] = fin(acc[j][r] + bia[r]);
     }
-  }
+  };
+  const float dv = p.out_div, dinv = 1.f / p.out_div;  // the MRF mean (common.h: mrf_div)
+  if (dv == 1.f) store_all([](float v) { return v; });
+  else if (mrf_div_fast(dv)) store_all([=](float v) { return div_small_const(v, dv, dinv); });
+  else store_all([=](float v) { return v / dv; });
 }
 
 template <int C, bool RB2>

@@ -350,20 +350,24 @@ void resblock_chain32_kernel(const ResChain32Params p) {
   }
 
   // ---- epilogue: out = (x [+ out]) / div on the valid middle columns -------------------------------
-  const bool dodiv = p.out_div != 1.f;
+  // (three straight-line variants behind uniform branches: a select between the quotient forms inside the unrolled loop
+  // would compute the ~10-instruction IEEE sequence for every element whether it is used or not)
+  auto store_all = [&](auto fin) {
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int col = wcol + 32 * j;
-    const int t = t0 + col;
-    const bool ok = col >= p.S && col < NTC - p.S && t < Tb;  // t >= n0 >= 0 inside the window
-    if (!ok) continue;
+    for (int j = 0; j < NB; ++j) {
+      const int col = wcol + 32 * j;
+      const int t = t0 + col;
+      const bool ok = col >= p.S && col < NTC - p.S && t < Tb;  // t >= n0 >= 0 inside the window
+      if (!ok) continue;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = xr[j][r];
-      if (dodiv) v = v / p.out_div;
-      buf_store_f32(v, rso0, lane_off + 128 * j, ((r & 3) + 8 * (r >> 2)) * T * 4);
+      for (int r = 0; r < 16; ++r)
+        buf_store_f32(fin(xr[j][r]), rso0, lane_off + 128 * j, ((r & 3) + 8 * (r >> 2)) * T * 4);
     }
-  }
+  };
+  const float dv = p.out_div, dinv = 1.f / p.out_div;
+  if (dv == 1.f) store_all([](float v) { return v; });
+  else if (mrf_div_fast(dv)) store_all([=](float v) { return div_small_const(v, dv, dinv); });
+  else store_all([=](float v) { return v / dv; });
 }
 
 // per-side half-widths of the chain's convs, in execution order

@@ -18,6 +18,7 @@ raises from inside its modules: IndexError of nn.Embedding, the spline's discrim
 back in ONE D2H copy.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -90,6 +91,7 @@ class SynthesizerTrn:
         self._ws_dec = _Workspace()  # the decoder's own scratch in overlap mode (see set_overlap)
         self._enc_stream = None
         self.overlap = False
+        self._debug_overlap = bool(os.environ.get("WETTS_DEBUG_OVERLAP"))  # check the overlap contract on every call
         self.dec = _FoldedPart()
         self.flow = _FoldedPart()
         self.quiet = True      # the reference prints stage timers on every call (:273-279)
@@ -161,17 +163,21 @@ class SynthesizerTrn:
         self.overlap = bool(on)
         return self
 
-    def upload(self, t, dtype=None):
-        """Host tensor / array -> device tensor on the stream that will read it: the caller's stream, or in overlap
-        mode the encoder's side stream (whose work is NOT ordered behind the caller's stream, see set_overlap).  The
+    def upload(self, t, dtype=None, consumer="encoder"):
+        """Host tensor / array -> device tensor on the stream that will read it.  `consumer="encoder"` (ids, lengths,
+        speaker ids: what infer() / infer_encoder() read): the caller's stream, or in overlap mode the encoder's side
+        stream, whose work is NOT ordered behind the caller's stream (see set_overlap).  `consumer="decoder"` (a z chunk
+        for export_decoder_forward / hifigan): always the caller's stream, where the decoder runs in either mode.
+        A pinned source is copied without blocking the host (the copy is stream-ordered in front of its reader).  The
         wetts_amd hosts (sessions, batching, CLI) put their inputs on the device through this."""
         t = torch.as_tensor(t)
-        if not (self.overlap and self.device.type == "cuda"):
-            return t.to(device=self.device, dtype=dtype)
+        nb = bool(t.device.type == "cpu" and t.is_pinned())
+        if consumer != "encoder" or not (self.overlap and self.device.type == "cuda"):
+            return t.to(device=self.device, dtype=dtype, non_blocking=nb)
         if self._enc_stream is None:
             self._enc_stream = torch.cuda.Stream(device=self.device)
         with torch.cuda.stream(self._enc_stream):
-            return t.to(device=self.device, dtype=dtype)
+            return t.to(device=self.device, dtype=dtype, non_blocking=nb)
 
     def blob_layout(self):
         return checkpoint.blob_layout(self.cfg)
@@ -494,22 +500,7 @@ class SynthesizerTrn:
         padded batch to the longest utterance; ragged decodes row b over its own y_lengths[b] frames -- the audio
         the reference returns when that utterance is synthesised alone (its CLI's call shape) -- and writes zeros
         behind it.  The masked stages (encoder, durations, flow) are batch independent either way."""
-        if self.overlap and self.device.type == "cuda":
-            main = torch.cuda.current_stream(self.device)
-            if self._enc_stream is None:
-                self._enc_stream = torch.cuda.Stream(device=self.device)
-            with torch.cuda.stream(self._enc_stream):
-                st = self._encode(x, x_lengths, sid, float(noise_scale), float(length_scale),
-                                  float(noise_scale_w), eps_w, eps_z)
-                done = torch.cuda.Event()
-                done.record(self._enc_stream)
-            main.wait_event(done)
-            for v in st.values():  # allocated on the side stream, consumed (and later freed) on the caller's
-                if isinstance(v, torch.Tensor) and v.is_cuda:
-                    v.record_stream(main)
-        else:
-            st = self._encode(x, x_lengths, sid, float(noise_scale), float(length_scale),
-                              float(noise_scale_w), eps_w, eps_z)
+        st = self._encode_ordered(x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, eps_w, eps_z)
         Ty = st["Ty"]
         L = Ty if max_len is None else max(0, min(Ty, int(max_len)))
         o = self._decode(st["z"], st["g"], st["y_mask"], L, st["y_lengths"] if ragged else None)
@@ -517,11 +508,48 @@ class SynthesizerTrn:
         return (o, st["attn"].unsqueeze(1), st["y_mask"].unsqueeze(1),
                 (st["z"], st["z_p"], st["m_p"], st["logs_p"]))
 
+    def _encode_ordered(self, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, eps_w, eps_z):
+        """_encode for the public entry points (infer, infer_encoder, export_encoder_forward, the sessions): on the
+        caller's stream, or -- overlap mode -- on the side stream with the result ordered in front of whatever the
+        caller's stream does next.  EVERY entry point goes through here, so in overlap mode the encoder workspace
+        (self._ws) is only ever touched on the side stream: mixing infer() with infer_encoder() / the encoder session
+        cannot race on it.  WETTS_DEBUG_OVERLAP=1 checks the one contract of the mode on every call (see set_overlap):
+        it compares what the side stream reads of the id tensors NOW with their contents once the caller's stream has
+        drained, and raises if a device op that produces them was still pending (it serialises the pipeline: debug only)."""
+        if not (self.overlap and self.device.type == "cuda"):
+            return self._encode(x, x_lengths, sid, float(noise_scale), float(length_scale),
+                                float(noise_scale_w), eps_w, eps_z)
+        main = torch.cuda.current_stream(self.device)
+        if self._enc_stream is None:
+            self._enc_stream = torch.cuda.Stream(device=self.device)
+        if self._debug_overlap:
+            ins = [t for t in (x, x_lengths, sid, eps_w, eps_z) if isinstance(t, torch.Tensor) and t.is_cuda]
+            with torch.cuda.stream(self._enc_stream):
+                seen = [t.clone() for t in ins]  # what the side stream reads at this point of the caller's stream
+            main.synchronize()
+            self._enc_stream.synchronize()
+            for a, b in zip(seen, ins):
+                if not torch.equal(a, b):
+                    raise RuntimeError(
+                        "overlap mode: an input tensor was still being produced on the caller's stream when the call "
+                        "was made; the encoder stages read inputs on a side stream WITHOUT waiting for the caller's "
+                        "stream (SynthesizerTrn.set_overlap).  Materialise inputs first (upload(), or synchronise), "
+                        "or call set_overlap(False).")
+        with torch.cuda.stream(self._enc_stream):
+            st = self._encode(x, x_lengths, sid, float(noise_scale), float(length_scale),
+                              float(noise_scale_w), eps_w, eps_z)
+            done = torch.cuda.Event()
+            done.record(self._enc_stream)
+        main.wait_event(done)
+        for v in st.values():  # allocated on the side stream, consumed (and later freed) on the caller's
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                v.record_stream(main)
+        return st
+
     def infer_encoder(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1,
                       noise_scale_w=1.0, eps_w=None, eps_z=None):
         """models.py:282-331.  Returns (attn, y_mask, (z*y_mask, z_p, m_p, logs_p), g)."""
-        st = self._encode(x, x_lengths, sid, float(noise_scale), float(length_scale),
-                          float(noise_scale_w), eps_w, eps_z)
+        st = self._encode_ordered(x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, eps_w, eps_z)
         z = torch.empty_like(st["z"])
         _lib.check(_lib.load().wetts_mask_rows(_lib.ptr(st["z"]), _lib.ptr(st["y_mask"]), st["B"],
                                                self.inter_channels, st["Ty"], _lib.ptr(z),

@@ -26,8 +26,8 @@ class _SessionBase:
             raise RuntimeError("model must have weights loaded and live on a HIP device")
         self.model = model
 
-    def _dev(self, a, dtype):
-        return self.model.upload(np.asarray(a), dtype)
+    def _dev(self, a, dtype, consumer="encoder"):
+        return self.model.upload(np.asarray(a), dtype, consumer=consumer)
 
     def get_providers(self):
         return ["WettsHIPExecutionProvider"]
@@ -104,9 +104,9 @@ class EncoderSession(_SessionBase):
     """Streaming front half (export_encoder_forward, models.py:346-358): -> z [B, L, inter].
     `use_graph=True` replays captured HIP graphs for repeating shapes (see GraphedEncoder)."""
 
-    def __init__(self, model, use_graph=False, frame_bucket=32):
+    def __init__(self, model, use_graph=False, frame_bucket=32, phoneme_bucket=16, max_shapes=8, max_buckets=8):
         super().__init__(model)
-        self._graphed = GraphedEncoder(model, frame_bucket) if use_graph else None
+        self._graphed = GraphedEncoder(model, frame_bucket, phoneme_bucket, max_shapes, max_buckets) if use_graph else None
 
     def get_inputs(self):
         return InferenceSession.get_inputs(self)
@@ -144,15 +144,41 @@ class GraphedEncoder:
     to round-off (1e-6), not bit for bit.  The two standard-normal draws are made OUTSIDE the graphs (the Philox
     (seed, offset) pair is a kernel argument) into the graphs' input buffers, from the same stream positions as the
     plain path: a seed gives the same audio either way.  Buffers, workspaces included, are owned per graph entry
-    because a graph bakes the pointers in."""
+    because a graph bakes the pointers in.
 
-    def __init__(self, model: SynthesizerTrn, frame_bucket=32):
+    The caches are BOUNDED.  A serving process sees a new phoneme count with almost every request, and an entry is a
+    captured graph plus private input / output buffers plus a whole private workspace: unbounded, device memory grows
+    with every distinct shape and most requests pay a capture instead of a replay.  So (a) the phoneme count is bucketed
+    like the frame count: ids are padded with zeros to a multiple of `phoneme_bucket` and `x_lengths` keeps the true
+    length -- exactly a shorter utterance in a padded batch; the Tx-shaped results are returned as views of the first
+    Tx columns -- and (b) both caches are LRU: at most `max_shapes` first-half entries, each holding at most
+    `max_buckets` second-half graphs (a second-half graph reads its first half's buffers, so it lives and dies inside
+    that entry).  An evicted entry drops its graph, buffers and workspace."""
+
+    def __init__(self, model: SynthesizerTrn, frame_bucket=32, phoneme_bucket=16, max_shapes=8, max_buckets=8):
+        import collections
         if model._handle is None:
             raise RuntimeError("model must have weights loaded and live on a HIP device")
         self.model = model
         self.frame_bucket = int(frame_bucket)
-        self._pre = {}
-        self._post = {}
+        self.phoneme_bucket = max(1, int(phoneme_bucket))
+        self.max_shapes, self.max_buckets = max(1, int(max_shapes)), max(1, int(max_buckets))
+        self._pre = collections.OrderedDict()  # key -> {"pb", "graph", "post": OrderedDict(key2 -> {"qb", "graph"})}
+        self.captures = 0  # graphs captured so far (a replay does not count): what a cache-efficiency test reads
+
+    @staticmethod
+    def _lru_get(cache, key):
+        e = cache.get(key)
+        if e is not None:
+            cache.move_to_end(key)
+        return e
+
+    @staticmethod
+    def _lru_put(cache, key, e, cap):
+        cache[key] = e
+        while len(cache) > cap:
+            cache.popitem(last=False)  # least recently used: its graph, buffers and workspace go with it
+        return e
 
     def _capture(self, launch):
         launch()  # un-captured first: one-time initialisation must not land in the capture
@@ -160,6 +186,7 @@ class GraphedEncoder:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             launch()
+        self.captures += 1
         return graph
 
     def encode(self, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w):
@@ -168,31 +195,45 @@ class GraphedEncoder:
         from . import _lib
         m = self.model
         lib = _lib.load()
-        B, Tx = x.shape
+        import collections
+        B, Tx_in = x.shape
         I = m.inter_channels
+        pbk = self.phoneme_bucket
+        Tx = max(pbk, -(-int(Tx_in) // pbk) * pbk)  # padded phoneme count: positions >= x_lengths[b] are masked
         key = (int(B), int(Tx), float(length_scale), float(noise_scale_w))
-        e = self._pre.get(key)
+        e = self._lru_get(self._pre, key)
         if e is None:
             pb = m._pre_buffers(B, Tx, own=True)
-            e = self._pre[key] = {"pb": pb}
+            e = {"pb": pb, "post": collections.OrderedDict()}
             e["graph"] = self._capture(lambda: m._launch_pre(lib, pb, length_scale, noise_scale_w))
+            self._lru_put(self._pre, key, e, self.max_shapes)
         pb = e["pb"]
-        pb["x"].copy_(x)
+        if Tx == Tx_in:
+            pb["x"].copy_(x)
+        else:
+            pb["x"].zero_()
+            pb["x"][:, :Tx_in].copy_(x)
         pb["x_lengths"].copy_(x_lengths)
         if m.n_speakers > 0:
             pb["sid"].copy_(sid)
         if m.use_sdp:
-            m._randn_into(pb["eps_w"])
+            # randn(B, 2, Tx) of duration_predictors.py:257 is drawn contiguously at the TRUE phoneme count, as the
+            # plain path draws it (same stream positions), and placed in the first columns of the bucketed buffer
+            if Tx == Tx_in:
+                m._randn_into(pb["eps_w"])
+            else:
+                pb["eps_w"][:, :, :Tx_in].copy_(m._randn(B, 2, Tx_in))
         e["graph"].replay()
         y_host, Ty = m._read_lengths(pb)
         fb = self.frame_bucket
         Tyb = max(fb, -(-Ty // fb) * fb)
-        key2 = key + (Tyb, float(noise_scale))  # (the second graph reads the first one's buffers: same entry)
-        e2 = self._post.get(key2)
+        key2 = (Tyb, float(noise_scale))  # (the second graph reads the first one's buffers: it lives inside that entry)
+        e2 = self._lru_get(e["post"], key2)
         if e2 is None:
             qb = m._post_buffers(B, Tx, Tyb, own=True)
-            e2 = self._post[key2] = {"qb": qb}
+            e2 = {"qb": qb}
             e2["graph"] = self._capture(lambda: m._launch_post(lib, pb, qb, noise_scale))
+            self._lru_put(e["post"], key2, e2, self.max_buckets)
         qb = e2["qb"]
         # randn_like(m_p) of models.py:267 is [B, I, Ty]: drawn contiguously, as the plain path draws it, and placed
         # in the first Ty frames of the bucketed buffer (the rest is multiplied by mask 0)
@@ -203,7 +244,14 @@ class GraphedEncoder:
         e2["graph"].replay()
         view = {k: (qb[k][:, :Ty] if k in ("f2p", "y_mask", "attn") else qb[k][:, :, :Ty])
                 for k in ("f2p", "y_mask", "attn", "m_p", "logs_p", "z_p", "z")}
+        view["attn"] = view["attn"][:, :, :Tx_in]
         st = m._stage_dict(pb, dict(view, B=B, Tx=Tx, Ty=Ty), y_host, Ty)
+        if Tx != Tx_in:  # the Tx-shaped stage tensors: views of the true phoneme count
+            for k in ("x_enc", "stats"):
+                st[k] = st[k][:, :, :Tx_in]
+            for k in ("x_mask", "logw", "w_ceil"):
+                st[k] = st[k][:, :Tx_in]
+            st["Tx"] = int(Tx_in)
         return st
 
 
@@ -280,8 +328,9 @@ class DecoderSession(_SessionBase):
 
     def run(self, output_names, feeds, run_options=None):
         self._check(output_names)
-        z = self._dev(feeds["z"], torch.float32)
-        sid = self._dev(feeds["sid"], torch.int64)
+        # (read by the decoder, which runs on the caller's stream in either mode -- not the encoder's side stream)
+        z = self._dev(feeds["z"], torch.float32, consumer="decoder")
+        sid = self._dev(feeds["sid"], torch.int64, consumer="decoder")
         if self._graphed is not None and z.shape[1] > 0:
             g = self.model._speaker(sid, z.shape[0])
             return [self._graphed(z.transpose(1, 2), g).cpu().numpy()]
@@ -334,29 +383,33 @@ def get_chunks_min(mel_len, block_size, pad_size, min_chunk=TRITON_MIN_CHUNK):
     return wins, pad_end
 
 
-def depad_bounds_min(chunk_num, chunk_id, block, pad, upsample, n_samples, pad_end):
+def depad_bounds_min(chunk_num, chunk_id, block, pad, upsample, n_samples, pad_end, strict_reference=False):
     """Sample range to keep of a window decoded under the min-chunk protocol (depadding,
     stream_tts/1/model.py:89-111): as depad_bounds, except that the last window drops `pad_end * upsample`
     samples at its end.  Two behaviours of the reference are NOT reproduced, because they are crashes, not
     results: a last window that needed no padding (pad_end None) with chunk_num > 1 raises TypeError there
     (`-pad_end * upsample`, :105) -- here the window's tail is kept, as the two other streaming clients do; a
     single window (chunk_id 0 is also the last) keeps `block * upsample` samples there, which includes audio
-    decoded from reflected frames when L < block -- here it is clipped to the samples of real frames."""
+    decoded from reflected frames when L < block -- here it is clipped to the samples of real frames, unless
+    `strict_reference` asks for the reference client's stream sample for sample (min(block, MIN_CHUNK) * upsample
+    samples for a single short window: the tail is the vocoder's rendering of mirrored frames, not speech)."""
     front = min(chunk_id * block, pad)
     real = n_samples - (pad_end or 0) * upsample  # samples decoded from real (not reflected) frames
     if chunk_id == 0:
-        return 0, min(real, block * upsample)
+        return 0, min(n_samples if (strict_reference and chunk_num == 1) else real, block * upsample)
     if chunk_id == chunk_num - 1:
         return front * upsample, real
     return front * upsample, (front + block) * upsample
 
 
-def stream_decode(decoder, z, sid, chunk_size=40, pad_size=10, min_chunk=None):
+def stream_decode(decoder, z, sid, chunk_size=40, pad_size=10, min_chunk=None, strict_reference=False):
     """Decodes z [1,L,C] window by window with overlap-discard; yields float32 audio pieces
     (numpy) whose concatenation has L*hop samples.  `decoder` is a DecoderSession.
 
     `min_chunk` (e.g. TRITON_MIN_CHUNK with chunk_size=TRITON_BLOCK_SIZE, pad_size=TRITON_PAD_SIZE) selects the
-    Triton twin's protocol: a short last window is reflect-padded to min_chunk frames before it is decoded."""
+    Triton twin's protocol: a short last window is reflect-padded to min_chunk frames before it is decoded.
+    `strict_reference` (min-chunk protocol only): an utterance shorter than min_chunk yields the reference client's
+    min(chunk_size, min_chunk) * hop samples -- its audio of the mirrored frames included -- instead of L * hop."""
     hop = decoder.model.hop_length
     if min_chunk is None:
         wins, pad_end = get_chunks(z.shape[1], chunk_size, pad_size), None
@@ -371,5 +424,5 @@ def stream_decode(decoder, z, sid, chunk_size=40, pad_size=10, min_chunk=None):
         if min_chunk is None:
             a, b = depad_bounds(len(wins), i, chunk_size, pad_size, hop, out.shape[1])
         else:
-            a, b = depad_bounds_min(len(wins), i, chunk_size, pad_size, hop, out.shape[1], last_pad)
+            a, b = depad_bounds_min(len(wins), i, chunk_size, pad_size, hop, out.shape[1], last_pad, strict_reference)
         yield out[0, a:b]

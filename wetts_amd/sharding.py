@@ -230,9 +230,13 @@ def shard_utterances(lengths, world_size):
     loads = [0] * world_size
     counts = [0] * world_size
     shards = [[] for _ in range(world_size)]
-    cap = -(-len(lengths) // world_size)  # keep batch counts equal (weak scaling: B/rank fixed)
+    # keep batch counts equal (weak scaling: B/rank fixed): n = q * world + rem, so `rem` ranks take q + 1 utterances and
+    # the others q -- a rank may only take its (q + 1)-th while fewer than `rem` ranks have one (a plain cap of
+    # ceil(n / world) let two ranks fill up and left the third two short: 15 / 15 / 13 for 43 over 3)
+    q, rem = divmod(len(lengths), world_size)
     for i in order:
-        cands = [r for r in range(world_size) if counts[r] < cap]
+        full = sum(1 for r in range(world_size) if counts[r] > q)
+        cands = [r for r in range(world_size) if counts[r] < q or (counts[r] == q and full < rem)]
         r = min(cands, key=lambda q: (loads[q], q))
         shards[r].append(i)
         loads[r] += int(lengths[i])
