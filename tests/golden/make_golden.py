@@ -75,6 +75,10 @@ BIG_CASES = {
     # BASELINE.json configs[4] (SURVEY 8d "cfg 5": hop 512 = [8,8,4,2] / [16,16,8,4], 48 kHz): the f32 generator of
     # the stress config against the live reference (the 16-bit modes are held against this f32 path)
     "stress48k_b2": ("stress48k", 256, 1, 2, 48, [48, 31], 38, 308, (0.667, 1.0, 0.8)),
+    # BASELINE.json configs[1] AT ITS BENCHED BATCH: 16 x 128 phonemes, all full length (bench.py's shape), through the
+    # live reference.  12.6 MB of audio + 9.5 MB of z would not be a small fixture, so the fixture keeps every 16th
+    # audio sample and every 8th frame of z (10th / 11th field: strides) beside the full logw / y_mask / bit-packed attn
+    "v1_b16x128": ("v1", 256, 1, 16, 128, [128] * 16, 39, 310, (0.667, 0.92, 0.8), None, (16, 8)),
 }
 ONLY = os.environ.get("WETTS_GOLDEN_ONLY")  # comma-separated case names (default: all)
 
@@ -139,8 +143,9 @@ def run_big_cases():
         x = torch.randint(0, n_vocab, (B, Tx), generator=gi)
         x_len = torch.tensor(lens, dtype=torch.long)
         sid = torch.randint(0, n_spk, (B,), generator=gi)
-        if len(spec) > 9:  # explicit speaker ids
+        if len(spec) > 9 and spec[9] is not None:  # explicit speaker ids
             sid = torch.tensor(spec[9], dtype=torch.long)
+        strides = spec[10] if len(spec) > 10 else None  # (audio stride, z frame stride) of a sub-sampled fixture
         ns, ls, nsw = scales
         real_randn, real_randn_like = torch.randn, torch.randn_like
 
@@ -167,16 +172,24 @@ def run_big_cases():
         frac = (torch.ceil(w) - w)[x_mask > 0]
         margin = float(torch.minimum(frac, 1 - frac).min())
         Ty = z.shape[2]
+        full = dict(z=z.numpy(), audio=o.numpy())
+        if strides:  # sub-sampled fixture: strided views + the full tensors' shapes and float64 sums
+            sa, sz = strides
+            full = dict(audio_sub=o.numpy()[..., ::sa].copy(), z_sub=z.numpy()[..., ::sz].copy(),
+                        sub_strides=np.array([sa, sz]), audio_shape=np.array(o.shape), z_shape=np.array(z.shape),
+                        audio_sum=float(o.double().sum()), audio_sqsum=float(o.double().pow(2).sum()))
         np.savez_compressed(
             os.path.join(OUT, name + ".npz"),
             model=mname, n_vocab=n_vocab, n_speakers=n_spk, weight_seed=wseed, noise_seed=nseed,
             noise="randomstate", scales=np.array(scales, np.float64),
             blob_checksum=synth.blob_checksum(blob),
-            x=x.numpy(), x_lengths=x_len.numpy(), sid=sid.numpy(),
-            x_enc=xe.numpy(), m_p=m_p.numpy(), logs_p=logs_p.numpy(), x_mask=x_mask.numpy(),
+            x=x.numpy(), x_lengths=x_len.numpy(), sid=sid.numpy(), x_mask=x_mask.numpy(),
+            # (the encoder's stage boundaries are pinned at this phoneme count by v1_b4x128; a sub-sampled fixture
+            # leaves them out to stay small)
+            **({} if strides else dict(x_enc=xe.numpy(), m_p=m_p.numpy(), logs_p=logs_p.numpy())),
             logw=logw.numpy(), ceil_margin=margin,
             attn_bits=np.packbits(attn.numpy().astype(np.uint8), axis=-1),
-            attn_shape=np.array(attn.shape), y_mask=y_mask.numpy(), z=z.numpy(), audio=o.numpy())
+            attn_shape=np.array(attn.shape), y_mask=y_mask.numpy(), **full)
         print(f"{name}: Ty={Ty} audio={tuple(o.shape)} rms={float(o.pow(2).mean().sqrt()):.4f} "
               f"ceil_margin={margin:.2e} frames/phone={float(y_mask.sum() / x_mask.sum()):.2f}")
 

@@ -11,10 +11,11 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def _net(mname, n_vocab, n_spk, seed=0):
+def _net(mname, n_vocab, n_spk, seed=0, sd=None):
     from wetts_amd import SynthesizerTrn, config, synth
     net = SynthesizerTrn(n_vocab, 513, 32, n_speakers=n_spk, **config.MODEL_CONFIGS[mname])
-    sd = synth.make_state_dict(net.cfg, seed)
+    if sd is None:
+        sd = synth.make_state_dict(net.cfg, seed)
     net.load_state_dict(sd).to("cuda")
     return net, sd
 
@@ -80,6 +81,37 @@ def test_v1_b16x128_properties_and_oracle_spot_check():
     # per row, including the padded tail each utterance sees behind its last frame
     for i in range(4):
         assert util.rms(o[sub[i]].cpu().numpy() - ref["o"][i].numpy()) < 1e-4
+
+
+def test_v1_b16x128_matches_the_reference_at_the_benched_batch():
+    """BASELINE.json configs[1] AT THE BATCH bench.py RUNS -- 16 x 128 phonemes, all full length, length_scale 0.92 --
+    against the live reference's own infer() (tests/golden/v1_b16x128.npz; the fixture keeps every 16th audio sample and
+    every 8th frame of z beside the full durations, mask and alignment): durations to 1e-4, y_mask / alignment EQUAL,
+    z and audio on the sub-sampled grid within the 1e-4 abs-RMS gate, and the full audio's sum / energy."""
+    case = util.load_case("v1_b16x128")
+    cfg, sd, W, _ = util.case_model(case)
+    net, _ = _net("v1", int(case["n_vocab"]), int(case["n_speakers"]), sd=sd)
+    ns, ls, nsw = [float(v) for v in case["scales"]]
+    o, attn, ym, (z, z_p, m_p, logs_p) = net.infer(
+        util.t(case["x"]).cuda(), util.t(case["x_lengths"]).cuda(), sid=util.t(case["sid"]).cuda(), noise_scale=ns,
+        length_scale=ls, noise_scale_w=nsw, eps_w=util.t(case["eps_w"]).cuda(), eps_z=util.t(case["eps_z"]).cuda())
+    st = net._last
+    sa, sz = (int(v) for v in case["sub_strides"])
+    logw_err = float(np.abs(st["logw"].cpu().numpy() - case["logw"][:, 0]).max())
+    w_err = float(np.abs(np.exp(st["logw"].cpu().numpy()) - np.exp(case["logw"][:, 0])).max()) * ls
+    assert logw_err < 1e-4 and 10 * w_err < float(case["ceil_margin"]), (logw_err, w_err, float(case["ceil_margin"]))
+    assert tuple(o.shape) == tuple(case["audio_shape"]) and tuple(z.shape) == tuple(case["z_shape"])
+    assert np.array_equal(ym.cpu().numpy(), case["y_mask"])
+    assert np.array_equal(attn.cpu().numpy().astype(np.uint8), case["attn"])
+    on = o.cpu().numpy()
+    e_z = util.rel_rms(z.cpu().numpy()[..., ::sz], case["z_sub"])
+    e_a = util.rms(on[..., ::sa] - case["audio_sub"])
+    rel_a = util.rel_rms(on[..., ::sa], case["audio_sub"])
+    e_sum = abs(float(on.astype(np.float64).sum()) - float(case["audio_sum"])) / on.size
+    e_sq = abs(float((on.astype(np.float64) ** 2).sum()) / float(case["audio_sqsum"]) - 1.0)
+    print("v1 B=16x128 vs the reference golden: logw max", logw_err, "z rel rms", e_z, "audio abs rms", e_a, "rel", rel_a,
+          "mean err", e_sum, "energy rel err", e_sq)
+    assert e_z < 2e-4 and e_a < 1e-4 and rel_a < 2e-3 and e_sum < 1e-6 and e_sq < 1e-4
 
 
 def test_v3_b64_speaker_path_and_ragged_b64():

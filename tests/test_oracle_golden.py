@@ -37,6 +37,26 @@ def test_infer_matches_reference(name):
     assert util.rel_rms(st["o"].numpy(), case["audio"]) < 2e-4
 
 
+def test_infer_matches_reference_at_the_benched_batch():
+    """configs[1] at 16 x 128 phonemes (the sub-sampled fixture v1_b16x128): the oracle against the live reference's
+    durations, alignment and the strided z / audio views (~20 s of CPU)."""
+    case = util.load_case("v1_b16x128")
+    cfg, _, W, _ = util.case_model(case)
+    ns, ls, nsw = [float(v) for v in case["scales"]]
+    torch.set_num_threads(8)
+    st = vo.infer(W, util.cfg_dict(cfg), util.t(case["x"]), util.t(case["x_lengths"]), util.t(case["sid"]),
+                  noise_scale=ns, length_scale=ls, noise_scale_w=nsw, eps_w=util.t(case["eps_w"]),
+                  eps_z=util.t(case["eps_z"]), return_stages=True)
+    sa, sz = (int(v) for v in case["sub_strides"])
+    w_err = float(np.abs(np.exp(st["logw"].numpy()) - np.exp(case["logw"])).max()) * ls
+    assert float(case["ceil_margin"]) > 10 * w_err
+    assert np.array_equal(st["y_mask"].numpy(), case["y_mask"])
+    assert np.array_equal(st["attn"].numpy().astype(np.uint8), case["attn"])
+    assert util.rel_rms(st["z"].numpy()[..., ::sz], case["z_sub"]) < 5e-5
+    assert util.rms(st["o"].numpy()[..., ::sa] - case["audio_sub"]) < 2e-5
+    assert abs(float(st["o"].double().pow(2).sum()) / float(case["audio_sqsum"]) - 1.0) < 1e-5
+
+
 def test_mas_known_answers():
     d = np.load(util.GOLDEN + "/mas_kat.npz")
     for i in range(int(d["n"])):

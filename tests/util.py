@@ -25,6 +25,8 @@ INFER_CASES = ["tiny_sdp_b3", "tiny_dp_b2", "tiny_sdp_nonoise", "tiny_sdp_single
                "stress48k_b2"]  # BASELINE configs[4] generator (hop 512, [8,8,4,2]) at f32 vs the live reference
 # every committed golden is a GPU parity case (round 5): nothing is held against the oracle only
 ORACLE_ONLY_CASES = []
+# sub-sampled full-batch fixtures (make_golden.py: every 16th audio sample, every 8th frame of z): own tests
+STRIDED_CASES = ["v1_b16x128"]  # BASELINE configs[1] at its benched batch, 16 x 128 phonemes
 BIG_CASES = ["v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64", "aishell3_b4x128", "tiny_mono_post_b2x64", "v2_b4x128",
              "stress48k_b2"]
 
@@ -41,7 +43,7 @@ def load_case(name):
     c = {k: d[k] for k in d.files}
     if "noise" in c and str(c["noise"]) == "randomstate":  # compact full-size fixture
         B, Tx = c["x"].shape
-        I, Ty = c["z"].shape[1], c["z"].shape[2]
+        I, Ty = (c["z"].shape[1], c["z"].shape[2]) if "z" in c else (int(c["z_shape"][1]), int(c["z_shape"][2]))
         c["eps_w"] = big_case_noise(c["noise_seed"], (B, 2, Tx), "w")
         c["eps_z"] = big_case_noise(c["noise_seed"], (B, I, Ty), "z")
         shp = tuple(int(v) for v in c["attn_shape"])
