@@ -1,10 +1,13 @@
 #!/bin/bash
-# One GPU-box pass (round 4): parity tests, rocprofv3 kernel stats + HBM counters for every benched line (f32 headline,
+# One GPU-box pass (round 5): parity tests, rocprofv3 kernel stats + HBM counters for every benched line (f32 headline,
 # 16-bit decoder, configs[2], configs[4], Vocos, VITS2 + Vocos, uint8), the bench lines, streaming, MAS.
-# Outputs -> gpurun_out/ ; `python tools/summarize_profiles.py r04` copies the judged summaries into profiles/.
+# Outputs -> gpurun_out/ ; `python tools/summarize_profiles.py r05` copies the judged summaries into profiles/.
 # SKIP_TESTS=1 skips the pytest pass (it is also run by tools/gpu_tests.sh).
 mkdir -p gpurun_out
 R=/root/repo
+# the library this pass measures: the digest of its sources (wetts_amd/build.py), stamped into the PMC summary so that
+# bench.py can say whether the committed traffic figure belongs to the library that runs (roofline.traffic_current)
+cut -c1-16 wetts_amd/lib/build.sha256 > gpurun_out/lib_digest.txt
 if [ -z "$SKIP_TESTS" ]; then
   python -m pytest tests -m gpu -q --timeout 900 -rf -s 2>&1 | grep -v "^\[wetts" > gpurun_out/pytest_gpu_full.log
   tail -40 gpurun_out/pytest_gpu_full.log > gpurun_out/pytest_gpu.log
@@ -29,7 +32,7 @@ prof vocos --model vocos
 prof vits2vocos --model vits2_vocos_v1
 prof uint8 --decoder-dtype uint8
 cd $R
-python tools/summarize_profiles.py r04 > gpurun_out/traffic_summary.txt 2>&1  # bench.py reads profiles/r04_hbm_traffic.json
+python tools/summarize_profiles.py r05 > gpurun_out/traffic_summary.txt 2>&1  # bench.py reads the newest profiles/r*_hbm_traffic.json
 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err
 cut -c1-420 gpurun_out/bench.json
 python bench.py --gpus 2 --steps 2 --warmup 1 > gpurun_out/bench_gpus2_refused.json 2> gpurun_out/bench_gpus2_refused.err; echo "gpus2 exit=$?" | tee -a gpurun_out/bench_gpus2_refused.err

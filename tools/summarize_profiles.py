@@ -10,7 +10,7 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = "gpurun_out"
 import os
 for a, b in [("prof_stats_baker/r_kernel_stats.csv", "kernel_stats.csv"), ("bench.json",) * 2,
@@ -84,6 +84,9 @@ CLASSES = (("dominant_conv_mfma", "baker", is_mrf, None), ("mrf16_baker", "bf16"
            # uint8: bench.py counts one launch per Conv node = its qconv_i8_kernel (the quantise / range kernels'
            # bytes are charged to that node)
            ("mrf_uint8", "uint8", is_u8, "qconv_i8_kernel"))
+# digest of the library sources the passes ran on (tools/gpu_round.sh writes it on the GPU box)
+lib_digest = open(f"{src}/lib_digest.txt").read().strip() if os.path.exists(f"{src}/lib_digest.txt") else None
+out["lib_digest"] = lib_digest
 for key, sub, in_class, count_only in CLASSES:
     f = agg(f"{src}/pmc_fetch_{sub}/r_counter_collection.csv", "FETCH_SIZE")
     w = agg(f"{src}/pmc_write_{sub}/r_counter_collection.csv", "WRITE_SIZE")
@@ -116,6 +119,7 @@ for key, sub, in_class, count_only in CLASSES:
         # rocprofv3 --stats view of the same class (compare with bench.py roofline.avg_launch_ms)
         "rocprof_avg_duration_ms": dom.get("stat_ns", 0.0) / max(1, dom.get("stat_calls", 0)) / 1e6,
         "rocprof_calls": dom.get("stat_calls", 0),
+        "lib_digest": lib_digest,
         "kernels": kernels,
     }
     if not f:
