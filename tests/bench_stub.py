@@ -32,9 +32,10 @@ class StubNet:
 
     def load_blob(self, blob):
         from wetts_amd import checkpoint
-        if os.environ.get("WETTS_STUB_HANG_RANK") == os.environ.get("RANK") and os.environ.get("WETTS_STUB_HANG_AT") == "load":
+        me = os.environ.get("RANK", "0")
+        if os.environ.get("WETTS_STUB_HANG_RANK") == me and os.environ.get("WETTS_STUB_HANG_AT") == "load":
             time.sleep(3600)  # a rank whose GPU hangs after the rendezvous
-        if os.environ.get("WETTS_STUB_CRASH_RANK") == os.environ.get("RANK"):
+        if os.environ.get("WETTS_STUB_CRASH_RANK") == me:
             raise RuntimeError("stub: this rank dies while loading its weights")
         assert blob.dtype == torch.float32 and blob.numel() == checkpoint.blob_numel(self.cfg)
         self.blob_sum = float(blob.double().sum())

@@ -44,7 +44,6 @@ def _other_compiler_is_xfail(request):
 # kernels that are allowed to touch scratch, with a bound in bytes per lane: spills outside their MFMA loops (checked in
 # the ISA when they were admitted), or an indexed local array
 SCRATCH_ALLOWED = {
-    "void wetts::conv_dma_kernel<4, true>": 32,       # gate epilogue of the B >= 64 flow path
     "wetts::spline_inverse_kernel": 128,              # bin tables indexed at run time
 }
 

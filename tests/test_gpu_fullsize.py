@@ -482,8 +482,8 @@ def test_ragged_decode_with_upsample_rates_that_are_not_multiples_of_four():
 
 
 def test_flow_at_b64_matches_oracle_on_sub_batch():
-    """The f32 flow at B = 64 x ~760 frames is where the large-launch kernels run -- conv_dma_kernel (in_layers k = 5 on
-    the LDS-DMA structure with edge-tile zero padding), pw_gemm_kernel strips with residual / mask epilogues -- and the
+    """The f32 flow at B = 64 x ~760 frames is where the large-launch schedules run -- in_layers k = 5 on the 64 x 128 /
+    128 x 128 tiles the mid-size cost model picks at this batch, pw_gemm_kernel strips with residual / mask epilogues -- and the
     frame count is not a multiple of 4 for ragged lengths (rows re-padded on the way in and out).  The flow is masked,
     so a sub-batch is exact: three utterances (first, a short one, last) against oracle.flow_reverse on the device's
     own z_p."""

@@ -49,6 +49,7 @@ python bench.py --stream --model vits2_vocos_v1 --stream-cpu > gpurun_out/stream
 python bench.py --mas > gpurun_out/mas.json 2>/dev/null
 (export TMPDIR=/tmp; timeout 300 rocprofv3 --kernel-trace -d /tmp/b1 -o b1 --output-format csv -- python tools/trace_b1.py --reps 5 > gpurun_out/b1_run.txt 2>&1; python tools/trace_b1.py --summarize /tmp/b1 > gpurun_out/b1_summary.txt 2>&1)
 WETTS_BENCH_B=16 WETTS_XSHAPES=512:1536:1:760,1536:512:1:760,192:384:1:760,192:384:5:760,512:1026:1:760 python tools/bench_conv.py 6,0 > gpurun_out/pw_gemm_microbench.txt 2>&1
+WETTS_BENCH_ITERS=10 python tools/bench_conv.py 0 2>&1 | grep -v amdgpu.ids > gpurun_out/conv_microbench.txt
 for f in gpurun_out/bench_*.json gpurun_out/bench.json; do echo $f; python -c "
 import json,sys
 d=json.load(open('$f')); r=d.get('roofline',{}); print('  ', round(d['value']/1e6,1),'M samples/s', round(d['ms_per_step'],2),'ms', d['dtype'][:30], 'frac', round(r.get('frac') or 0,3), 'mrf_share', round(r.get('mrf_share_of_step',0),3), 'traffic', r.get('traffic'))

@@ -200,11 +200,6 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream);
 // eligible launches there.  variant: 0 = production choice, 7 / 8 / 9 = forced stage shapes (micro-benchmarks)
 bool pw_gemm_eligible(const PackedConv& pc, const ConvParams& p);
 int32_t launch_pw_gemm(const PackedConv& pc, const ConvParams& p, hipStream_t stream, int variant);
-// k-tap convs at dilation 1 with a plain input on the same LDS-DMA structure (stages of 8 channels, zero padding by
-// fixing up the edge tiles in LDS)
-bool conv_dma_eligible(const PackedConv& pc, const ConvParams& p);
-// (*taken = false and nothing launched when the launch is too small for it to pay; taken == null forces it)
-int32_t launch_conv_dma(const PackedConv& pc, const ConvParams& p, hipStream_t stream, bool* taken);
 // n independent convs of one shape class in ONE launch where that is possible (conv_mfma.hip), else n launches
 // (*launches = how many kernels went out)
 int32_t launch_conv_group(const PackedConv* const* pcs, const ConvParams* ps, int n, hipStream_t stream,

@@ -806,11 +806,6 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
     static const int pw_on = [] { const char* e = getenv("WETTS_PW_GEMM"); return e ? atoi(e) : 1; }();  // A/B switch
     const int v = conv_variant();
     if (pw_on && (v == 0 || (v >= 7 && v <= 9)) && pw_gemm_eligible(pc, p)) return launch_pw_gemm(pc, p, stream, v);
-    if (pw_on && (v == 0 || v == 10) && conv_dma_eligible(pc, p)) {
-      bool taken = true;
-      WETTS_TRY(launch_conv_dma(pc, p, stream, v == 10 ? nullptr : &taken));
-      if (taken) return WETTS_OK;
-    }
   }
   // tile selection: fill the chip first, then maximise per-wave register reuse
   const int64_t cols = (int64_t)p.N * p.B;
@@ -830,7 +825,25 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
   auto nblk = [&](int mt, int nt) { return (int64_t)cdiv(p.M, mt) * cdiv(p.N, nt) * p.B; };
   constexpr int64_t kFill = 384;
   if (p.M >= 128 && cols >= 4096) {
-    if (nblk(128, 128) >= kFill) return launch_cfg<1, 4, 4, 1>(p, stream);
+    // Grids of many rounds (the MRF shapes: >= 1500 blocks of 128 x 128): the big tile.  Mid-size grids -- the flow's
+    // in_layers, the encoders' FFN convs, conv_pre: a few hundred big tiles on 256 CUs -- by a cost model fitted to
+    // tools/bench_conv.py at B = 16 and B = 64 (profiles/r04_inlayer_tiles.txt, r05_ffn_tiles_b64.txt): rounds of blocks
+    // per CU x tile area / relative tile efficiency (64 x 64: 1, 64 x 128: 1.07, 128 x 128: 1.18).  It reproduces the
+    // measured order in every case -- B = 16 in_layers: 64 x 64 (96 vs 77 / 71 TF/s); B = 64 FFN 192 -> 768 over 128
+    // columns per item: 64 x 128 (101 vs 84 on the big tile, 95 on 64 x 64); B = 64 in_layers: 64 x 128 / 128 x 128 (125 /
+    // 124 vs 117) -- where the old rule (big tile from 384 blocks up) left 17-21 % on the table at B = 64.
+    const int64_t n128 = nblk(128, 128);
+    constexpr int kCUs = 256;
+    if (n128 >= 4 * kCUs) return launch_cfg<1, 4, 4, 1>(p, stream);
+    // (a grid of fewer blocks than CUs leaves CUs idle and one wave per SIMD: never a candidate while another shape fills the
+    // chip -- the FFN's 768 -> 192 at B = 64 is 192 tiles of 64 x 128: 67 TF/s against 70 on 384 tiles of 64 x 64)
+    auto cost = [&](int64_t blocks, int area, double eff) {
+      return (blocks < kCUs ? 4.0 : 1.0) * (double)((blocks + kCUs - 1) / kCUs) * area / eff;
+    };
+    const double c128 = cost(n128, 128 * 128, 1.18), c64w = cost(nblk(64, 128), 64 * 128, 1.07),
+                 c64 = cost(nblk(64, 64), 64 * 64, 1.0);
+    if (c128 <= c64w && c128 <= c64) return launch_cfg<1, 4, 4, 1>(p, stream);
+    if (c64w <= c64) return launch_cfg<1, 2, 2, 2>(p, stream);
     return launch_cfg<1, 1, 2, 2>(p, stream);
   }
   if (p.M > 32 && cols >= 8192) {

@@ -53,7 +53,6 @@ struct PwParams {
   int64_t out_mask_stride;
   int out_act;
   int B, S, upb, U, mtiles;
-  int ktaps, pad, Tin;  // k-tap convs (conv_dma_kernel): taps at dilation 1, "same" padding, valid input length
   // WaveNet residual / skip update instead of a store (modules.py:79-86; ConvParams.wn_*): rows < wn_H (not on the last
   // layer) -> h = (h + v) * mask, the others -> skip (+)= v.  h, skip: contiguous [B][wn_H][N].  wn_H % 32 == 0.
   float* wn_h;
@@ -120,7 +119,7 @@ struct PwLds {
 
 // acc + bias (+ per-utterance bias) -> activation -> output mask -> store; buffer addressing (one lane offset per
 // 32-column unit + a uniform row offset), bias rows by scalar loads
-template <int NBP, bool GATE = false>
+template <int NBP>
 __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[NBP], int b, int rowu, int colj0, int half) {
   // ---- epilogue -------------------------------------------------------------------------------------------------
   // bias: rows rowu + rr (+ 4 for the upper half-wave) are uniform addresses -> scalar loads, one select per row
@@ -135,30 +134,6 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[NBP
     om[j] = (io.mask && col < p.N) ? io.mask[col] : 1.f;
   }
   const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
-  if (GATE) {
-    // WaveNet gate (OUT_GATE, common.h): packed rows (2i, 2i + 1) = (tanh row i, sigmoid row H + i) sit in registers
-    // (r, r + 1) of one lane; output row i of the H-row tensor.  M = 2 H is a multiple of 128 here (conv_dma launch).
-    const int gH = p.M >> 1;
-#pragma unroll
-    for (int j = 0; j < NBP; ++j) voff[j] = (2 * half * io.o_cs + colj0 + 32 * j) * 4;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      const int rr = (r & 3) + 8 * (r >> 2);  // even
-      const int ilo = (rowu + rr) >> 1, ihi = ilo + 2;  // uniform output rows of the two half-waves
-      float t0 = 0.f, t1 = 0.f, s0 = 0.f, s1 = 0.f;
-      if (p.bias) { t0 = p.bias[ilo]; t1 = p.bias[ihi]; s0 = p.bias[gH + ilo]; s1 = p.bias[gH + ihi]; }
-      if (bb) { t0 += bb[ilo]; t1 += bb[ihi]; s0 += bb[gH + ilo]; s1 += bb[gH + ihi]; }
-      const float tb = half ? t1 : t0, sb = half ? s1 : s0;
-      const int soff = __builtin_amdgcn_readfirstlane(ilo * io.o_cs * 4);
-#pragma unroll
-      for (int j = 0; j < NBP; ++j) {
-        if (colj0 + 32 * j >= p.N) continue;
-        const float v = wn_gate(acc[j][r] + tb, acc[j][r + 1] + sb);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rso, voff[j], soff, 0);
-      }
-    }
-    return;
-  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int rr = (r & 3) + 8 * (r >> 2);
@@ -323,138 +298,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
-// ---- k-tap convs (dilation 1, "same" padding, plain input): the flow's in_layers, the encoders' FFN convs ----------
-// Same structure with a stage of 8 input channels: the B tile of a stage is [8 rows][32 * NBP + k - 1 (+ alignment)]
-// columns starting at the 16-byte boundary at or below column n0 - pad (`sh` shifts the B reads to match), shared by
-// all taps (tap t reads it t columns to the right); the A tile of a wave is the stage's k groups of the packed
-// weights (group = (chunk, tap, channel half): one 1 KiB DMA each).  Zero padding: the DMA cannot predicate columns, so
-// tiles that touch a row's ends overwrite the out-of-range columns of the landed stage with zeros (one extra barrier
-// per stage, edge tiles only).
-constexpr int kTapMaxPieces = 36;  // 16-byte pieces per B row: (128 + 6 + 3 + 3) / 4 rounded up
-template <int NBMAX>
-struct TapLds {
-  static constexpr int kRowsB = 8;
-  static constexpr int kB = kRowsB * (NBMAX == 4 ? kTapMaxPieces : NBMAX == 2 ? 20 : 12) * 4 + 256;  // + one DMA of slack
-  static size_t bytes(int ktaps) { return (size_t)2 * (kB + 4 * ktaps * 256) * sizeof(float); }
-};
-
-template <int NBMAX, int NBP, bool GATE>
-__device__ __forceinline__ void tap_pass(const PwParams& p, float* smem, int b, int mtile, int n0, int lane, int wave,
-                                         __amdgpu_buffer_rsrc_t rsx, __amdgpu_buffer_rsrc_t rsw) {
-  using L = TapLds<NBMAX>;
-  const int half = lane >> 5;
-  const int kt = p.ktaps;
-  const int kbuf = L::kB + 4 * kt * 256;  // floats per buffer
-  const int nstages = p.K / 8;
-  const int tstart = (n0 - p.pad) & ~3;   // first staged time (may be negative)
-  const int sh = (n0 - p.pad) & 3;
-  const int PPR = (32 * NBP + kt - 1 + sh + 3) >> 2;  // pieces per row
-  const int RS = PPR * 4;
-  const int TI = (8 * PPR + 63) >> 6;      // B instructions per stage (whole block), <= 5
-  // lane offsets of this wave's (at most two) B instructions; out-of-range columns read the row's first / last piece
-  int vB[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int P = (wave + 4 * q) * 64 + lane;
-    const int row = min(P / PPR, 7), piece = P % PPR;
-    int col = tstart + piece * 4;
-    col = max(0, min(col, p.x_cs - 4));
-    vB[q] = (row * p.x_cs + col) * 4;
-  }
-  const int vA = lane * 16;
-  const int mt32 = mtile * 4 + wave;
-  const int sA0 = __builtin_amdgcn_readfirstlane(mt32 * p.G * 1024);
-  auto issue = [&](int st, float* buf) {
-    const int soffB = __builtin_amdgcn_readfirstlane(st * 8 * p.x_cs * 4);
-    if (wave < TI)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(buf + wave * 256), 16, vB[0],
-                                               soffB, 0, 0);
-    if (wave + 4 < TI)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(buf + (wave + 4) * 256), 16,
-                                               vB[1], soffB, 0, 0);
-    // A: groups (chunk = st / 2, tap, channel half = st & 1) of this wave's 32 rows
-    float* abuf = buf + L::kB + wave * (kt * 256);
-    const int g0 = (st >> 1) * (kt * 2) + (st & 1);
-    for (int t = 0; t < kt; ++t) {
-      const int soff = __builtin_amdgcn_readfirstlane(sA0 + (g0 + 2 * t) * 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(abuf + t * 256), 16, vA, soff, 0,
-                                               0);
-    }
-  };
-  issue(0, smem);
-
-  f32x16 acc[NBP];
-  const int rowu = mtile * 128 + wave * 32;
-  const int colj0 = n0 + (lane & 31);
-  pw_acc_init<NBP>(p, acc, b, rowu, colj0, half);
-
-  // zero padding of "same" convs: staged times < 0 or >= Tin (uniform per block)
-  const bool edge = tstart < 0 || tstart + RS > p.Tin;
-  for (int st = 0; st < nstages; ++st) {
-    float* cur = smem + (st & 1) * kbuf;
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    __syncthreads();
-    if (st + 1 < nstages) issue(st + 1, smem + ((st + 1) & 1) * kbuf);
-    if (edge) {
-      for (int idx = threadIdx.x; idx < 8 * RS; idx += 256) {
-        const int q = idx % RS, t = tstart + q;
-        if (t < 0 || t >= p.Tin) cur[idx] = 0.f;
-      }
-      __syncthreads();
-    }
-    const float* Bb = cur + half * RS + sh + (lane & 31);
-    const float* Ab = cur + L::kB + wave * (kt * 256) + lane * 4;
-    for (int t = 0; t < kt; ++t) {
-      const f32x4v a = *reinterpret_cast<const f32x4v*>(Ab + t * 256);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float bv[NBP];
-#pragma unroll
-        for (int j = 0; j < NBP; ++j) bv[j] = Bb[(s * 2) * RS + t + 32 * j];
-        const float av = s == 0 ? a.x : s == 1 ? a.y : s == 2 ? a.z : a.w;
-#pragma unroll
-        for (int j = 0; j < NBP; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[j], 0, 0, 0);
-      }
-    }
-  }
-  __syncthreads();
-  pw_epilogue<NBP, GATE>(p, acc, b, rowu, colj0, half);
-}
-
-template <int NBMAX, bool GATE = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void conv_dma_kernel(const PwParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bid = blockIdx.x;
-  const int total = gridDim.x;
-  if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
-  const int part = bid % p.S;
-  bid /= p.S;
-  const int mtile = bid % p.mtiles;
-  const int b = __builtin_amdgcn_readfirstlane(bid / p.mtiles);
-  __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.x + (int64_t)b * p.x_bs), 0, __builtin_amdgcn_readfirstlane(p.K * p.x_cs * 4), kPwRsrcDword3);
-  __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (int)p.wpk_bytes,
-                                                                 kPwRsrcDword3);
-  int u = part * p.upb;
-  const int u1 = min(u + p.upb, p.U);
-  while (u < u1) {
-    const int w = u1 - u;
-    if (NBMAX >= 4 && w >= 4) {
-      tap_pass<NBMAX, (NBMAX >= 4 ? 4 : NBMAX), GATE>(p, smem, b, mtile, u * 32, lane, wave, rsx, rsw);
-      u += 4;
-    } else if (NBMAX >= 2 && w >= 2) {
-      tap_pass<NBMAX, (NBMAX >= 2 ? 2 : NBMAX), GATE>(p, smem, b, mtile, u * 32, lane, wave, rsx, rsw);
-      u += 2;
-    } else {
-      tap_pass<NBMAX, 1, GATE>(p, smem, b, mtile, u * 32, lane, wave, rsx, rsw);
-      u += 1;
-    }
-  }
-}
-
 // ---- host side --------------------------------------------------------------------------------------------------
 static int g_cus = 0;
 static int device_cus() {
@@ -483,22 +326,6 @@ bool pw_gemm_eligible(const PackedConv& pc, const ConvParams& p) {
   if (p.Tin > p.x_cs || p.x_cs < 4 || p.Tout != p.Tin) return false;
   if ((int64_t)pc.nchunks * 16 * p.x_cs * 4 >= (1ll << 31)) return false;
   if (p.k_rows_padded && p.x_bs < (int64_t)pc.nchunks * 16 * p.x_cs) return false;
-  return true;
-}
-
-bool conv_dma_eligible(const PackedConv& pc, const ConvParams& p) {
-  if (pc.up != 0 || pc.dil != 1 || pc.ktaps < 3 || pc.ktaps > 7 || (pc.ktaps & 1) == 0 || pc.pad != (pc.ktaps - 1) / 2)
-    return false;
-  if (p.in_act != IN_NONE || p.in_mask != nullptr || p.in_rev_base >= 0 || p.lens != nullptr) return false;
-  if (p.accum || p.out_div != 1.f || p.wn_skip != nullptr) return false;
-  if (p.res && (p.out_act != OUT_NONE || p.out_mask)) return false;
-  if (p.res && (pc.M % 128) != 0) return false;
-  if (p.out_act == OUT_GATE && (pc.M % 128) != 0) return false;  // whole wave blocks: no row predicates in the gate store
-  if ((pc.Cin % 16) != 0 || pc.Cin < 32) return false;
-  if ((p.x_cs & 3) != 0 || (p.x_bs & 3) != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0) return false;
-  if (p.Tin > p.x_cs || p.x_cs < 4 || p.Tout != p.Tin || p.Tin < 8) return false;
-  if ((int64_t)pc.Cin * p.x_cs * 4 >= (1ll << 31)) return false;
-  if ((int64_t)pc.M * p.o_cs * 4 >= (1ll << 31) || (p.res && (int64_t)pc.M * p.r_cs * 4 >= (1ll << 31))) return false;
   return true;
 }
 
@@ -544,65 +371,6 @@ static int32_t launch_pw(const PwParams& p, int64_t blocks, hipStream_t stream, 
     hipLaunchKernelGGL((pw_gemm_kernel<CKS, NBMAX, true>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
   else
     hipLaunchKernelGGL((pw_gemm_kernel<CKS, NBMAX>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
-  WETTS_LAUNCH_CHECK();
-  return WETTS_OK;
-}
-
-int32_t launch_conv_dma(const PackedConv& pc, const ConvParams& cp, hipStream_t stream, bool* taken) {
-  PwParams p;
-  memset(&p, 0, sizeof(p));
-  p.x = cp.x;
-  p.x_bs = cp.x_bs;
-  p.x_cs = (int)cp.x_cs;
-  p.K = pc.Cin;
-  p.N = cp.Tout;
-  p.Tin = cp.Tin;
-  p.ktaps = pc.ktaps;
-  p.pad = pc.pad;
-  p.wpk = pc.wpk;
-  p.G = pc.nchunks * pc.ktaps * 2;
-  p.mtiles = cdiv(pc.M, 128);
-  p.wpk_bytes = (int64_t)p.mtiles * 4 * p.G * 1024;
-  p.bias = pc.bias;
-  p.bias_b = cp.bias_b;
-  p.bias_b_stride = cp.bias_b_stride;
-  p.M = pc.M;
-  p.out = cp.out;
-  p.o_bs = cp.o_bs;
-  p.o_cs = (int)cp.o_cs;
-  p.res = cp.res;
-  p.r_bs = cp.r_bs;
-  p.r_cs = (int)cp.r_cs;
-  p.out_mask = cp.out_mask;
-  p.out_mask_stride = cp.out_mask_stride;
-  p.out_act = cp.out_act;
-  p.B = cp.B;
-  p.U = cdiv(p.N, 32);
-  if (p.B <= 0 || p.N <= 0 || p.M <= 0) return WETTS_OK;
-  WETTS_REQUIRE(p.wpk_bytes < (1ll << 31), "conv_dma: packed weight too large");
-  const int strips = p.B * p.mtiles;
-  const size_t lds = TapLds<4>::bytes(p.ktaps);
-  const int slots = (int)((160 * 1024) / lds) < 4 ? (int)((160 * 1024) / lds) : 4;
-  pw_schedule(strips, p.U, p.K * p.ktaps, slots, &p.S, &p.upb);
-  const int64_t blocks = (int64_t)strips * p.S;
-  WETTS_REQUIRE(blocks < (1ll << 31), "conv_dma grid too large");
-  // Measured (tools/bench_conv.py, 192 -> 384 k = 5 and the FFN shapes): this kernel wins where a block gets at least
-  // three 32-column units and the grid two blocks per CU (B = 64 x 760 columns: 115 vs 98 TF/s); below that a stage is
-  // too few MFMAs per barrier and the 64x64 tiles of conv_mfma_kernel are faster (B = 16: 63 vs 78 TF/s)
-  if (taken) *taken = p.upb >= 3 && blocks >= 2 * device_cus() && (pc.M % 128) == 0;
-  if (taken && !*taken) return WETTS_OK;
-  static signed char opt_in[64] = {}, opt_in_gate[64] = {};
-  const bool gate = cp.out_act == OUT_GATE;
-  if (lds > 64 * 1024 &&
-      !(gate ? lds_opt_in(reinterpret_cast<const void*>(&conv_dma_kernel<4, true>), opt_in_gate)
-             : lds_opt_in(reinterpret_cast<const void*>(&conv_dma_kernel<4>), opt_in))) {
-    set_error("conv_dma_kernel: the device refused the %zu-byte dynamic LDS opt-in", lds);
-    return WETTS_E_HIP;
-  }
-  if (gate)
-    hipLaunchKernelGGL((conv_dma_kernel<4, true>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
-  else
-    hipLaunchKernelGGL((conv_dma_kernel<4>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

@@ -26,6 +26,8 @@
 // outputs, S = sum_{i>=1} h_i.  Positions outside [0, T) are written as zeros at every stage (each
 // conv pads ITS input).  Operation order and rounding points per output element equal the
 // conv-by-conv path (same packed weights, same group order), so results are bit-identical to it.
+#include <stdlib.h>
+
 #include "common.h"
 #include "resblock32.h"
 
@@ -55,10 +57,15 @@ __device__ __forceinline__ float lrelu2(float x, float slope) {
   return r;
 }
 
-template <int C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// NB = 32-column accumulator blocks per wave.  4: tiles of 128 * WN columns, two blocks per CU (LDS and 177 registers).
+// 3: tiles of 96 * WN columns -- 25 % fewer accumulator registers (<= 168: three waves per SIMD) and an LDS tile of at most
+// 53 KB, i.e. THREE blocks per CU where the chain's margins allow it: the chain is a sequence of short MFMA runs
+// separated by barriers and LDS write passes (k = 3 at C = 32: 192 MFMAs per wave between them), and a third resident
+// block is what hides those phases; the price is a larger share of halo columns (2 S of 96 * WN instead of 128 * WN).
+template <int C, int NB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 2 ? 4 : NB == 3 ? 3 : 2, NB == 2 ? 4 : NB == 3 ? 3 : 2)))
 void resblock_chain32_kernel(const ResChain32Params p) {
-  constexpr int WM = C / 32, WN = 4 / WM, NB = 4;
+  constexpr int WM = C / 32, WN = 4 / WM;
   constexpr int NTC = 32 * NB * WN;
   constexpr int NCH = C / kConvCK;
   constexpr int RPW = C / 4;                                   // staged rows per wave
@@ -306,6 +313,7 @@ void resblock_chain32_kernel(const ResChain32Params p) {
           const int soff = ((r & 3) + 8 * (r >> 2)) * T * 4;  // uniform
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
+            if (jj + u >= NB) continue;
             const int col = wcol + 32 * (jj + u);
             const bool ok = col >= p.S && col < NTC - p.S && t0 + col < Tb;
             pv[u][r] = 0.f;
@@ -313,9 +321,11 @@ void resblock_chain32_kernel(const ResChain32Params p) {
           }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u) {
+          if (jj + u >= NB) continue;
 #pragma unroll
           for (int r = 0; r < 16; ++r) xr[jj + u][r] += pv[u][r];
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -385,6 +395,26 @@ static void chain_geometry(int ktaps, const int* dil, int npairs, int* S, int* M
   *Mmin = m;
 }
 
+// Accumulator blocks per wave of a launch (see the kernel): 3 at C = 32 where THREE blocks of the narrower tile fit a
+// CU's LDS, else 4.  Measured (profiles/r05_chain_narrow_tiles_ab.txt, C = 32): k = 3 whole chain 97.7 -> 98.6 TF/s,
+// k = 7 as three pairs 113.0 -> 116.8 (and ahead of the whole chain's 112.3, which the 15 % halo bound now rules out by
+// itself), k = 11 pairs 124.2 -> 125.8; headline 61.14 -> 60.9 ms/step same box.  C = 64 loses 1 % (its halo share
+// doubles twice as fast) and keeps 4.  WETTS_CHAIN_NB3=0 is the A/B switch (2: two blocks per wave, four resident
+// blocks -- measured too, no better than 3).
+static int g_chain_nb3 = -1;
+static int chain_nb(int C, int Mmin) {
+  if (g_chain_nb3 < 0) {
+    const char* e = getenv("WETTS_CHAIN_NB3");
+    g_chain_nb3 = e ? atoi(e) : 3;
+  }
+  if (!g_chain_nb3 || C > 32) return 4;
+  // (the switch's value 2 asks for two blocks per wave = FOUR resident blocks: measurement only)
+  const int want = g_chain_nb3 == 2 ? 2 : 3, blocks = want == 2 ? 4 : 3;
+  const int ntc = 32 * want * (4 / (C / 32));
+  const int wp = (ntc + 2 * Mmin + 4 + 3) & ~3;
+  return blocks * (int64_t)C * wp * 4 <= 160 * 1024 ? want : 4;
+}
+
 bool resblock_chain32_supported(const PackedConv* c1, const PackedConv* c2, int npairs, int max_lds_bytes,
                                 int max_waste_pct) {
   if (npairs < 1 || npairs > RESCHAIN32_MAX_PAIRS) return false;
@@ -402,7 +432,7 @@ bool resblock_chain32_supported(const PackedConv* c1, const PackedConv* c2, int 
   int S, Mmin;
   chain_geometry(k, dil, npairs, &S, &Mmin);
   if (Mmin > RESCHAIN32_MAX_M) return false;
-  const int NTC = 128 * (4 / (C / 32));
+  const int NTC = 32 * chain_nb(C, Mmin) * (4 / (C / 32));
   if (2 * S * 100 > max_waste_pct * NTC || NTC - 2 * S <= 0) return false;
   const int Wp = (NTC + 2 * Mmin + 4 + 3) & ~3;
   return (int64_t)C * Wp * 4 <= max_lds_bytes;
@@ -411,12 +441,12 @@ bool resblock_chain32_supported(const PackedConv* c1, const PackedConv* c2, int 
 int resblock_chain32_nto(int C, int ktaps, const int* dil, int npairs) {
   int S, Mmin;
   chain_geometry(ktaps, dil, npairs, &S, &Mmin);
-  return 128 * (4 / (C / 32)) - 2 * S;
+  return 32 * chain_nb(C, Mmin) * (4 / (C / 32)) - 2 * S;
 }
 
-template <int C>
+template <int C, int NB>
 static int32_t launch_chain(ResChain32Params p, hipStream_t stream) {
-  constexpr int NTC = 128 * (4 / (C / 32));
+  constexpr int NTC = 32 * NB * (4 / (C / 32));
   chain_geometry(p.ktaps, p.dil, p.npairs, &p.S, &p.Mmin);
   p.NTO = NTC - 2 * p.S;
   WETTS_REQUIRE(p.NTO > 0, "chain halo exceeds the tile");
@@ -434,11 +464,11 @@ static int32_t launch_chain(ResChain32Params p, hipStream_t stream) {
   (void)hipGetDevice(&dev);
   static bool attr_done[64] = {};  // per device: tiles above the default 64 KB dynamic-LDS limit
   if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-    WETTS_HIP_CHECK(hipFuncSetAttribute((const void*)resblock_chain32_kernel<C>,
+    WETTS_HIP_CHECK(hipFuncSetAttribute((const void*)resblock_chain32_kernel<C, NB>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
-  hipLaunchKernelGGL((resblock_chain32_kernel<C>), dim3(grid), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((resblock_chain32_kernel<C, NB>), dim3(grid), dim3(256), lds, stream, p);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
@@ -464,10 +494,13 @@ int32_t launch_resblock_chain32(const PackedConv* c1, const PackedConv* c2, int 
     p.bias[2 * pr + 1] = c2[pr].bias;
     p.dil[pr] = c1[pr].dil;
   }
+  int S_, Mmin_;
+  chain_geometry(p.ktaps, p.dil, npairs, &S_, &Mmin_);
+  const int nb = chain_nb(c1[0].Cin, Mmin_);
   switch (c1[0].Cin) {
-    case 32: return launch_chain<32>(p, stream);
-    case 64: return launch_chain<64>(p, stream);
-    default: return launch_chain<128>(p, stream);
+    case 32: return nb == 3 ? launch_chain<32, 3>(p, stream) : nb == 2 ? launch_chain<32, 2>(p, stream) : launch_chain<32, 4>(p, stream);
+    case 64: return launch_chain<64, 4>(p, stream);
+    default: return launch_chain<128, 4>(p, stream);
   }
 }
 
