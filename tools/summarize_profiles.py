@@ -31,7 +31,10 @@ for a, b in [("prof_stats_baker/r_kernel_stats.csv", "kernel_stats.csv"), ("benc
              ("bench_cfg4_stress48k_f16.json",) * 2,
              ("bench_gpus2_refused.err",) * 2, ("bench_2rank_dryrun.json",) * 2, ("pytest_gpu.log",) * 2,
              ("b1_summary.txt", "b1_anatomy.txt"), ("stream_v1_bf16.json",) * 2]:
-    if os.path.exists(f"{src}/{a}"):
+    # gpurun_out/ accumulates over rounds (every call merges into it): only what THIS pass wrote is copied -- files not
+    # older than the pass's library-digest stamp
+    fresh_after = os.path.getmtime(f"{src}/lib_digest.txt") - 5 if os.path.exists(f"{src}/lib_digest.txt") else 0
+    if os.path.exists(f"{src}/{a}") and os.path.getmtime(f"{src}/{a}") >= fresh_after:
         shutil.copy(f"{src}/{a}", f"profiles/{tag}_{b}")
 
 
