@@ -74,6 +74,9 @@ def parse_args():
     ap.add_argument("--overlap", type=int, default=1,
                     help="1: SynthesizerTrn.set_overlap(True) -- the encoder stages of step k + 1 run on a side stream beside "
                          "the decoder of step k (back-to-back calls as a two-stage pipeline); 0: strictly one stage at a time")
+    ap.add_argument("--decoder-serial", action="store_true",
+                    help="f32 decoder: the three ResBlock chains of a stage on ONE stream (WETTS_DECODER_SERIAL; the "
+                         "form whose kernel trace has non-overlapping per-kernel durations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-fixture", type=int, default=16,
                     help="also time the oracle on the first N utterances of the batch as ONE padded call (SURVEY 8d's "
@@ -602,6 +605,8 @@ def _bench(args, rank, local_rank, world, mon):
         net.set_overlap(True)
     if ddtype != "f32":
         net.set_decoder_dtype(ddtype)
+    elif args.decoder_serial:
+        net.set_decoder_dtype("f32", serial=True)
     if fdtype != "f32":
         net.set_flow_dtype(fdtype)
 
@@ -682,8 +687,24 @@ def _bench(args, rank, local_rank, world, mon):
         iso_bytes = be.read_mrf_bytes(net)
         iso_ms, iso_launches = be.read_mrf_timing(net)
         be.set_mrf_timing(net, False)
-        net.set_overlap(True)
         iso = (iso_ms, iso_launches, iso_frames, iso_bytes)
+        # ... and, for the f32 decoder, the same with the three-stream fork of a stage's chains off as well
+        # (WETTS_DECODER_SERIAL): one launch after the other on one stream -- the form whose per-kernel durations a
+        # kernel trace can be compared with (in the forked form the kernels of the three chains overlap in time)
+        if ddtype == "f32" and hasattr(net, "set_decoder_dtype") and not getattr(be, "label", None) and \
+                not args.decoder_serial:
+            net.set_decoder_dtype("f32", serial=True)
+            be.set_mrf_timing(net, True)
+            ser_frames = 0.0
+            for _ in range(max(1, min(3, args.steps))):
+                _, yms = step()
+                ser_frames += float(sum((ym.sum().item() if decode == "ragged" else ym.numel()) for ym in yms))
+            be.sync()
+            ser_ms, ser_launches = be.read_mrf_timing(net)
+            be.set_mrf_timing(net, False)
+            net.set_decoder_dtype("f32", serial=False)
+            iso = iso + ((ser_ms, ser_launches, ser_frames),)
+        net.set_overlap(True)
 
     # PCIe-inclusive variant (SURVEY 8d's wall: H2D of the ids, D2H of the audio; the driver contract
     # says inputs are resident when the timed region starts, so this is reported beside `value`,
@@ -832,7 +853,7 @@ def _bench(args, rank, local_rank, world, mon):
         }
         stamp_traffic(roofline, traffic_src, traffic_dig)
     if iso and iso[0] > 0 and roofline.get("unit") in ("TFLOP/s", "GB/s"):
-        iso_ms, iso_launches, iso_frames, iso_bytes = iso
+        iso_ms, iso_launches, iso_frames, iso_bytes = iso[:4]
         per = mfl * iso_frames if roofline["unit"] == "TFLOP/s" else iso_bytes * dense_frac
         ach = per / (iso_ms * 1e-3) / (1e12 if roofline["unit"] == "TFLOP/s" else 1e9)
         roofline["isolated"] = {
@@ -840,6 +861,17 @@ def _bench(args, rank, local_rank, world, mon):
             "note": "the same class over extra steps with the pipelining off (nothing else on the chip): kernel quality; "
                     "`achieved` / `frac` above are the timed region's, where the class runs beside the next step's "
                     "encoder stages"}
+    if iso and len(iso) > 4 and iso[4][0] > 0 and roofline.get("unit") == "TFLOP/s":
+        ser_ms, ser_launches, ser_frames = iso[4]
+        ach = mfl * ser_frames / (ser_ms * 1e-3) / 1e12
+        roofline["isolated_serial"] = {
+            "achieved": ach, "frac": ach / roofline["peak"], "launches_per_step": ser_launches / max(1, min(3, args.steps)),
+            "avg_launch_ms": ser_ms / max(1, ser_launches),
+            "note": "pipelining off AND the stage's three ResBlock chains on ONE stream (WETTS_DECODER_SERIAL, grouped "
+                    "launches): one kernel at a time, so `avg_launch_ms` is directly a rocprofv3 --stats average "
+                    "(profiles/r05_kernel_stats_serial.csv).  In the default schedule the chains of a stage run on three "
+                    "streams: `launches` / `avg_launch_ms` above are then the class's WALL time (HIP events around each "
+                    "stage) per launch, and a trace's per-kernel durations overlap and sum to more than it"}
     backend = dist.get_backend() if world > 1 else "none"
     observed_world = dist.get_world_size() if world > 1 else 1
     prec = ("fp32" if ddtype == "f32" else
@@ -869,6 +901,8 @@ def _bench(args, rank, local_rank, world, mon):
                                f"{prec}, {n_speakers} speaker(s), {sr} Hz ({wtag})",
                    "global_batch": total, "phonemes": phonemes, "hop": hop,
                    "padded_sub_batches_per_step": nb, "decode": decode,
+                   "decoder_schedule": ("one stream (--decoder-serial)" if args.decoder_serial else
+                                        "a stage's k = 3 / 7 / 11 ResBlock chains on three streams") if ddtype == "f32" else "one stream",
                    "pipelining": ("encoder stages of call k + 1 on a side stream beside the decoder of call k "
                                   "(SynthesizerTrn.set_overlap)") if args.overlap else "none",
                    "sub_batch_plan": {"chosen_by": "equal-count (--buckets)" if args.buckets > 0 else

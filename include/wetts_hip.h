@@ -272,6 +272,12 @@ int32_t wetts_hifigan_ragged(const wetts_model_t* m, const float* z, int64_t z_b
  * restates the published operator definitions). */
 #define WETTS_DECODER_UINT8_DYNAMIC 3
 #define WETTS_DECODER_UNFUSED 0x10
+/* f32 HiFi-GAN: by default the k = 3 / 7 / 11 ResBlock chains of a stage run on three HIP streams forked from / joined to the
+ * call's stream (they are independent until the MRF sum; one chain's launch tails are filled by the others' work).
+ * OR-ing WETTS_DECODER_SERIAL into `precision` keeps every launch on the call's stream, one after the other (the round-4
+ * schedule with grouped launches): bit-identical, and the form in which a kernel trace's per-kernel durations do not
+ * overlap (measurement). */
+#define WETTS_DECODER_SERIAL 0x20
 int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision);
 
 /* One Conv1d ("same" padding) as a dynamically quantised ONNX graph computes it -- the building block

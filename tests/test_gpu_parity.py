@@ -277,6 +277,28 @@ def test_fused_resblock_pair_bit_identical(dtype, L, cname):
     assert np.array_equal(a, b), f"max |diff| {np.abs(a - b).max()}"
 
 
+@pytest.mark.parametrize("cname,B,L", [("v1_b2", 4, 300), ("v1_b2", 2, 37), ("v2_b2", 3, 200), ("stress48k_b2", 2, 150)])
+def test_three_stream_fork_of_the_chains_is_bit_identical_to_one_stream(cname, B, L):
+    """The default f32 decoder schedule runs the k = 3 / 7 / 11 ResBlock chains of a stage on three HIP streams (forked
+    from / joined to the caller's stream; the running MRF sum is ordered chain j - 1 -> chain j by events);
+    WETTS_DECODER_SERIAL keeps every launch on the caller's stream with the grouped launches of round 4.  Same kernels on
+    the same values in the same sum order: the audio must be EQUAL -- on big launches (whole-chain kernels, grouped
+    convs), on launches of a few tiles, and when called twice back to back (stream re-use)."""
+    case = util.load_case(cname)
+    net, cfg, W = _model(case)
+    torch.manual_seed(6)
+    z = torch.randn(B, cfg.inter_channels, L).cuda()
+    sid = torch.zeros(B, dtype=torch.long)
+    g = torch.nn.functional.embedding(sid, W["emb_g.weight"]).cuda() if "emb_g.weight" in W else None
+    net.set_decoder_dtype(torch.float32, serial=True)
+    a = net.hifigan(z, g).cpu().numpy()
+    net.set_decoder_dtype(torch.float32, serial=False)
+    b1 = net.hifigan(z, g)
+    b2 = net.hifigan(z, g)  # no synchronisation in between: the second call re-uses the aux streams and events
+    torch.cuda.synchronize()
+    assert np.isfinite(a).all() and np.array_equal(a, b1.cpu().numpy()) and np.array_equal(a, b2.cpu().numpy())
+
+
 @pytest.mark.parametrize("name", ["tiny_sdp_b3", "v1_b2", "v1_b4x128"])
 def test_wn_update_in_the_conv_epilogue_is_bit_identical(name):
     """The f32 flow's residual / skip update (modules.py:79-86) runs in the epilogue of the res_skip conv

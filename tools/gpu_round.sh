@@ -25,6 +25,9 @@ prof() {  # $1 = tag, rest = bench flags: kernel stats + the two HBM counter pas
   find $R/gpurun_out/prof_stats_$tag $R/gpurun_out/pmc_fetch_$tag $R/gpurun_out/pmc_write_$tag -name "*kernel_trace.csv" -delete 2>/dev/null
 }
 prof baker
+# the same line with the stage's chains on ONE stream: per-kernel durations of this trace do not overlap (kernel quality)
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats_baker_serial -o r -- python $R/bench.py --decoder-serial --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_stats_baker_serial.log 2>&1
+find $R/gpurun_out/prof_stats_baker_serial -name "*kernel_trace.csv" -delete 2>/dev/null
 prof bf16 --decoder-dtype bf16
 prof cfg2 --config multilingual
 prof stress48k --config stress48k
@@ -37,6 +40,7 @@ python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/benc
 cut -c1-420 gpurun_out/bench.json
 python bench.py --gpus 2 --steps 2 --warmup 1 > gpurun_out/bench_gpus2_refused.json 2> gpurun_out/bench_gpus2_refused.err; echo "gpus2 exit=$?" | tee -a gpurun_out/bench_gpus2_refused.err
 WETTS_BENCH_SINGLE_DEVICE=1 WETTS_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_2rank_dryrun.json 2> gpurun_out/bench_2rank_dryrun.err; echo "dryrun exit=$?"
+python bench.py --decoder-serial --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_serial.json 2>/dev/null
 for dt in bf16 f16 uint8; do python bench.py --steps 10 --warmup 3 --no-cpu-baseline --decoder-dtype $dt > gpurun_out/bench_$dt.json 2>/dev/null; done
 python bench.py --config multilingual --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_cfg2_multilingual_bf16.json 2>/dev/null
 python bench.py --config multilingual --decoder-dtype f32 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_cfg2_multilingual_f32.json 2>/dev/null

@@ -14,6 +14,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = "gpurun_out"
 import os
 for a, b in [("prof_stats_baker/r_kernel_stats.csv", "kernel_stats.csv"), ("bench.json",) * 2,
+             ("prof_stats_baker_serial/r_kernel_stats.csv", "kernel_stats_serial.csv"), ("bench_serial.json",) * 2,
              ("bench_bf16.json",) * 2, ("bench_f16.json",) * 2, ("bench_uint8.json",) * 2,
              ("bench_ungrouped.json",) * 2,
              ("prof_stats_cfg2/r_kernel_stats.csv", "kernel_stats_cfg2_multilingual_bf16.csv"),
@@ -125,6 +126,18 @@ for key, sub, in_class, count_only in CLASSES:
         "lib_digest": lib_digest,
         "kernels": kernels,
     }
+    if key == "dominant_conv_mfma":
+        # the f32 decoder's default schedule runs a stage's chains on three streams: the per-kernel durations of THAT trace
+        # overlap.  The --decoder-serial trace (one stream) gives the class's kernels one at a time:
+        sps = f"{src}/prof_stats_baker_serial/r_kernel_stats.csv"
+        if os.path.exists(sps):
+            rows = [r for r in csv.DictReader(open(sps)) if in_class(r["Name"])]
+            calls = sum(int(r["Calls"]) for r in rows)
+            out[key]["rocprof_avg_duration_ms_serial"] = sum(float(r["TotalDurationNs"]) for r in rows) / max(1, calls) / 1e6
+            out[key]["rocprof_calls_serial"] = calls
+            out[key]["note"] = ("rocprof_avg_duration_ms: the default (three-stream) schedule -- overlapping kernels, sums "
+                                "to more than the class's wall time; rocprof_avg_duration_ms_serial: --decoder-serial, "
+                                "compare with bench.py roofline.isolated_serial.avg_launch_ms")
     if not f:
         del out[key]  # this pass was not run
         continue

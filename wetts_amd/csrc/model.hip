@@ -422,6 +422,7 @@ struct wetts_model {
   // bf16 decoder (opt-in, wetts_set_decoder_precision): weights packed by the setter
   mutable int dec_precision = 0;  // 0 = f32, 1 = bf16, 2 = f16
   mutable int dec_unfused = 0;    // diagnostic: run ResBlock1 pairs as two conv launches
+  mutable int dec_serial = 0;     // WETTS_DECODER_SERIAL: no three-stream fork of a stage's chains
   int fuse32_lds = 160 * 1024;    // largest f32 pair tile run fused (WETTS_FUSE32_LDS, bytes)
   int fuse32_kmax128 = 11;        // C>=128 pairs with this many taps or more stay unfused
   int fuse32_maxc = 32;           // widest stage whose f32 pairs run fused (WETTS_FUSE32_MAXC): since the
@@ -460,6 +461,12 @@ struct wetts_model {
   // the model's own standard-normal stream (wetts_infer with eps == NULL)
   mutable uint64_t rng_seed = 0, rng_offset = 0;
   int mrf_streams = 1;
+  // Stages of at most this many channels run their k = 3 / 7 / 11 chains on three streams (0: none; the default covers every
+  // stage).  Round 5, same box, 20 steps (profiles/r05_mrf_fork_ab.txt): grouped launches on one stream 60.46 / 60.37
+  // ms/step; fork for C <= 32: 60.31; <= 64: 60.16; <= 128: 60.08; every stage: 59.76 -- the chain-kernel launches and the
+  // last c2 of each chain (which must add the running sum in chain order) cannot be grouped, and their ramps and tails are
+  // what the other chains' work fills.  Bit-identical to the one-stream schedule (same launches, same sum order, by events).
+  int mrf_fork_maxc = 1 << 20;
   // WETTS_TUNE dds_fused: a DDSConv of the duration predictor in one launch (dds_fused.hip).  1: for small launches
   // (B * ceil(Tx / 6) <= 128 blocks of 32 columns, 6 of them valid: encoder call 1.70 -> 1.63 ms at B = 1, Tx = 64);
   // 2: always (64-column tiles; no faster than the 12 launches it replaces, profiles/r03_dds_fused_ab.txt); 0: never
@@ -919,7 +926,7 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     // WETTS_TUNE="name=value,name=value", names as in the table below
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {
-        {"stage2_pct", &m->stage2_pct}, {"dds_fused", &m->dds_fused}, {"wn_fuse", &m->wn_fuse}, {"wn_gate", &m->wn_gate}, {"mrf_streams", &m->mrf_streams},                  {"fuse32_lds", &m->fuse32_lds},
+        {"stage2_pct", &m->stage2_pct}, {"dds_fused", &m->dds_fused}, {"wn_fuse", &m->wn_fuse}, {"wn_gate", &m->wn_gate}, {"mrf_streams", &m->mrf_streams}, {"mrf_fork_maxc", &m->mrf_fork_maxc},                  {"fuse32_lds", &m->fuse32_lds},
         {"fuse32_kmax128", &m->fuse32_kmax128},   {"fuse32_maxc", &m->fuse32_maxc},
         {"fuse32_kmax", &m->fuse32_kmax},         {"fuse32_kwide", &m->fuse32_kwide},
         {"fuse2_maxc", &m->fuse2_maxc},           {"fuse2_waste_pct", &m->fuse2_waste_pct},
@@ -1982,7 +1989,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
     // chains concurrently when the stage's convs are launches of a few blocks (a streaming window): three
     // independent 10-25 us kernels then share the chip instead of queueing behind each other
     const bool small_stage = !lens && (int64_t)cdiv(ch, 64) * cdiv(len, 64) * B <= m->small_max_tiles;
-    const int nstreams = (m->small_fork && small_stage && c->resblock == 1) ? nk : m->mrf_streams;
+    const int nstreams = (c->resblock == 1 && ((m->small_fork && small_stage) || (ch <= m->mrf_fork_maxc && !m->dec_serial))) ? nk : m->mrf_streams;
     const bool forked = nstreams > 1;
     if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_fork, s));
     // the chain kernel addresses one utterance's [C][T] plane with 32-bit byte offsets and buffer descriptors: a
@@ -1999,7 +2006,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
       float* ft = chain_buf[j][2];
       const float* rx = xu;  // current resblock x
       // a whole ResBlock1 in one launch (resblock_chain32.hip): x read once, the MRF sum written once
-      if (c->resblock == 1 && !m->dec_unfused && !forked && nd <= RESCHAIN32_MAX_PAIRS &&
+      if (c->resblock == 1 && !m->dec_unfused && nd <= RESCHAIN32_MAX_PAIRS &&
           ch <= m->chain_whole_maxc && m->chain_whole_waste_pct > 0 && len % 4 == 0 && chain_addr_ok &&
           resblock_chain32_supported(rb.c1.data(), rb.c2.data(), nd, m->fuse32_lds / 2,
                                      m->chain_whole_waste_pct)) {
@@ -2017,7 +2024,10 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
           cp.slope = 0.1f;
           cp.lens = lens;
           cp.len_mul = spf;
+          // (forked: the launch adds the running sum, which is ordered chain j - 1 -> chain j)
+          if (forked && j > 0) WETTS_HIP_CHECK(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
           WETTS_TRY(launch_resblock_chain32(rb.c1.data(), rb.c2.data(), nd, cp, sj));
+          if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_chain[j], sj));
           if (tm && tm->on) tm->launches += 1;
           mrf_count(m, 1, 2 + (j > 0 ? 1 : 0), ch, len, B, 4);
           continue;
@@ -2663,7 +2673,8 @@ int32_t wetts_dynamic_quant_conv1d(const float* x, const float* w, const float* 
 int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision) {
   WETTS_REQUIRE(m != nullptr, "null model");
   const int unfused = (precision & WETTS_DECODER_UNFUSED) ? 1 : 0;
-  precision &= ~WETTS_DECODER_UNFUSED;
+  m->dec_serial = (precision & WETTS_DECODER_SERIAL) ? 1 : 0;
+  precision &= ~(WETTS_DECODER_UNFUSED | WETTS_DECODER_SERIAL);
   WETTS_REQUIRE(precision >= 0 && precision <= 3,
                 "precision must be 0 (f32), 1 (bf16), 2 (f16) or 3 (uint8 dynamic quantisation)");
   m->dec_unfused = unfused;

@@ -120,17 +120,21 @@ class SynthesizerTrn:
     def cuda(self, device=None):
         return self.to("cuda" if device is None else device)
 
-    def set_decoder_dtype(self, dtype, fused=True):
+    def set_decoder_dtype(self, dtype, fused=True, serial=False):
         """HiFi-GAN arithmetic: torch.float32 (default, parity-gated), torch.bfloat16 or
         torch.float16 (16-bit activations/weights, f32 accumulation; encoder / duration / flow stay f32).
         `fused=False` runs every ResBlock1 (c1, c2) pair as two conv launches instead of the fused
-        LDS-resident kernel -- bit-identical, for diagnostics."""
+        LDS-resident kernel -- bit-identical, for diagnostics.  `serial=True` keeps the f32 decoder's launches on the
+        caller's stream one after the other instead of running a stage's three ResBlock chains on three streams --
+        bit-identical; the form in which a kernel trace's per-kernel durations do not overlap."""
         prec = {torch.float32: 0, "f32": 0, "fp32": 0, torch.bfloat16: 1, "bf16": 1,
                 torch.float16: 2, "f16": 2, "fp16": 2,
                 # the `export_onnx.py --quant` variant (export_onnx.py:149-157): uint8 dynamic quantisation
                 torch.uint8: 3, torch.quint8: 3, "uint8": 3, "u8": 3}[dtype]
         if not fused:
             prec |= 0x10  # WETTS_DECODER_UNFUSED
+        if serial:
+            prec |= 0x20  # WETTS_DECODER_SERIAL: one launch after the other on the caller's stream (measurement)
         self._decoder_precision = prec
         if self._handle is not None:
             _lib.check(_lib.load().wetts_set_decoder_precision(self._handle, prec),
@@ -163,6 +167,14 @@ class SynthesizerTrn:
         self.overlap = bool(on)
         return self
 
+    def _new_enc_stream(self):
+        """The side stream of overlap mode.  WETTS_ENC_STREAM_PRIORITY (measurement switch) asks for a stream priority
+        (torch convention: lower = higher priority)."""
+        pr = os.environ.get("WETTS_ENC_STREAM_PRIORITY")
+        if pr is not None:
+            return torch.cuda.Stream(device=self.device, priority=int(pr))
+        return torch.cuda.Stream(device=self.device)
+
     def upload(self, t, dtype=None, consumer="encoder"):
         """Host tensor / array -> device tensor on the stream that will read it.  `consumer="encoder"` (ids, lengths,
         speaker ids: what infer() / infer_encoder() read): the caller's stream, or in overlap mode the encoder's side
@@ -175,7 +187,7 @@ class SynthesizerTrn:
         if consumer != "encoder" or not (self.overlap and self.device.type == "cuda"):
             return t.to(device=self.device, dtype=dtype, non_blocking=nb)
         if self._enc_stream is None:
-            self._enc_stream = torch.cuda.Stream(device=self.device)
+            self._enc_stream = self._new_enc_stream()
         with torch.cuda.stream(self._enc_stream):
             return t.to(device=self.device, dtype=dtype, non_blocking=nb)
 
@@ -521,7 +533,7 @@ class SynthesizerTrn:
                                 float(noise_scale_w), eps_w, eps_z)
         main = torch.cuda.current_stream(self.device)
         if self._enc_stream is None:
-            self._enc_stream = torch.cuda.Stream(device=self.device)
+            self._enc_stream = self._new_enc_stream()
         if self._debug_overlap:
             ins = [t for t in (x, x_lengths, sid, eps_w, eps_z) if isinstance(t, torch.Tensor) and t.is_cuda]
             with torch.cuda.stream(self._enc_stream):
