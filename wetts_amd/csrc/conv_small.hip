@@ -267,8 +267,11 @@ template <int KT, int SCH, int MAXKG>
 static int32_t launch_small_cfg(const ConvParams& p, hipStream_t stream, int force_kg = 0) {
   const int64_t blocks = (int64_t)cdiv(p.M, 32) * cdiv(p.N, 32) * p.B;
   const int NS = p.nchunks / SCH;
-  // WETTS_SMALL_KG8_NS / WETTS_SMALL_KG16_NS (experiment): stages from which 8 / 16 waves are used
-  static const int ns8 = getenv("WETTS_SMALL_KG8_NS") ? atoi(getenv("WETTS_SMALL_KG8_NS")) : 16;
+  // WETTS_SMALL_KG8_NS / WETTS_SMALL_KG16_NS (experiment): stages from which 8 / 16 waves are used.  8 waves from 8 stages
+  // (round 5; was 16): the flow's in_layers (12 stages) and the C = 128 window convs get the 8-wave split -- B = 1
+  // encoder call 1.491 -> 1.455 ms, first window 1.054 -> 1.025, first chunk 2.54 -> 2.48 ms same box
+  // (profiles/r05_small_launch_knobs.txt)
+  static const int ns8 = getenv("WETTS_SMALL_KG8_NS") ? atoi(getenv("WETTS_SMALL_KG8_NS")) : 8;
   static const int ns16 = getenv("WETTS_SMALL_KG16_NS") ? atoi(getenv("WETTS_SMALL_KG16_NS")) : 32;
   int kg = 4;
   if (NS >= ns8 && blocks * 2 <= 512) kg = 8;
