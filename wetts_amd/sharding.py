@@ -237,7 +237,7 @@ def shard_utterances(lengths, world_size):
     for i in order:
         full = sum(1 for r in range(world_size) if counts[r] > q)
         cands = [r for r in range(world_size) if counts[r] < q or (counts[r] == q and full < rem)]
-        r = min(cands, key=lambda q: (loads[q], q))
+        r = min(cands, key=lambda c: (loads[c], c))
         shards[r].append(i)
         loads[r] += int(lengths[i])
         counts[r] += 1
