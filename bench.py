@@ -731,8 +731,16 @@ def _bench(args, rank, local_rank, world, mon):
         allt = [torch.zeros_like(mine_t) for _ in range(world)]
         dist.all_gather(allt, mine_t)
         rank_ms = [float(t.item()) for t in allt]
+    backend = dist.get_backend() if world > 1 else "none"
+    observed_world = dist.get_world_size() if world > 1 else 1
     if world > 1:
         dist.barrier()  # the last collective: rank 0 formats the line (and, if asked, times the CPU baseline) alone
+        be.sync()
+        mon.done()  # (before the store goes away under the monitor thread)
+        try:  # every rank leaves the group in order (no "process group has NOT been destroyed" noise, no rank that
+            dist.destroy_process_group()  # tears its communicator down while a peer still uses it)
+        except Exception as e:  # never fail a finished measurement on the way out
+            sys.stderr.write(f"[wetts rank {rank}/{world}] destroy_process_group: {e}\n")
     mon.done()
     if rank != 0:
         return
@@ -872,8 +880,6 @@ def _bench(args, rank, local_rank, world, mon):
                     "(profiles/r05_kernel_stats_serial.csv).  In the default schedule the chains of a stage run on three "
                     "streams: `launches` / `avg_launch_ms` above are then the class's WALL time (HIP events around each "
                     "stage) per launch, and a trace's per-kernel durations overlap and sum to more than it"}
-    backend = dist.get_backend() if world > 1 else "none"
-    observed_world = dist.get_world_size() if world > 1 else 1
     prec = ("fp32" if ddtype == "f32" else
             "uint8 dynamic-quantised decoder convs (int32 accumulate)" if ddtype == "uint8" else
             ddtype + " decoder") + \
