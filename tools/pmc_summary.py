@@ -12,7 +12,12 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in files:
     for row in csv.DictReader(open(f)):
         name = row.get("Kernel_Name", "?")
-        if "conv_mfma" not in name and len(sys.argv) < 3:
+        if len(sys.argv) >= 3 and sys.argv[2] == "mrf":  # the f32 MRF class: tagged convs, grouped launches, chain kernels
+            import re
+            mm = re.search(r"conv_mfma_kernel<\d+, \d+, \d+, \d+, \d+, (true|false)", name)
+            if not ((mm and mm.group(1) == "true") or "conv_mfma_group_kernel" in name or "resblock_chain32_kernel" in name):
+                continue
+        elif "conv_mfma" not in name and len(sys.argv) < 3:
             continue
         key = (name[:70], row.get("Grid_Size", ""), row.get("LDS_Block_Size", ""))
         agg[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
@@ -28,3 +33,5 @@ for key, ctr in sorted(agg.items()):
                 print(f"    {k}/WAVE_CYCLES = {m[k] / wc:.3f}")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "SQ_BUSY_CYCLES" in m:
         print(f"    MFMA_BUSY/BUSY_CYCLES = {m['SQ_VALU_MFMA_BUSY_CYCLES'] / m['SQ_BUSY_CYCLES']:.3f}")
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
+        print(f"    MFMA_BUSY/GRBM_GUI_ACTIVE = {m['SQ_VALU_MFMA_BUSY_CYCLES'] / m['GRBM_GUI_ACTIVE']:.3f}")
