@@ -207,22 +207,46 @@ void conv_bf16_kernel(const ConvBParams p) {
   const int wcol0 = n0 + wn * (32 * NB);
   const bool rows_ok = mrow_blk + 32 <= p.M;
 
-  // residual / running sum folded into the accumulator init (plain convs only)
+  // residual / running sum folded into the accumulator init (plain convs only).  Three phases -- all residual loads, all
+  // running-sum loads, then the conversions and adds: as one loop (load, load, add per 16-byte piece) every piece was a
+  // serialised memory round trip before the first MFMA (the f32 kernel's same defect cost the lone last-c2 launches 40 %
+  // of their matrix time, profiles/r05_sq_counters_mrf.txt).  Same values, same additions: bit-identical.
   if (p.up == 0 && (p.res || p.accum) && rows_ok) {
+    uint4 rr[NB][2], oo[NB][2];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = wcol0 + 32 * j + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = co_blk + 16 * i + 8 * half;
+        rr[j][i] = make_uint4(0u, 0u, 0u, 0u);
+        if (p.res && t < p.N)
+          rr[j][i] = *reinterpret_cast<const uint4*>(p.res + (int64_t)b * p.r_bs + (int64_t)t * p.cout + c);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = wcol0 + 32 * j + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = co_blk + 16 * i + 8 * half;
+        oo[j][i] = make_uint4(0u, 0u, 0u, 0u);
+        if (p.accum && t < p.N)
+          oo[j][i] = *reinterpret_cast<const uint4*>(p.out + (int64_t)b * p.o_bs + (int64_t)t * p.cout + c);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int t = wcol0 + 32 * j + (lane & 31);
       if (t < p.N) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int c = co_blk + 16 * i + 8 * half;
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = 0.f;
           if (p.res) {
-            uint4 rr = *reinterpret_cast<const uint4*>(p.res + (int64_t)b * p.r_bs +
-                                                       (int64_t)t * p.cout + c);
-            const unsigned w4[4] = {rr.x, rr.y, rr.z, rr.w};
+            const unsigned w4[4] = {rr[j][i].x, rr[j][i].y, rr[j][i].z, rr[j][i].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               v[2 * e] = cv_in<F16>((unsigned short)(w4[e] & 0xffffu));
@@ -230,9 +254,7 @@ void conv_bf16_kernel(const ConvBParams p) {
             }
           }
           if (p.accum) {
-            uint4 oo = *reinterpret_cast<const uint4*>(p.out + (int64_t)b * p.o_bs +
-                                                       (int64_t)t * p.cout + c);
-            const unsigned w4[4] = {oo.x, oo.y, oo.z, oo.w};
+            const unsigned w4[4] = {oo[j][i].x, oo[j][i].y, oo[j][i].z, oo[j][i].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               v[2 * e] += cv_in<F16>((unsigned short)(w4[e] & 0xffffu));

@@ -322,19 +322,45 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, int bid) {
     const unsigned rcs4 = (unsigned)p.r_cs * 4u, ocs4 = (unsigned)p.o_cs * 4u;
     const unsigned rlane = (unsigned)(4 * (lane >> 5)) * rcs4 + (unsigned)(lane & 31) * 4u;
     const unsigned olane = (unsigned)(4 * (lane >> 5)) * ocs4 + (unsigned)(lane & 31) * 4u;
+    // Two phases behind block-level branches.  (Round 5: as one loop -- `v = res; if (accum) v += out` per element -- the
+    // compiler put a uniform branch, the two loads, a vmcnt(0) and the add behind each other for EVERY element: 64
+    // serialised memory round trips per wave before its first MFMA.  The launches that have both operands -- the last
+    // c2 of each ResBlock chain, 8 ms of the headline step -- ran with the matrix pipe 60-83 % busy for it,
+    // profiles/r05_sq_counters_mrf.txt.)  Same values, same additions: bit-identical.
+    if (rbase) {  // the residual: every load in flight at once, first use is the first MFMA
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
+      for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned rr = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2));
+        for (int r = 0; r < 16; ++r) {
+          const unsigned rr = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2));
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          float v = 0.f;
-          if (rbase) v = *reinterpret_cast<const float*>(rbase + (rr * rcs4 + rlane + 128u * j));
-          if (p.accum)
-            v += *reinterpret_cast<const float*>(abase_o + (rr * ocs4 + olane + 128u * j));
-          acc[i][j][r] = v;
+          for (int j = 0; j < NB; ++j)
+            acc[i][j][r] = *reinterpret_cast<const float*>(rbase + (rr * rcs4 + rlane + 128u * j));
         }
+    }
+    if (p.accum) {  // + the running sum: two column blocks' worth of temporaries at a time, one wait, then the adds
+#pragma unroll
+      for (int jh = 0; jh < NB; jh += 2) {
+        float pv[MB][16][2];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned rr = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2));
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+              if (jh + u < NB)
+                pv[i][r][u] = *reinterpret_cast<const float*>(abase_o + (rr * ocs4 + olane + 128u * (jh + u)));
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+              if (jh + u < NB) acc[i][jh + u][r] += pv[i][r][u];
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   } else if (pre_res) {
