@@ -467,22 +467,32 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, int bid) {
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
       const int mrow0 = mtile * MT + (wm * MB + i) * 32 + 4 * half;
+      // every bias value of this wave's 8 row pairs first (rows clamped: the loads are unconditional), then the stores:
+      // loaded inside the store loop each row pair was its own load / wait / use round trip at the end of every tile
+      float bt[8], bs[8], ut[8], us[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = 2 * q;
+        const int gi = min(mrow0 + (r & 3) + 8 * (r >> 2), p.M - 2) >> 1;
+        bt[q] = p.bias ? p.bias[gi] : 0.f;
+        bs[q] = p.bias ? p.bias[gH + gi] : 0.f;
+        ut[q] = bb ? bb[gi] : 0.f;
+        us[q] = bb ? bb[gH + gi] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const int row = mrow0 + (r & 3) + 8 * (r >> 2);
         if (row >= p.M) continue;
-        const int gi = row >> 1;
+        const int gi = row >> 1, q = r >> 1;
         // the sums of the launch this one replaces, to the bit: whole tiles of the plain epilogue add acc + (bias +
         // bias_b), edge tiles (the generic tail) (acc + bias) + bias_b
-        float bt = 0.f, bs = 0.f, ut = 0.f, us = 0.f;
-        if (p.bias) { bt = p.bias[gi]; bs = p.bias[gH + gi]; }
-        if (bb) { ut = bb[gi]; us = bb[gH + gi]; }
-        if (full_tile) { bt += ut; bs += us; ut = us = 0.f; }
+        float b0 = bt[q], b1 = bs[q], u0 = ut[q], u1 = us[q];
+        if (full_tile) { b0 += u0; b1 += u1; u0 = u1 = 0.f; }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           const int col = n0 + wn * (32 * NB) + j * 32 + (lane & 31);
           if (col < N)
-            p.out[ob + (int64_t)gi * p.o_cs + col] = wn_gate((acc[i][j][r] + bt) + ut, (acc[i][j][r + 1] + bs) + us);
+            p.out[ob + (int64_t)gi * p.o_cs + col] = wn_gate((acc[i][j][r] + b0) + u0, (acc[i][j][r + 1] + b1) + u1);
         }
       }
     }

@@ -132,16 +132,27 @@ __global__ __launch_bounds__(256) void layernorm_reg_kernel(
   const int t = (blockIdx.x % tblocks) * TL + tl;
   const bool ok = t < T;
   const int64_t base = (int64_t)b * C * T + (ok ? t : 0);
-  float v[PER], rv[PER], gm[PER], bt[PER];
+  float v[PER], av[PER], rv[PER], gm[PER], bt[PER];
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int c = cg + CG * j;
     const int cc = c < C ? c : 0;  // clamped: every load is issued, the value is dropped below
     v[j] = a[base + (int64_t)cc * T];
-    if (add) v[j] += add[base + (int64_t)cc * T];
     rv[j] = res ? res[base + (int64_t)cc * T] : 0.f;
     gm[j] = gamma[cc];
     bt[j] = beta[cc];
+  }
+  // the second summand in its own pass behind ONE branch: as `if (add) v[j] += add[..]` inside the loop above, every j
+  // became load, load, s_waitcnt vmcnt(0), add -- PER serialised round trips, which is what "all loads in flight" was
+  // written to avoid (found in the ISA, round 5; same additions, bit-identical)
+  if (add) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int c = cg + CG * j;
+      av[j] = add[base + (int64_t)(c < C ? c : 0) * T];
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) v[j] += av[j];
   }
   const float mk = (mask && ok) ? mask[(int64_t)b * T + t] : 1.f;
   float sum = 0.f;
