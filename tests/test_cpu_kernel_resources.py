@@ -84,3 +84,19 @@ def test_pointwise_gemm_and_16bit_kernels_keep_their_occupancy(table):
             assert v["VGPRs"] <= 192 and v["ScratchSize"] == 0, (k, v)
         if "rb2_stage16_kernel<" in k:  # two blocks of four waves per CU
             assert v["VGPRs"] <= 256 and v["ScratchSize"] == 0, (k, v)
+
+
+def test_no_serialised_load_round_trips_in_the_kernels_fixed_for_them():
+    """tools/isa_scan.py: a run of `load ... s_waitcnt vmcnt(0)` pairs = every load waits for memory before the next is
+    issued.  Round 5 found that shape in LayerNorm (`if (add) v[j] += add[..]` inside the load loop: PER round trips per
+    launch, 8.5 -> 5.9 us once batched) and in conv_mfma_kernel's accumulator init (1.7 % of the headline); LayerNorm's ISA
+    is simple enough to pin: no run longer than 3 pairs.  (conv_mfma_kernel keeps runs of 64 in its EDGE-tile paths by
+    design, so its fix is pinned by the SQ-counter profile instead, profiles/r05_sq_counters_mrf.txt.)"""
+    import isa_scan
+    if not os.path.exists(isa_scan.OBJDUMP):
+        pytest.skip("needs llvm-objdump")
+    runs = isa_scan.scan(_lib.LIB_PATH)
+    ln = {k: v for k, v in runs.items() if "layernorm_reg_kernel<" in k}
+    assert len(ln) >= 3, sorted(runs)[:5]
+    for k, (run, pairs) in ln.items():
+        assert run <= 3, (k, run, pairs)
