@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define WETTS_ABI_VERSION 8
+#define WETTS_ABI_VERSION 9
 
 #define WETTS_OK 0
 #define WETTS_E_INVALID (-1)   /* bad argument / unsupported configuration */
@@ -106,7 +106,11 @@ typedef struct wetts_config {
   /* speaker-conditioned text encoder (models.py:87-101, attentions.py:39-48,74-78): at layer 2
    * x = (x + spk_emb_linear(g)) * x_mask */
   int32_t use_spk_conditioned_encoder;
-  int32_t reserved[7];
+  /* SynthesizerTrn(..., is_onnx=...) (models.py:50,111 -> VocosGenerator, decoders.py:279-283): the iSTFT arithmetic of a
+   * Vocos model at create; see wetts_set_istft_mode().  export_onnx.py:59 forces it to 1 for every exported graph.
+   * HiFi-GAN models ignore it, as the reference does. */
+  int32_t is_onnx;
+  int32_t reserved[6];
 } wetts_config_t;
 
 typedef struct wetts_model wetts_model_t; /* opaque */
@@ -279,6 +283,24 @@ int32_t wetts_hifigan_ragged(const wetts_model_t* m, const float* z, int64_t z_b
  * overlap (measurement). */
 #define WETTS_DECODER_SERIAL 0x20
 int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision);
+
+/* iSTFT head of a Vocos model (decoders.py:300-304).  The reference has TWO, selected by the module's `is_onnx` flag:
+ *   WETTS_ISTFT_TORCH (0)  torchaudio InverseSpectrogram == torch.istft(hann, center=True): frames = irfft(S) * hann,
+ *                          overlap-add, DIVIDED by the overlap-added hann^2 envelope, n_fft/2 trimmed per side
+ *                          -- what SynthesizerTrn.infer() of a model built by inference.py computes;
+ *   WETTS_ISTFT_ONNX  (1)  OnnxSTFT.inverse (utils/stft.py:325-340): conv_transpose1d with
+ *                          pinv(scale * rDFT basis)^T * hann, scale = n_fft / hop (== irfft * hann / scale), overlap-add,
+ *                          same trim, NO envelope division -- what every graph export_onnx.py writes computes
+ *                          (export_onnx.py:59 sets hps.model.is_onnx = True), i.e. the arithmetic behind
+ *                          inference_onnx.py, cli/model.py, runtime/core/model/vits_model.cc and the Triton repos.
+ *                          At hop = n_fft / 4 the interior is 0.375 x the torch.istft audio; the first and last
+ *                          n_fft/2 samples differ in shape as well.
+ * The mode is the config's is_onnx at create; this call switches a live model (both bases are built at create; a host
+ * flag read at launch time, so it applies to the calls issued after it).  HiFi-GAN models accept and ignore it. */
+#define WETTS_ISTFT_TORCH 0
+#define WETTS_ISTFT_ONNX 1
+int32_t wetts_set_istft_mode(const wetts_model_t* m, int32_t mode);
+int32_t wetts_get_istft_mode(const wetts_model_t* m);
 
 /* One Conv1d ("same" padding) as a dynamically quantised ONNX graph computes it -- the building block
  * of WETTS_DECODER_UINT8_DYNAMIC, exposed for validation: DynamicQuantizeLinear over the whole x,

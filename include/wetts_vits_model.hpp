@@ -59,12 +59,19 @@ class VitsModel {
     Check(hipMemcpy(d, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
     Check(wetts_create(&cfg_, d, (int64_t)blob.size(), nullptr, &model_), "wetts_create");
     hop_ = wetts_hop_length(model_);
+    // The reference class runs the two graphs export_onnx.py wrote, and that script builds its model with
+    // hps.model.is_onnx = True (export_onnx.py:59): a Vocos decoder graph ends in OnnxSTFT.inverse
+    // (utils/stft.py:325-340), not torch.istft.  This twin stands where those sessions stood, so it computes the
+    // same head whatever the config says (HiFi-GAN models have no such switch and ignore the call).
+    Check(wetts_set_istft_mode(model_, WETTS_ISTFT_ONNX), "wetts_set_istft_mode");
   }
   ~VitsModel() { wetts_destroy(model_); }
   VitsModel(const VitsModel&) = delete;
   VitsModel& operator=(const VitsModel&) = delete;
 
   int hop_length() const { return hop_; }
+  // WETTS_ISTFT_TORCH: the iSTFT of SynthesizerTrn.infer() in the PyTorch CLI (inference.py) instead of the exported graphs'
+  void set_istft_mode(int mode) { Check(wetts_set_istft_mode(model_, mode), "wetts_set_istft_mode"); }
   void set_scales(float noise, float length, float noise_w) {
     noise_scale_ = noise; length_scale_ = length; noise_scale_w_ = noise_w;
   }

@@ -1,8 +1,12 @@
 """TEST INFRASTRUCTURE ONLY -- never imported by the product path (wetts_amd/).
 
-Imports the *unmodified* reference VITS code from /root/reference with three unused
+Imports the *unmodified* reference VITS code from /root/reference with three absent
 third-party imports stubbed (torchaudio, librosa, numba), exactly as SURVEY.md §8(c)
-documents.  Only usable inside the build container (the GPU box has no /root/reference);
+documents.  Two of the stubbed symbols ARE on the inference path and are given their published
+behaviour instead of a raiser: torchaudio's InverseSpectrogram (== torch.istft, below) and librosa's
+pad_center (OnnxSTFT.__init__, utils/stft.py:283 -- reached by every is_onnx=True Vocos model, i.e. by every
+exported graph; rounds 1-5 stubbed it as a raiser, so no such model could be built and the OnnxSTFT head went
+unpinned).  Only usable inside the build container (the GPU box has no /root/reference);
 used by tests/golden/make_golden.py to generate the committed golden vectors and by the
 CPU tests that pin oracle/vits_oracle.py against the live reference when it is present.
 """
@@ -61,6 +65,21 @@ class _InverseSpectrogram:
                            normalized=False, onesided=True, length=length, return_complex=False)
 
 
+def _pad_center(data, size, axis=-1, **kwargs):
+    """librosa.util.pad_center (librosa/util/utils.py): zero-pads `data` along `axis` to `size` with the data
+    centred (lpad = (size - n) // 2); raises when size < n.  OnnxSTFT.__init__ (utils/stft.py:283) calls it with
+    the window and filter_length; for win_length == filter_length (every reference config) it is the identity."""
+    import numpy as np
+    size = kwargs.get("size", size)
+    n = data.shape[axis]
+    if size < n:
+        raise ValueError(f"Target size ({size}) must be at least input size ({n})")
+    lpad = int((size - n) // 2)
+    lengths = [(0, 0)] * data.ndim
+    lengths[axis] = (lpad, int(size - n - lpad))
+    return np.pad(data, lengths, **{k: v for k, v in kwargs.items() if k != "size"})
+
+
 def install_stubs():
     if "torchaudio" not in sys.modules:
         ta = _stub("torchaudio")
@@ -71,7 +90,7 @@ def install_stubs():
                               Resample=_raiser("Resample"))
     if "librosa" not in sys.modules:
         lb = _stub("librosa")
-        lb.util = _stub("librosa.util", pad_center=_raiser("pad_center"),
+        lb.util = _stub("librosa.util", pad_center=_pad_center,
                         tiny=_raiser("tiny"), normalize=_raiser("normalize"))
         lb.filters = _stub("librosa.filters", mel=_raiser("mel"))
     if "numba" not in sys.modules:

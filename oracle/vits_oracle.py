@@ -423,10 +423,37 @@ def hifigan(W, cfg, z, g):
 # ------------------------------------------------------------------------------------------------
 # Vocos generator  (model/decoders.py:221-308: ConvNeXtLayer :221-248, VocosGenerator :251-305)
 # ------------------------------------------------------------------------------------------------
+def onnx_stft_inverse_basis(n_fft, hop, win_length):
+    """OnnxSTFT.__init__'s `inverse_basis` buffer (utils/stft.py:266-290): pinv(scale * [Re; Im] rows 0..n_fft/2 of
+    fft(eye(n_fft))) transposed, as a conv_transpose1d weight [n_fft + 2, 1, n_fft], times the periodic hann window
+    (scipy get_window('hann', win_length, fftbins=True), zero-centre-padded to n_fft -- librosa's pad_center, the
+    identity for win_length == n_fft)."""
+    import numpy as np
+    scale = n_fft / hop
+    fb = np.fft.fft(np.eye(n_fft))
+    cutoff = int(n_fft / 2 + 1)
+    fb = np.vstack([np.real(fb[:cutoff, :]), np.imag(fb[:cutoff, :])])
+    inv = torch.FloatTensor(np.linalg.pinv(scale * fb).T[:, None, :])
+    w = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_length) / win_length)
+    lpad = (n_fft - win_length) // 2
+    w = np.pad(w, (lpad, n_fft - win_length - lpad))
+    return inv * torch.from_numpy(w).float()
+
+
+def onnx_stft_inverse(mag, phase, n_fft, hop, win_length):
+    """OnnxSTFT.inverse (utils/stft.py:325-340): conv_transpose1d of [mag cos; mag sin] with the inverse basis at
+    stride hop, n_fft/2 samples cut from each end.  No window-envelope division."""
+    x = torch.cat([mag * torch.cos(phase), mag * torch.sin(phase)], dim=1)
+    o = F.conv_transpose1d(x, onnx_stft_inverse_basis(n_fft, hop, win_length), stride=hop, padding=0)
+    o = o[:, :, int(n_fft / 2):]
+    return o[:, :, :-int(n_fft / 2)]
+
+
 def vocos(W, cfg, z, g):
     """VocosGenerator.forward.  The iSTFT is torch.istft with the arguments
     torchaudio.transforms.InverseSpectrogram(n_fft, hop_length, win_length, center=True) passes
-    (hann window, not normalized, one-sided, length=None) -- decoders.py:279,304."""
+    (hann window, not normalized, one-sided, length=None) -- decoders.py:279,304 -- or, for a model built with
+    is_onnx=True (cfg["is_onnx"]; every exported graph, export_onnx.py:59), OnnxSTFT.inverse -- decoders.py:300-301."""
     x = F.pad(z, (1, 0), mode="reflect")               # nn.ReflectionPad1d([1, 0])
     x = conv1d(W, "dec.in_conv", x)
     if g is not None:
@@ -446,8 +473,10 @@ def vocos(W, cfg, z, g):
     x = conv1d(W, "dec.out_conv", x)
     mag, phase = x.chunk(2, dim=1)
     mag = mag.exp().clamp_max(max=1e2)
-    spec = mag * (phase.cos() + 1j * phase.sin())
     n_fft, hop, win = cfg["istft_n_fft"], cfg["istft_hop_length"], cfg["istft_win_length"]
+    if cfg.get("is_onnx", 0):
+        return onnx_stft_inverse(mag, phase, n_fft, hop, win)
+    spec = mag * (phase.cos() + 1j * phase.sin())
     o = torch.istft(spec, n_fft, hop, win, window=torch.hann_window(win), center=True,
                     normalized=False, onesided=True, length=None, return_complex=False)
     return o.unsqueeze(1)

@@ -52,6 +52,16 @@ CASES = {
     "tiny_mono_inter_b3": ("tiny_mono_inter", 40, 3, 3, 12, [12, 5, 9], 19, 109, (0.667, 1.0, 0.8)),
     # B = 1, noise-free: the call shape of the native C++ host (vits_model.cc:37-87 feeds one utterance)
     "tiny_sdp_b1_nonoise": ("tiny", 40, 3, 1, 14, [14], 20, 110, (0.0, 1.0, 0.0)),
+    # The model export_onnx.py builds (`hps['model']['is_onnx'] = True`, export_onnx.py:59): VocosGenerator ends in
+    # OnnxSTFT.inverse (utils/stft.py:325-340) instead of torchaudio's InverseSpectrogram (decoders.py:279-283,300-304).
+    # Same weights, inputs and noise as vocos_b2 / tiny_vocos_b2 (10th field: ctor overrides), so everything up to the
+    # spectrogram is shared and the two heads can be held side by side.  main() also asserts that export_forward -- the
+    # function the ONNX graph is traced from (export_onnx.py:82) -- returns this audio.
+    "vocos_onnx_b2": ("vocos", 64, 2, 2, 8, [8, 5], 23, 203, (0.667, 1.0, 0.8), dict(is_onnx=True)),
+    "tiny_vocos_onnx_b2": ("tiny_vocos", 40, 2, 2, 10, [10, 6], 15, 105, (0.667, 1.0, 0.8), dict(is_onnx=True)),
+    # B = 1, noise-free, exported arithmetic: what the native C++ host (the twin of vits_model.cc, which runs the
+    # exported graphs) must reproduce for a Vocos model
+    "tiny_vocos_onnx_b1_nonoise": ("tiny_vocos", 40, 2, 1, 14, [14], 27, 111, (0.0, 1.0, 0.0), dict(is_onnx=True)),
 }
 # Full-size cases (BASELINE.json configs[1]/[2] phoneme counts): these switch on the kernels the tiny
 # cases never reach -- MFMA text-encoder attention (Tx >= 64), the flash attention of the VITS2 flows,
@@ -79,13 +89,27 @@ BIG_CASES = {
     # live reference.  12.6 MB of audio + 9.5 MB of z would not be a small fixture, so the fixture keeps every 16th
     # audio sample and every 8th frame of z (10th / 11th field: strides) beside the full logw / y_mask / bit-packed attn
     "v1_b16x128": ("v1", 256, 1, 16, 128, [128] * 16, 39, 310, (0.667, 0.92, 0.8), None, (16, 8)),
+    # the reference's published-metric config (vits2_vocos_v1, runtime/cpu_triton_stream/README.md) AS EXPORTED
+    # (is_onnx=True, 12th field: ctor overrides); same weights / inputs / noise as vits2_vocos_b2x64
+    "vits2_vocos_onnx_b2x64": ("vits2_vocos_v1", 128, 1, 2, 64, [64, 49], 34, 304, (0.667, 1.0, 0.8), None, None,
+                               dict(is_onnx=True)),
+    # BASELINE.json configs[2] AT ITS BENCHED BATCH: multilingual v3, 64 x 128 phonemes, two speakers with sid
+    # alternating 0 / 1 (SURVEY 8d cfg 3), through the live reference at f32 -- the absolute anchor the bf16 line is
+    # held to.  Sub-sampled like v1_b16x128 (every 32nd audio sample, every 16th frame of z).
+    # 13th field: the length_scale is calibrated (a scan of +0.0005 steps above the nominal value, recorded in the
+    # fixture's `scales`) so that no duration w = exp(logw) * length_scale of the 8192 / 2048 phonemes sits within
+    # 1e-4 of an integer: ceil(w) is then the same on any f32 implementation (SURVEY 8d lets the builder pin the
+    # length scale), and alignment EQUALITY is a fair demand of the GPU path at this batch.
+    "v3_b64x128": ("v3", 256, 2, 64, 128, [128] * 64, 40, 311, (0.667, 1.0, 0.8), [0, 1] * 32, (32, 16), None, True),
+    # BASELINE.json configs[4] AT ITS BENCHED BATCH: the 48 kHz stress generator, 16 x 128 phonemes, f32 reference
+    "stress48k_b16x128": ("stress48k", 256, 1, 16, 128, [128] * 16, 41, 312, (0.667, 0.92, 0.8), None, (32, 8), None, True),
 }
 ONLY = os.environ.get("WETTS_GOLDEN_ONLY")  # comma-separated case names (default: all)
 
 
-def build_reference(model_name, n_vocab, n_speakers, sd):
+def build_reference(model_name, n_vocab, n_speakers, sd, overrides=None):
     SynthesizerTrn, _, _, _ = ref_import.import_reference()
-    model = dict(config.MODEL_CONFIGS[model_name])
+    model = dict(config.MODEL_CONFIGS[model_name], **(overrides or {}))
     with contextlib.redirect_stdout(io.StringIO()):
         net = SynthesizerTrn(n_vocab, 513, 32, n_speakers=n_speakers, **model).eval()
     missing, unexpected = net.load_state_dict(sd, strict=False)
@@ -93,7 +117,8 @@ def build_reference(model_name, n_vocab, n_speakers, sd):
     # everything the synthetic checkpoint does not carry must be outside the infer() path
     # (post_transformer: built by ResidualCouplingTransformersLayer but its use is commented out,
     # flows.py:152-154)
-    bad = [k for k in missing if not (k.startswith("enc_q.") or k.startswith("dp.post_")
+    # dec.stft.*: the two constant buffers OnnxSTFT registers (utils/stft.py:289-290), built by its ctor
+    bad = [k for k in missing if not (k.startswith("enc_q.") or k.startswith("dp.post_") or k.startswith("dec.stft.")
                                       or k.startswith("dp.flows.1.") or ".post_transformer." in k)]
     assert not bad, bad
     return net
@@ -135,10 +160,11 @@ def run_big_cases():
         mname, n_vocab, n_spk, B, Tx, lens, wseed, nseed, scales = spec[:9]
         if ONLY and name not in ONLY.split(","):
             continue
-        cfg = config.make_config(config.MODEL_CONFIGS[mname], n_vocab, n_spk)
+        ov = spec[11] if len(spec) > 11 else None  # ctor overrides (is_onnx=True)
+        cfg = config.make_config(dict(config.MODEL_CONFIGS[mname], **(ov or {})), n_vocab, n_spk)
         sd = synth.make_state_dict(cfg, wseed)
         blob = checkpoint.pack_blob(cfg, sd)
-        net = build_reference(mname, n_vocab, n_spk, sd)
+        net = build_reference(mname, n_vocab, n_spk, sd, ov)
         gi = torch.Generator().manual_seed(nseed + 7)
         x = torch.randint(0, n_vocab, (B, Tx), generator=gi)
         x_len = torch.tensor(lens, dtype=torch.long)
@@ -158,6 +184,22 @@ def run_big_cases():
             assert t.dim() == 3 and t.shape[0] == B and t.shape[1] == cfg.inter_channels  # models.py:267
             return big_noise(nseed, tuple(t.shape), "z")
 
+        if len(spec) > 12 and spec[12]:  # calibrate length_scale for the widest ceil() margin (see BIG_CASES)
+            with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()), \
+                    mock.patch.object(torch, "randn", fake_randn):
+                g0 = net.emb_g(sid).unsqueeze(-1) if net.n_speakers > 0 else None
+                xe0, _, _, xm0 = net.enc_p(x, x_len, g=g0)
+                lw0 = net.dp(xe0, xm0, g=g0, reverse=True, noise_scale=nsw) if net.use_sdp else net.dp(xe0, xm0, g=g0)
+            best = None
+            for k in range(41):
+                cand = float(np.float32(ls + 0.0005 * k))
+                w0 = torch.exp(lw0) * xm0 * cand
+                f0 = (torch.ceil(w0) - w0)[xm0 > 0]
+                m0 = float(torch.minimum(f0, 1 - f0).min())
+                if best is None or m0 > best[0]:
+                    best = (m0, cand)
+            ls = best[1]
+            scales = (ns, ls, nsw)
         with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()), \
                 mock.patch.object(torch, "randn", fake_randn), \
                 mock.patch.object(torch, "randn_like", fake_randn_like):
@@ -181,7 +223,7 @@ def run_big_cases():
         np.savez_compressed(
             os.path.join(OUT, name + ".npz"),
             model=mname, n_vocab=n_vocab, n_speakers=n_spk, weight_seed=wseed, noise_seed=nseed,
-            noise="randomstate", scales=np.array(scales, np.float64),
+            noise="randomstate", scales=np.array(scales, np.float64), is_onnx=int(cfg.is_onnx),
             blob_checksum=synth.blob_checksum(blob),
             x=x.numpy(), x_lengths=x_len.numpy(), sid=sid.numpy(), x_mask=x_mask.numpy(),
             # (the encoder's stage boundaries are pinned at this phoneme count by v1_b4x128; a sub-sampled fixture
@@ -199,13 +241,15 @@ def main():
         raise SystemExit("reference not present; golden vectors can only be generated in the "
                          "build container")
     torch.set_num_threads(1)
-    for name, (mname, n_vocab, n_spk, B, Tx, lens, wseed, nseed, scales) in CASES.items():
+    for name, spec in CASES.items():
+        mname, n_vocab, n_spk, B, Tx, lens, wseed, nseed, scales = spec[:9]
+        ov = spec[9] if len(spec) > 9 else None  # ctor overrides (is_onnx=True)
         if ONLY and name not in ONLY.split(","):
             continue
-        cfg = config.make_config(config.MODEL_CONFIGS[mname], n_vocab, n_spk)
+        cfg = config.make_config(dict(config.MODEL_CONFIGS[mname], **(ov or {})), n_vocab, n_spk)
         sd = synth.make_state_dict(cfg, wseed)
         blob = checkpoint.pack_blob(cfg, sd)
-        net = build_reference(mname, n_vocab, n_spk, sd)
+        net = build_reference(mname, n_vocab, n_spk, sd, ov)
         gi = torch.Generator().manual_seed(nseed + 7)
         x = torch.randint(0, n_vocab, (B, Tx), generator=gi)
         x_len = torch.tensor(lens, dtype=torch.long)
@@ -214,6 +258,12 @@ def main():
         torch.manual_seed(nseed)
         eps_w = torch.randn(B, 2, Tx) if cfg.use_sdp else torch.zeros(B, 2, Tx)
         o, attn, y_mask, z, z_p, m_pe, logs_pe = run_reference(net, x, x_len, sid, scales, nseed)
+        if ov and ov.get("is_onnx"):
+            # the function the exported graph is traced from (export_onnx.py:82): same draws, same audio
+            torch.manual_seed(nseed)
+            with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+                oe = net.export_forward(x, x_len, torch.tensor([list(scales)] * B), sid)
+            assert torch.equal(oe, o), "export_forward differs from infer() on the is_onnx model"
         Ty = z.shape[2]
         torch.manual_seed(nseed)
         if cfg.use_sdp:
@@ -231,7 +281,7 @@ def main():
         np.savez_compressed(
             os.path.join(OUT, name + ".npz"),
             model=mname, n_vocab=n_vocab, n_speakers=n_spk, weight_seed=wseed, noise_seed=nseed,
-            scales=np.array(scales, np.float64), blob_checksum=synth.blob_checksum(blob),
+            scales=np.array(scales, np.float64), blob_checksum=synth.blob_checksum(blob), is_onnx=int(cfg.is_onnx),
             x=x.numpy(), x_lengths=x_len.numpy(), sid=sid.numpy(),
             eps_w=eps_w.numpy(), eps_z=eps_z.numpy(),
             x_enc=xe.numpy(), m_p=m_p.numpy(), logs_p=logs_p.numpy(), x_mask=x_mask.numpy(),
@@ -246,6 +296,8 @@ def main():
     torch.set_num_threads(8)
     run_big_cases()
     if ONLY:
+        if "vocos_onnx_stream_kat" in ONLY.split(","):
+            vocos_onnx_stream_kat()
         return
     # MAS known-answer vectors from the reference's maximum_path (numba stub => plain Python)
     _, _, _, mas = ref_import.import_reference()
@@ -285,6 +337,53 @@ def main():
     print("generate_path_kat: ok")
     chunk_kat()
     chunk_kat_triton()
+    vocos_onnx_stream_kat()
+
+
+def vocos_onnx_stream_kat():
+    """The reference's streaming client on an EXPORTED Vocos model, end to end: the is_onnx=True reference module stands
+    for the two graphs (encoder = export_encoder_forward, decoder = export_decoder_forward, export_onnx.py:94,127),
+    and the chunk loop is inference_onnx.py:146-158 with its own get_chunks / depadding lifted from the file's AST.
+    Windows through OnnxSTFT.inverse have edges unlike torch.istft's (no envelope division), so what the
+    overlap-discard margins leave of them is part of the answer.  Stored: z [1,L,192] of one utterance, sid, the
+    streamed audio for (block, pad) = (40, 10) and (16, 4), and the one-window decode."""
+    import ast
+    import math
+    src = open(os.path.join(ref_import.REF_VITS, "inference_onnx.py")).read()
+    fns = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name in ("get_chunks", "depadding")]
+    ns = {"math": math, "np": np}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "inference_onnx.py", "exec"), ns)
+    mname, n_vocab, n_spk, wseed, nseed = "vits2_vocos_v1", 64, 1, 42, 313
+    ov = dict(is_onnx=True)
+    cfg = config.make_config(dict(config.MODEL_CONFIGS[mname], **ov), n_vocab, n_spk)
+    sd = synth.make_state_dict(cfg, wseed)
+    blob = checkpoint.pack_blob(cfg, sd)
+    net = build_reference(mname, n_vocab, n_spk, sd, ov)
+    gi = torch.Generator().manual_seed(nseed + 7)
+    x = torch.randint(0, n_vocab, (1, 17), generator=gi)
+    x_len = torch.tensor([17])
+    sid = torch.zeros(1, dtype=torch.long)
+    scales = torch.tensor([[0.667, 1.0, 0.8]])
+    torch.manual_seed(nseed)
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        z = net.export_encoder_forward(x, x_len, scales, sid)  # [1, L, 192]
+        whole = net.export_decoder_forward(z, sid)
+        hop = cfg.istft_hop_length
+        streams = {}
+        for block, pad in ((40, 10), (16, 4)):
+            chunks = ns["get_chunks"](z.numpy(), block, pad)
+            pieces = []
+            for i, ch in enumerate(chunks):
+                a = net.export_decoder_forward(torch.from_numpy(np.ascontiguousarray(ch)), sid)[0].numpy()
+                pieces.append(ns["depadding"](a, len(chunks), i, block, pad, hop))
+            streams[f"stream_{block}_{pad}"] = np.concatenate(pieces, axis=1)
+    L = z.shape[1]
+    assert all(v.shape[1] == L * hop for v in streams.values())
+    np.savez_compressed(os.path.join(OUT, "vocos_onnx_stream_kat.npz"), model=mname, n_vocab=n_vocab, n_speakers=n_spk,
+                        weight_seed=wseed, blob_checksum=synth.blob_checksum(blob), is_onnx=1, z=z.numpy(),
+                        sid=sid.numpy(), whole=whole.numpy(), **streams)
+    print(f"vocos_onnx_stream_kat: L={L} frames, {L * hop} samples, whole-vs-stream rms "
+          + ", ".join(f"{k}: {float(np.sqrt(np.mean((v - whole[0].numpy()) ** 2))):.2e}" for k, v in streams.items()))
 
 
 def chunk_kat():

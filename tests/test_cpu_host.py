@@ -398,3 +398,39 @@ def test_mrf_mean_quotient_is_the_ieee_division_for_every_float(tmp_path):
     for d in ("3", "2"):
         bad, zsign = (int(v) for v in subprocess.check_output([exe, d], timeout=600).split())
         assert bad == 0 and zsign == 1, (d, bad, zsign)
+
+
+def test_is_onnx_is_a_constructor_argument_not_an_ignored_kwarg():
+    """models.py:50,111: `is_onnx` selects VocosGenerator's iSTFT (decoders.py:279-283); export_onnx.py:59 sets it for
+    every exported graph.  It must reach the C config, be switchable, and show in state_dict() as the reference's two
+    OnnxSTFT buffers; a HiFi-GAN model takes it without effect (the reference's Generator has no such argument)."""
+    from oracle import vits_oracle as vo
+    from wetts_amd import SynthesizerTrn
+    assert config.make_config(config.MODEL_CONFIGS["vocos"], 10, 1).is_onnx == 0
+    assert config.make_config(dict(config.MODEL_CONFIGS["vocos"], is_onnx=True), 10, 1).is_onnx == 1
+    assert config.make_config(dict(config.MODEL_CONFIGS["v1"], is_onnx=True), 10, 1).is_onnx == 1
+    net = SynthesizerTrn(40, 513, 32, n_speakers=2, **dict(config.MODEL_CONFIGS["tiny_vocos"], is_onnx=True))
+    assert net.is_onnx is True and net.cfg.is_onnx == 1
+    sd = synth.make_state_dict(net.cfg, 3)
+    net.load_state_dict(sd)
+    out = net.state_dict()
+    inv = vo.onnx_stft_inverse_basis(64, 16, 64)
+    assert tuple(out["dec.stft.inverse_basis"].shape) == (66, 1, 64) == tuple(out["dec.stft.forward_basis"].shape)
+    assert float((out["dec.stft.inverse_basis"] - inv).abs().max()) < 1e-9
+    net.set_is_onnx(False)
+    assert net.cfg.is_onnx == 0 and "dec.stft.inverse_basis" not in net.state_dict()
+    # a checkpoint saved from an is_onnx module carries the buffers: loading it must not trip on them
+    net.load_state_dict(dict(sd, **{"dec.stft.inverse_basis": inv, "dec.stft.forward_basis": inv}))
+    from oracle import ref_import
+    if ref_import.available():
+        Ref, *_ = ref_import.import_reference()
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref = Ref(40, 513, 32, n_speakers=2, **dict(config.MODEL_CONFIGS["tiny_vocos"], is_onnx=True)).eval()
+        rsd = ref.state_dict()
+        net.set_is_onnx(True)
+        out = net.state_dict()
+        for k in ("dec.stft.forward_basis", "dec.stft.inverse_basis"):
+            assert tuple(rsd[k].shape) == tuple(out[k].shape)
+            assert float((rsd[k] - out[k]).abs().max()) < 1e-8, k

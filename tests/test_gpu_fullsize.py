@@ -83,14 +83,15 @@ def test_v1_b16x128_properties_and_oracle_spot_check():
         assert util.rms(o[sub[i]].cpu().numpy() - ref["o"][i].numpy()) < 1e-4
 
 
-def test_v1_b16x128_matches_the_reference_at_the_benched_batch():
-    """BASELINE.json configs[1] AT THE BATCH bench.py RUNS -- 16 x 128 phonemes, all full length, length_scale 0.92 --
-    against the live reference's own infer() (tests/golden/v1_b16x128.npz; the fixture keeps every 16th audio sample and
-    every 8th frame of z beside the full durations, mask and alignment): durations to 1e-4, y_mask / alignment EQUAL,
-    z and audio on the sub-sampled grid within the 1e-4 abs-RMS gate, and the full audio's sum / energy."""
-    case = util.load_case("v1_b16x128")
+def _strided_case_run(name, dtype=None, flow16=False):
+    """infer() of a sub-sampled full-batch fixture on its own inputs and noise -> (case, outputs, error rows)."""
+    case = util.load_case(name)
     cfg, sd, W, _ = util.case_model(case)
-    net, _ = _net("v1", int(case["n_vocab"]), int(case["n_speakers"]), sd=sd)
+    net, _ = _net(str(case["model"]), int(case["n_vocab"]), int(case["n_speakers"]), sd=sd)
+    if dtype is not None:
+        net.set_decoder_dtype(dtype)
+        if flow16:
+            net.set_flow_dtype(dtype)
     ns, ls, nsw = [float(v) for v in case["scales"]]
     o, attn, ym, (z, z_p, m_p, logs_p) = net.infer(
         util.t(case["x"]).cuda(), util.t(case["x_lengths"]).cuda(), sid=util.t(case["sid"]).cuda(), noise_scale=ns,
@@ -104,14 +105,41 @@ def test_v1_b16x128_matches_the_reference_at_the_benched_batch():
     assert np.array_equal(ym.cpu().numpy(), case["y_mask"])
     assert np.array_equal(attn.cpu().numpy().astype(np.uint8), case["attn"])
     on = o.cpu().numpy()
-    e_z = util.rel_rms(z.cpu().numpy()[..., ::sz], case["z_sub"])
-    e_a = util.rms(on[..., ::sa] - case["audio_sub"])
-    rel_a = util.rel_rms(on[..., ::sa], case["audio_sub"])
-    e_sum = abs(float(on.astype(np.float64).sum()) - float(case["audio_sum"])) / on.size
-    e_sq = abs(float((on.astype(np.float64) ** 2).sum()) / float(case["audio_sqsum"]) - 1.0)
-    print("v1 B=16x128 vs the reference golden: logw max", logw_err, "z rel rms", e_z, "audio abs rms", e_a, "rel", rel_a,
-          "mean err", e_sum, "energy rel err", e_sq)
-    assert e_z < 2e-4 and e_a < 1e-4 and rel_a < 2e-3 and e_sum < 1e-6 and e_sq < 1e-4
+    rows = dict(logw_max=logw_err, z_rel=util.rel_rms(z.cpu().numpy()[..., ::sz], case["z_sub"]),
+                audio_abs=util.rms(on[..., ::sa] - case["audio_sub"]), audio_rel=util.rel_rms(on[..., ::sa], case["audio_sub"]),
+                mean_err=abs(float(on.astype(np.float64).sum()) - float(case["audio_sum"])) / on.size,
+                energy_rel=abs(float((on.astype(np.float64) ** 2).sum()) / float(case["audio_sqsum"]) - 1.0),
+                ref_rms=util.rms(case["audio_sub"]))
+    return case, rows
+
+
+@pytest.mark.parametrize("name", util.STRIDED_CASES)
+def test_benched_batch_matches_the_reference_at_f32(name):
+    """BASELINE.json configs[1] / [2] / [4] AT THE BATCH bench.py RUNS THEM -- v1 16 x 128, v3 64 x 128 with two speakers
+    (sid alternating), stress48k 16 x 128, all full length -- against the live reference's own f32 infer()
+    (tests/golden/{v1_b16x128,v3_b64x128,stress48k_b16x128}.npz; the fixtures keep every 16th / 32nd audio sample and
+    every 8th / 16th frame of z beside the full durations, mask and alignment): durations to 1e-4, y_mask / alignment
+    EQUAL, z and audio on the sub-sampled grid within the 1e-4 abs-RMS gate (north_star: 1e-3), and the full audio's
+    sum / energy."""
+    case, r = _strided_case_run(name)
+    print(name, "f32 vs the reference golden:", r)
+    assert r["z_rel"] < 2e-4 and r["audio_abs"] < 1e-4 and r["audio_rel"] < 2e-3 and r["mean_err"] < 1e-6 and r["energy_rel"] < 1e-4
+
+
+# absolute waveform RMS error of the 16-bit lines vs the REFERENCE's f32 audio, as bench.py runs them (decoder + flow at
+# 16 bit): the stated gates.  north_star's 1e-3 is set for f32; bf16 (8 bits of mantissa through ~30 stacked convs) is
+# held to 2e-3 absolute at a reference RMS of 0.112 (measured 7-8e-4), f16 to 5e-4 at 0.137 (measured 1.6e-4).
+REDUCED_VS_REFERENCE = [("v3_b64x128", torch.bfloat16, 2e-3, 2e-2), ("stress48k_b16x128", torch.float16, 5e-4, 4e-3)]
+
+
+@pytest.mark.parametrize("name,dtype,abs_gate,rel_gate", REDUCED_VS_REFERENCE)
+def test_benched_batch_at_its_benched_precision_vs_the_reference(name, dtype, abs_gate, rel_gate):
+    """configs[2] (bf16) and configs[4] (f16) at their benched batch AND precision against the live reference's f32
+    golden -- an absolute anchor, not the HIP f32 run: alignment EQUAL (the duration path stays f32), audio within the
+    stated absolute RMS on the sub-sampled grid."""
+    case, r = _strided_case_run(name, dtype, flow16=True)
+    print(name, str(dtype), "decoder + flow vs the reference f32 golden:", r)
+    assert r["audio_abs"] < abs_gate and r["audio_rel"] < rel_gate and r["energy_rel"] < 5e-2
 
 
 def test_v3_b64_speaker_path_and_ragged_b64():

@@ -24,17 +24,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TINY_RF = 19
 
 
-@pytest.mark.parametrize("chunk,pad", [(16, 20), (16, 12), (40, 10)])
-def test_native_vits_model_forward_and_stream_vs_reference_golden(tmp_path, chunk, pad):
+# Vocos "tiny_vocos" head: 2 ConvNeXt layers (depthwise k3: 1 frame each), the reflection pad's shift (1), the iSTFT's
+# overlap (n_fft / hop / 2 = 2 frames per side) => < 8 frames
+TINY_VOCOS_RF = 8
+
+
+@pytest.mark.parametrize("cname,rf,chunk,pad", [("tiny_sdp_b1_nonoise", TINY_RF, 16, 20), ("tiny_sdp_b1_nonoise", TINY_RF, 16, 12),
+                                                ("tiny_sdp_b1_nonoise", TINY_RF, 40, 10),
+                                                # a Vocos model: the class stands where the EXPORTED graphs stood, so it must
+                                                # reproduce the is_onnx=True reference (OnnxSTFT.inverse) from a plain config
+                                                ("tiny_vocos_onnx_b1_nonoise", TINY_VOCOS_RF, 16, 8),
+                                                ("tiny_vocos_onnx_b1_nonoise", TINY_VOCOS_RF, 40, 10)])
+def test_native_vits_model_forward_and_stream_vs_reference_golden(tmp_path, cname, rf, chunk, pad):
     """pad >= the receptive field: EVERY streamed sample is interior (the streamed waveform equals the one-shot
     decode and the reference golden); pad < RF (incl. the reference's defaults 40 / 10): the samples whose window
     covers their receptive field."""
     from wetts_amd import build
     exe = os.path.join(build.LIBDIR, "vits_model_main")
     assert os.path.exists(exe), "native test host not built (run __graft_entry__.build())"
-    case = util.load_case("tiny_sdp_b1_nonoise")
+    case = util.load_case(cname)
     assert case["x"].shape[0] == 1 and tuple(case["scales"]) == (0.0, 1.0, 0.0)
     cfg, sd, W, blob = util.case_model(case)
+    cfg.is_onnx = 0  # the native class selects the exported graphs' iSTFT itself (wetts_vits_model.hpp ctor)
     n = int(case["x_lengths"][0])
     ph = case["x"][0, :n].astype(np.int64)
     sid = int(case["sid"][0])
@@ -51,10 +62,10 @@ def test_native_vits_model_forward_and_stream_vs_reference_golden(tmp_path, chun
         f.write(expect.tobytes())
     env = dict(os.environ, LD_LIBRARY_PATH=build.LIBDIR + ":/opt/rocm/lib:" +
                os.environ.get("LD_LIBRARY_PATH", ""))
-    r = subprocess.run([exe, str(path), str(chunk), str(pad), str(TINY_RF)], capture_output=True, text=True,
+    r = subprocess.run([exe, str(path), str(chunk), str(pad), str(rf)], capture_output=True, text=True,
                        env=env, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
-    if pad >= TINY_RF:  # all samples interior
+    if pad >= rf:  # all samples interior
         fields = dict(kv.split("=") for kv in r.stdout.split() if "=" in kv)
         assert float(fields["all_worst"]) < 1e-4

@@ -20,9 +20,8 @@ ABS_RMS_OURS = 1e-4
 def _model(case):
     from wetts_amd import SynthesizerTrn, config
     cfg, sd, W, blob = util.case_model(case)
-    mname = str(case["model"])
     net = SynthesizerTrn(int(case["n_vocab"]), 513, 32, n_speakers=int(case["n_speakers"]),
-                         **config.MODEL_CONFIGS[mname])
+                         **util.model_dict(case))
     net.load_state_dict(sd)
     net.to("cuda")
     return net, cfg, W

@@ -37,10 +37,12 @@ def test_infer_matches_reference(name):
     assert util.rel_rms(st["o"].numpy(), case["audio"]) < 2e-4
 
 
-def test_infer_matches_reference_at_the_benched_batch():
-    """configs[1] at 16 x 128 phonemes (the sub-sampled fixture v1_b16x128): the oracle against the live reference's
-    durations, alignment and the strided z / audio views (~20 s of CPU)."""
-    case = util.load_case("v1_b16x128")
+@pytest.mark.parametrize("name", util.STRIDED_CASES)
+def test_infer_matches_reference_at_the_benched_batch(name):
+    """BASELINE configs[1] / [2] / [4] at their benched batch (the sub-sampled fixtures v1_b16x128, v3_b64x128,
+    stress48k_b16x128): the oracle against the live reference's durations, alignment and the strided z / audio views
+    (~20-40 s of CPU each)."""
+    case = util.load_case(name)
     cfg, _, W, _ = util.case_model(case)
     ns, ls, nsw = [float(v) for v in case["scales"]]
     torch.set_num_threads(8)
@@ -55,6 +57,41 @@ def test_infer_matches_reference_at_the_benched_batch():
     assert util.rel_rms(st["z"].numpy()[..., ::sz], case["z_sub"]) < 5e-5
     assert util.rms(st["o"].numpy()[..., ::sa] - case["audio_sub"]) < 2e-5
     assert abs(float(st["o"].double().pow(2).sum()) / float(case["audio_sqsum"]) - 1.0) < 1e-5
+
+
+def test_onnx_stft_head_is_0375_of_torch_istft_in_the_interior_and_differs_at_the_edges():
+    """The two Vocos heads side by side on the SAME model and noise (vocos_b2 / vocos_onnx_b2 share weights, inputs and
+    draws): OnnxSTFT.inverse has no window-envelope division, so at hop = n_fft / 4 (sum of hann^2 = 1.5, scale = 4) its
+    interior is 0.375 x the torch.istft audio; the first / last n_fft/2 samples differ in shape."""
+    a, b = util.load_case("vocos_b2"), util.load_case("vocos_onnx_b2")
+    assert np.array_equal(a["z"], b["z"]) and int(b["is_onnx"]) == 1
+    nf = 1024
+    ta, tb = a["audio"][0, 0], b["audio"][0, 0]
+    assert util.rel_rms(tb[nf:-nf], 0.375 * ta[nf:-nf]) < 1e-5
+    assert util.rel_rms(tb[:nf // 2], 0.375 * ta[:nf // 2]) > 1e-2
+
+
+def test_oracle_streams_the_exported_vocos_model_like_the_references_client():
+    """vocos_onnx_stream_kat.npz (the reference's chunk loop over export_decoder_forward of an is_onnx module): the
+    oracle's decoder on the windows of session.get_chunks, cut by session.depad_bounds, reproduces the stream."""
+    from wetts_amd import session
+    case = util.load_case("vocos_onnx_stream_kat")
+    cfg, _, W, _ = util.case_model(case)
+    cd = util.cfg_dict(cfg)
+    assert cd["is_onnx"] == 1
+    z = util.t(case["z"]).transpose(1, 2)
+    g = torch.nn.functional.embedding(util.t(case["sid"]), W["emb_g.weight"]).unsqueeze(-1)
+    hop = cfg.istft_hop_length
+    with torch.no_grad():
+        assert util.rms(vo.decoder(W, cd, z, g).numpy() - case["whole"]) < 2e-6
+        for block, pad in ((40, 10), (16, 4)):
+            wins = session.get_chunks(z.shape[2], block, pad)
+            pieces = []
+            for i, (ws, we) in enumerate(wins):
+                a = vo.decoder(W, cd, z[:, :, ws:we], g).numpy().reshape(1, -1)
+                lo, hi = session.depad_bounds(len(wins), i, block, pad, hop, a.shape[1])
+                pieces.append(a[:, lo:hi])
+            assert util.rms(np.concatenate(pieces, axis=1) - case[f"stream_{block}_{pad}"]) < 2e-6
 
 
 def test_mas_known_answers():

@@ -22,13 +22,17 @@ INFER_CASES = ["tiny_sdp_b3", "tiny_dp_b2", "tiny_sdp_nonoise", "tiny_sdp_single
                # examples/*/configs/v2.json (ResBlock1 stages of 64 / 32 / 16 / 8 channels) at 8 and at 128 phonemes
                "v2_b2", "v2_b4x128",
                "vits2_v1_b2",  # examples/baker/configs/vits2_v1.json: pre_conv flows + HiFi-GAN v1
-               "stress48k_b2"]  # BASELINE configs[4] generator (hop 512, [8,8,4,2]) at f32 vs the live reference
+               "stress48k_b2",  # BASELINE configs[4] generator (hop 512, [8,8,4,2]) at f32 vs the live reference
+               # is_onnx=True models -- what export_onnx.py builds (export_onnx.py:59): the Vocos head ends in
+               # OnnxSTFT.inverse (utils/stft.py:325-340), not torch.istft
+               "vocos_onnx_b2", "tiny_vocos_onnx_b2", "tiny_vocos_onnx_b1_nonoise", "vits2_vocos_onnx_b2x64"]
 # every committed golden is a GPU parity case (round 5): nothing is held against the oracle only
 ORACLE_ONLY_CASES = []
 # sub-sampled full-batch fixtures (make_golden.py: every 16th audio sample, every 8th frame of z): own tests
-STRIDED_CASES = ["v1_b16x128"]  # BASELINE configs[1] at its benched batch, 16 x 128 phonemes
+# BASELINE configs[1] / [2] / [4] at their benched batch: 16 x 128 (v1), 64 x 128 two speakers (v3), 16 x 128 (stress48k)
+STRIDED_CASES = ["v1_b16x128", "v3_b64x128", "stress48k_b16x128"]
 BIG_CASES = ["v1_b4x128", "v3_b3x128", "vits2_vocos_b2x64", "aishell3_b4x128", "tiny_mono_post_b2x64", "v2_b4x128",
-             "stress48k_b2"]
+             "stress48k_b2", "vits2_vocos_onnx_b2x64"]
 
 
 def big_case_noise(seed, shape, which):
@@ -51,11 +55,19 @@ def load_case(name):
     return c
 
 
+def model_dict(case):
+    """The `hps.model` dict of a golden case: the named config plus the ctor overrides the fixture records
+    (is_onnx=True: the model export_onnx.py builds, export_onnx.py:59)."""
+    m = dict(config.MODEL_CONFIGS[str(case["model"])])
+    if "is_onnx" in case and int(case["is_onnx"]):
+        m["is_onnx"] = True
+    return m
+
+
 def case_model(case):
     """(cfg struct, reference-keyed state_dict, folded weights dict, blob) of a golden case."""
     mname = str(case["model"])
-    cfg = config.make_config(config.MODEL_CONFIGS[mname], int(case["n_vocab"]),
-                             int(case["n_speakers"]))
+    cfg = config.make_config(model_dict(case), int(case["n_vocab"]), int(case["n_speakers"]))
     sd = synth.make_state_dict(cfg, int(case["weight_seed"]))
     blob = checkpoint.pack_blob(cfg, sd)
     assert abs(synth.blob_checksum(blob) - float(case["blob_checksum"])) <= \
@@ -77,7 +89,7 @@ def cfg_dict(cfg):
         resblock=cfg.resblock, vocoder_type=cfg.vocoder_type, vocos_num_layers=cfg.vocos_num_layers,
         istft_n_fft=cfg.istft_n_fft, istft_hop_length=cfg.istft_hop_length,
         istft_win_length=cfg.istft_win_length, transformer_flows=cfg.transformer_flows,
-        use_spk_conditioned_encoder=cfg.use_spk_conditioned_encoder,
+        use_spk_conditioned_encoder=cfg.use_spk_conditioned_encoder, is_onnx=int(cfg.is_onnx),
         resblock_kernel_sizes=[cfg.resblock_kernel_sizes[j] for j in range(nk)],
         resblock_dilation_sizes=[[cfg.resblock_dilation_sizes[j][i] for i in range(nd)]
                                  for j in range(nk)],

@@ -17,6 +17,10 @@ for f in files:
             mm = re.search(r"conv_mfma_kernel<\d+, \d+, \d+, \d+, \d+, (true|false)", name)
             if not ((mm and mm.group(1) == "true") or "conv_mfma_group_kernel" in name or "resblock_chain32_kernel" in name):
                 continue
+        elif len(sys.argv) >= 3 and sys.argv[2].startswith("re:"):  # any class: a regular expression on the kernel name
+            import re
+            if not re.search(sys.argv[2][3:], name):
+                continue
         elif "conv_mfma" not in name and len(sys.argv) < 3:
             continue
         key = (name[:70], row.get("Grid_Size", ""), row.get("LDS_Block_Size", ""))

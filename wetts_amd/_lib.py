@@ -22,7 +22,7 @@ class WettsError(RuntimeError):
     pass
 
 
-ABI_VERSION = 8  # WETTS_ABI_VERSION of include/wetts_hip.h this binding was written against
+ABI_VERSION = 9  # WETTS_ABI_VERSION of include/wetts_hip.h this binding was written against
 
 
 class Config(C.Structure):
@@ -62,7 +62,8 @@ class Config(C.Structure):
         ("istft_win_length", C.c_int32),
         ("transformer_flows", C.c_int32),
         ("use_spk_conditioned_encoder", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("is_onnx", C.c_int32),
+        ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -102,6 +103,8 @@ SIGNATURES = {
     "wetts_hifigan_ragged": (_I32, [_P, _P, _I64, _I64, _P, _P, _I32, _I32, _P, _P, _I64, _P]),
     "wetts_set_decoder_precision": (_I32, [_P, _I32]),
     "wetts_set_flow_precision": (_I32, [_P, _I32]),
+    "wetts_set_istft_mode": (_I32, [_P, _I32]),
+    "wetts_get_istft_mode": (_I32, [_P]),
     "wetts_dynamic_quant_conv1d": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "wetts_mas": (_I32, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _I64, _P]),
     "wetts_audio_to_int16": (_I32, [_P, _P, _I32, _I64, _P, _P]),

@@ -149,9 +149,11 @@ _UNSUPPORTED = {}  # option -> reason; every option of the reference's configs i
 def make_config(model, n_vocab, n_speakers):
     """`hps.model` (dict or HParams) + vocabulary / speaker counts -> wetts_config_t.
 
-    Argument meaning follows SynthesizerTrn.__init__ (models.py:19-51); unknown keys are ignored
-    exactly like the reference's **kwargs; options that switch to code paths outside the scoped hot
-    path raise instead of silently computing something else.
+    Argument meaning follows SynthesizerTrn.__init__ (models.py:19-51); keys the reference's ctor does not
+    name either are ignored exactly like its **kwargs; options that switch to code paths outside the scoped hot
+    path raise instead of silently computing something else.  `is_onnx` (models.py:50,111) IS a ctor argument of
+    the reference: it selects the Vocos head's iSTFT (decoders.py:279-283,300-304) and is carried into the
+    config; a HiFi-GAN model accepts it without effect, as in the reference.
     """
     for k, why in _UNSUPPORTED.items():
         if _get(model, k, False):
@@ -193,6 +195,7 @@ def make_config(model, n_vocab, n_speakers):
         if out_ch != c.istft_n_fft + 2:
             raise ValueError(f"vocos_out_channels={out_ch} must be n_fft + 2 = {c.istft_n_fft + 2} "
                              "(magnitude and phase of n_fft/2+1 bins, decoders.py:296)")
+    c.is_onnx = 1 if _get(model, "is_onnx", False) else 0  # `if self.is_onnx:` (decoders.py:279,300)
     c.n_vocab = int(n_vocab)
     c.inter_channels = int(_get(model, "inter_channels"))
     c.hidden_channels = int(_get(model, "hidden_channels"))

@@ -108,7 +108,9 @@ int32_t k_vocos_pad(const float* z, int64_t z_bs, int64_t z_cs, const float* mas
 //   ri_bs: batch stride of ri (rows beyond 2 * half are the caller's padding of the iSTFT GEMM's reduction)
 int32_t k_vocos_spec(const float* spec, int B, int half, int F, float* ri, hipStream_t s, int64_t ri_bs = 0);
 // windowed inverse-rDFT basis as a 1x1 conv weight [n_fft][2*half]: frame[n] = hann[n] * irfft(S)[n]
-int32_t k_istft_basis(int n_fft, float* w, hipStream_t s);
+//   inv_scale != 0: OnnxSTFT's inverse_basis (utils/stft.py:272-290) = float32(irfft * inv_scale) * float32(hann),
+//   inv_scale = hop / n_fft
+int32_t k_istft_basis(int n_fft, float* w, hipStream_t s, double inv_scale = 0.0);
 // ConvNeXtLayer front half (decoders.py:241-243): out = LayerNorm_C(dw_conv k3 (x)) in one pass (rows of stride T,
 // zero padding from column Tvalid); false = shape not covered, run k_dwconv + k_layernorm
 bool k_convnext_dwln(const float* x, const float* w, const float* wb, const float* gamma, const float* beta, int B, int C,
@@ -116,8 +118,9 @@ bool k_convnext_dwln(const float* x, const float* w, const float* wb, const floa
 // overlap-add + window-envelope normalisation + centre trim of torch.istft (center=True):
 // frames [B, n_fft, F] -> audio [B, (F-1)*hop]
 //   Fs: row stride of frames (>= F)
+//   envelope = 0: OnnxSTFT.inverse (utils/stft.py:325-340) -- the same overlap-add and trim, no envelope division
 int32_t k_istft_ola(const float* frames, int B, int n_fft, int hop, int F, float* audio,
-                    hipStream_t s, int Fs = 0);
+                    hipStream_t s, int Fs = 0, int envelope = 1);
 // out[r, :] = a[r, :] * scale[r]   (rows x cols), folds ConvNeXtLayer.scale into pw_conv2
 int32_t k_scale_rows(const float* a, const float* scale, int rows, int cols, float* out,
                      hipStream_t s);

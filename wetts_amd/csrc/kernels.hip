@@ -1015,7 +1015,13 @@ int32_t k_vocos_spec(const float* spec, int B, int half, int F, float* ri, hipSt
 // w[n][c]: c < half -> coefficient of Re S[c]; c >= half -> coefficient of Im S[c-half]
 //   irfft: x[n] = (1/N) sum_k a_k (Re S_k cos(2 pi k n / N) - Im S_k sin(2 pi k n / N)),
 //   a_0 = a_{N/2} = 1, else 2; times the periodic hann window (torch.hann_window default)
-__global__ void istft_basis_kernel(int n_fft, float* __restrict__ w) {
+// inv_scale != 0 selects OnnxSTFT's inverse basis (utils/stft.py:272-290): pinv(scale * F)^T * hann with F the
+// stacked [Re; Im] rows 0..N/2 of the DFT matrix and scale = n_fft / hop.  F^T F = (N/2) I + (1 1^T + a a^T) / 2
+// (a_n = (-1)^n), whose inverse is (2/N) I - (1 1^T + a a^T) / N^2, so pinv(F) = (F^T F)^-1 F^T is EXACTLY the irfft
+// matrix above (weights 1, 2, .., 2, 1 over N; the Im rows of k = 0 and N/2 are zero) and pinv(scale F) = irfft /
+// scale.  The reference rounds the float64 pinv to float32 and multiplies by the float32 window in float32
+// (stft.py:279-287); the same two roundings are made here.
+__global__ void istft_basis_kernel(int n_fft, double inv_scale, float* __restrict__ w) {
   const int half = n_fft / 2 + 1;
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)n_fft * 2 * half) return;
@@ -1028,16 +1034,20 @@ __global__ void istft_basis_kernel(int n_fft, float* __restrict__ w) {
   // reduce k*n mod N before the trig call to keep the argument small
   const double ang = pi2 * (double)((int64_t)k * n % n_fft) / n_fft;
   const double v = c < half ? cos(ang) : -sin(ang);
-  w[idx] = (float)(win * a * v / n_fft);
+  if (inv_scale != 0.0)
+    w[idx] = (float)(a * v / n_fft * inv_scale) * (float)win;
+  else
+    w[idx] = (float)(win * a * v / n_fft);
 }
 
-int32_t k_istft_basis(int n_fft, float* w, hipStream_t s) {
+int32_t k_istft_basis(int n_fft, float* w, hipStream_t s, double inv_scale) {
   int64_t n = (int64_t)n_fft * (n_fft + 2);
-  hipLaunchKernelGGL(istft_basis_kernel, grid1d(n, 256), dim3(256), 0, s, n_fft, w);
+  hipLaunchKernelGGL(istft_basis_kernel, grid1d(n, 256), dim3(256), 0, s, n_fft, inv_scale, w);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }
 
+template <bool ENV>
 __global__ void istft_ola_kernel(const float* __restrict__ frames, int B, int n_fft, int hop, int F, int Fs,
                                  float* __restrict__ audio) {
   const int64_t Ls = (int64_t)(F - 1) * hop;
@@ -1056,18 +1066,26 @@ __global__ void istft_ola_kernel(const float* __restrict__ frames, int B, int n_
   for (int64_t f = f_lo; f <= f_hi; ++f) {
     const int j = (int)(m - f * hop);  // 0 <= j < n_fft
     y += fb[(int64_t)j * Fs + f];
-    const float wv = 0.5f - 0.5f * cosf(pi2 * (float)j / (float)n_fft);
-    env += wv * wv;
+    if (ENV) {
+      const float wv = 0.5f - 0.5f * cosf(pi2 * (float)j / (float)n_fft);
+      env += wv * wv;
+    }
   }
-  audio[idx] = y / env;  // torch.istft: y / window_envelope (asserted > 1e-11 there)
+  // torch.istft: y / window_envelope (asserted > 1e-11 there); OnnxSTFT.inverse (stft.py:325-340): the bare
+  // overlap-add of conv_transpose1d, trimmed
+  audio[idx] = ENV ? y / env : y;
 }
 
 int32_t k_istft_ola(const float* frames, int B, int n_fft, int hop, int F, float* audio,
-                    hipStream_t s, int Fs) {
+                    hipStream_t s, int Fs, int envelope) {
   int64_t n = (int64_t)B * (F - 1) * hop;
   if (n <= 0) return WETTS_OK;
-  hipLaunchKernelGGL(istft_ola_kernel, grid1d(n, 256), dim3(256), 0, s, frames, B, n_fft, hop, F,
-                     Fs > 0 ? Fs : F, audio);
+  if (envelope)
+    hipLaunchKernelGGL(istft_ola_kernel<true>, grid1d(n, 256), dim3(256), 0, s, frames, B, n_fft, hop, F,
+                       Fs > 0 ? Fs : F, audio);
+  else
+    hipLaunchKernelGGL(istft_ola_kernel<false>, grid1d(n, 256), dim3(256), 0, s, frames, B, n_fft, hop, F,
+                       Fs > 0 ? Fs : F, audio);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

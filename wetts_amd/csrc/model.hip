@@ -100,6 +100,7 @@ static int validate_config(const wetts_config_t* c) {
                     (c->n_speakers > 0 && c->gin_channels > 0 && c->n_layers > 2),
                 "speaker-conditioned encoder needs speakers, gin_channels and n_layers > 2 "
                 "(cond_layer_idx = 2, attentions.py:44-48)");
+  WETTS_REQUIRE(c->is_onnx == 0 || c->is_onnx == 1, "is_onnx must be 0 or 1");
   if (c->vocoder_type == 1) {
     WETTS_REQUIRE(c->vocos_channels > 0 && c->vocos_h_channels > 0 && c->vocos_num_layers >= 1 &&
                       c->vocos_num_layers <= 64, "bad vocos channels / layers");
@@ -401,7 +402,8 @@ struct wetts_model {
   const float *dec_cond_w = nullptr, *dec_cond_b = nullptr;
   int hop = 1;
   // vocos decoder
-  PackedConv v_in, v_out, v_istft;
+  PackedConv v_in, v_out, v_istft, v_istft_onnx;
+  mutable int istft_mode = 0;  // WETTS_ISTFT_TORCH / WETTS_ISTFT_ONNX (cfg.is_onnx at create, wetts_set_istft_mode)
   std::vector<ConvNeXt> v_layers;
   const float *v_npre_g = nullptr, *v_npre_b = nullptr, *v_npost_g = nullptr, *v_npost_b = nullptr;
   std::vector<float*> v_owned;  // device buffers built at create (scaled pw2 weights, iSTFT basis)
@@ -600,6 +602,14 @@ static int32_t build_vocos(wetts_model* m, hipStream_t s) {
   WETTS_TRY(k_istft_basis(NF, basis, s));
   WETTS_TRY(pack_conv_weight(basis, nullptr, NF, VO, 1, 1, 0, 0, 0, s, &m->v_istft));
   m->all_packed.push_back(&m->v_istft);
+  // the second head: OnnxSTFT's inverse basis (utils/stft.py:272-290), used when the model is_onnx
+  float* basis_onnx = nullptr;
+  WETTS_HIP_CHECK(hipMalloc((void**)&basis_onnx, (size_t)NF * VO * sizeof(float)));
+  m->v_owned.push_back(basis_onnx);
+  WETTS_TRY(k_istft_basis(NF, basis_onnx, s, (double)c->istft_hop_length / (double)NF));
+  WETTS_TRY(pack_conv_weight(basis_onnx, nullptr, NF, VO, 1, 1, 0, 0, 0, s, &m->v_istft_onnx));
+  m->all_packed.push_back(&m->v_istft_onnx);
+  m->istft_mode = c->is_onnx ? WETTS_ISTFT_ONNX : WETTS_ISTFT_TORCH;
   m->hop = c->istft_hop_length;
   return WETTS_OK;
 }
@@ -1017,6 +1027,15 @@ void wetts_destroy(wetts_model_t* m) {
 }
 
 int32_t wetts_hop_length(const wetts_model_t* m) { return m ? m->hop : WETTS_E_INVALID; }
+
+int32_t wetts_set_istft_mode(const wetts_model_t* m, int32_t mode) {
+  WETTS_REQUIRE(m, "null model");
+  WETTS_REQUIRE(mode == WETTS_ISTFT_TORCH || mode == WETTS_ISTFT_ONNX, "istft mode must be 0 (torch.istft) or 1 (OnnxSTFT.inverse), got %d", mode);
+  m->istft_mode = mode;  // HiFi-GAN models carry it unused (decoders.py:17-61 takes no is_onnx)
+  return WETTS_OK;
+}
+
+int32_t wetts_get_istft_mode(const wetts_model_t* m) { return m ? m->istft_mode : WETTS_E_INVALID; }
 
 int32_t wetts_get_blob(const wetts_model_t* m, float* out_dev, int64_t numel, void* stream) {
   WETTS_REQUIRE(m && out_dev, "null argument");
@@ -1741,9 +1760,9 @@ static int32_t run_vocos(const wetts_model* m, const float* z, int64_t z_bs, int
     ConvParams p = conv_io(ri, VO, Fs, frames, NF, B);
     p.x_bs = (int64_t)VOp * Fs;
     p.k_rows_padded = 1;
-    WETTS_TRY(launch_conv(m->v_istft, p, s));
+    WETTS_TRY(launch_conv(m->istft_mode == WETTS_ISTFT_ONNX ? m->v_istft_onnx : m->v_istft, p, s));
   }
-  return k_istft_ola(frames, B, NF, c->istft_hop_length, F, audio, s, Fs);
+  return k_istft_ola(frames, B, NF, c->istft_hop_length, F, audio, s, Fs, m->istft_mode == WETTS_ISTFT_ONNX ? 0 : 1);
 }
 
 // output columns per block of the fused ResBlock pair kernels (resblock32.hip / resblock16.hip)

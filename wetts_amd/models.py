@@ -79,6 +79,7 @@ class SynthesizerTrn:
                      use_sdp=use_sdp, vocoder_type=vocoder_type, **kwargs)
         self.cfg = _config.make_config(model, n_vocab, n_speakers)
         self.vocoder_type = vocoder_type
+        self.is_onnx = bool(self.cfg.is_onnx)  # models.py:50,111: the Vocos head's iSTFT (see set_is_onnx)
         self.hop_length = 1
         for u in upsample_rates:
             self.hop_length *= int(u)
@@ -139,6 +140,20 @@ class SynthesizerTrn:
         if self._handle is not None:
             _lib.check(_lib.load().wetts_set_decoder_precision(self._handle, prec),
                        "set_decoder_precision")
+        return self
+
+    def set_is_onnx(self, on=True):
+        """The `is_onnx` ctor flag of the reference (models.py:50,111) on a live model: which iSTFT a Vocos head ends in
+        (decoders.py:300-304).  False: torchaudio's InverseSpectrogram == torch.istft -- what `infer()` of the PyTorch CLI
+        (inference.py) computes.  True: OnnxSTFT.inverse (utils/stft.py:325-340; conv_transpose1d with
+        pinv(scale * basis)^T * hann, no window-envelope division) -- what every graph export_onnx.py writes computes,
+        because that script forces hps.model.is_onnx = True (export_onnx.py:59).  At hop = n_fft / 4 the interior of
+        the two differs by the factor 0.375, the first / last n_fft/2 samples also in shape.  HiFi-GAN models take the
+        flag without effect, like the reference.  The ORT-shaped sessions (session.py) switch to True for their calls."""
+        self.is_onnx = bool(on)
+        self.cfg.is_onnx = int(self.is_onnx)
+        if self._handle is not None:
+            _lib.check(_lib.load().wetts_set_istft_mode(self._handle, int(self.is_onnx)), "set_istft_mode")
         return self
 
     def set_flow_dtype(self, dtype):
@@ -219,8 +234,14 @@ class SynthesizerTrn:
             blob = self._blob
         else:
             raise _lib.WettsError("no weights loaded: call load_state_dict(...) first")
-        return OrderedDict((name, blob[off:off + numel].view(shape))
-                           for name, off, numel, shape in checkpoint.blob_layout(self.cfg))
+        sd = OrderedDict((name, blob[off:off + numel].view(shape))
+                         for name, off, numel, shape in checkpoint.blob_layout(self.cfg))
+        if self.is_onnx and self.vocoder_type == "vocos":
+            # the two buffers OnnxSTFT registers (utils/stft.py:289-290); constants of the config, not of the checkpoint
+            fwd, inv = _onnx_stft_bases(int(self.cfg.istft_n_fft), int(self.cfg.istft_hop_length))
+            sd["dec.stft.forward_basis"] = fwd.to(blob.device)
+            sd["dec.stft.inverse_basis"] = inv.to(blob.device)
+        return sd
 
     def load_blob(self, blob):
         """Adopts an already packed float32 blob (CPU or device tensor), e.g. after a broadcast."""
@@ -611,6 +632,21 @@ class SynthesizerTrn:
         _lib.check(lib.wetts_audio_to_int16(_lib.ptr(a), _lib.ptr(ln), B, L, _lib.ptr(pcm),
                                             _lib.current_stream_ptr()), "audio_to_int16")
         return pcm
+
+
+def _onnx_stft_bases(n_fft, hop):
+    """OnnxSTFT's `forward_basis` / `inverse_basis` buffers [n_fft + 2, 1, n_fft] (utils/stft.py:266-290, hann window,
+    win_length == n_fft) for state_dict().  The device kernels build their own copy of the inverse one in closed form
+    (kernels.hip: istft_basis_kernel); this host restatement serves the state_dict surface only."""
+    import numpy as np
+    n = np.arange(n_fft)
+    k = np.arange(n_fft // 2 + 1)
+    ang = 2.0 * np.pi * ((k[:, None] * n[None, :]) % n_fft) / n_fft
+    basis = np.vstack([np.cos(ang), -np.sin(ang)])  # real and imaginary rows of fft(eye)[:cutoff]
+    win = torch.from_numpy(0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)).float()  # scipy get_window("hann", fftbins=True)
+    fwd = torch.from_numpy(basis[:, None, :]).float() * win
+    inv = torch.from_numpy(np.linalg.pinv((n_fft / hop) * basis).T[:, None, :]).float() * win
+    return fwd, inv
 
 
 def load_checkpoint(checkpoint_path, model, optimizer=None):

@@ -8,7 +8,18 @@ Every Python caller of the reference's exported models goes through
     decoder    : z f32[B,L,192], sid int64[B] -> output f32[B,1,L*hop]   (inference_onnx.py:146-151)
 These shims accept / return numpy arrays exactly like ort.InferenceSession so wetts/cli/model.py,
 inference_onnx.py or the Triton python backend can swap the session object and nothing else.
+
+Arithmetic: a session stands for a GRAPH export_onnx.py wrote, and that script builds its model with
+`hps['model']['is_onnx'] = True` (export_onnx.py:59).  For a Vocos model that flag swaps the decoder's last step
+(decoders.py:300-304): OnnxSTFT.inverse (utils/stft.py:325-340 -- conv_transpose1d with pinv(scale * basis)^T * hann,
+no window-envelope division: 0.375 x the torch.istft audio in the interior at hop = n_fft / 4, different first / last
+n_fft/2 samples) instead of torchaudio's InverseSpectrogram.  Sessions that run a decoder therefore compute the
+OnnxSTFT head for the duration of their calls, whatever the wrapped module's own `is_onnx` says (`is_onnx=False` at
+construction keeps the module's arithmetic -- the graph a patched export script without line 59 would trace).
+HiFi-GAN models have one arithmetic; the flag does nothing there.
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -21,10 +32,26 @@ class _Arg:
 
 
 class _SessionBase:
-    def __init__(self, model: SynthesizerTrn):
+    def __init__(self, model: SynthesizerTrn, is_onnx=True):
         if model._handle is None:
             raise RuntimeError("model must have weights loaded and live on a HIP device")
         self.model = model
+        self.is_onnx = bool(is_onnx)
+
+    @contextlib.contextmanager
+    def _graph_arithmetic(self):
+        """The exported graph's iSTFT head for the calls made inside (module docstring).  The switch is a host flag of
+        the handle read at launch time, so it covers exactly the launches issued in the block (the reference's sessions
+        are used from one thread at a time, like the module)."""
+        m = self.model
+        if not self.is_onnx or m.vocoder_type != "vocos" or m.is_onnx:
+            yield
+            return
+        m.set_is_onnx(True)
+        try:
+            yield
+        finally:
+            m.set_is_onnx(False)
 
     def _dev(self, a, dtype, consumer="encoder"):
         return self.model.upload(np.asarray(a), dtype, consumer=consumer)
@@ -50,8 +77,8 @@ class InferenceSession(_SessionBase):
     followed by zeros instead of the decoded padding tail.  `max_batch` caps a sub-batch (the Triton
     `generator` model's max_batch_size is 32, generator/config.pbtxt)."""
 
-    def __init__(self, model: SynthesizerTrn, max_pad_frac=None, max_batch=0, ragged=False):
-        super().__init__(model)
+    def __init__(self, model: SynthesizerTrn, max_pad_frac=None, max_batch=0, ragged=False, is_onnx=True):
+        super().__init__(model, is_onnx)
         self.max_pad_frac = max_pad_frac
         self.max_batch = max_batch
         self.ragged = ragged  # batching.synthesize(ragged=): rows decoded as the reference decodes them alone
@@ -67,6 +94,10 @@ class InferenceSession(_SessionBase):
 
     def run(self, output_names, feeds, run_options=None):
         self._check(output_names)
+        with self._graph_arithmetic():
+            return self._run(feeds)
+
+    def _run(self, feeds):
         scales = np.asarray(feeds["scales"], dtype=np.float32)
         ids = np.asarray(feeds["input"])
         lens = np.asarray(feeds["input_lengths"]).reshape(-1)  # Triton feeds [B,1] (tts/1/model.py:128)
@@ -300,7 +331,8 @@ class GraphedDecoder:
         """z [B, inter, L] (any strides), g [B, gin] or None -> audio [B, 1, L*hop] (a view of the
         graph's output buffer: consume or copy it before the next call with the same shape)."""
         B, _, L = z.shape
-        key = (int(B), int(L), g is not None)
+        # (a graph bakes in which iSTFT basis a Vocos head multiplies by: one entry per arithmetic)
+        key = (int(B), int(L), g is not None, bool(self.model.is_onnx))
         e = self._entries.get(key)
         if e is None:
             e = self._entries[key] = self._build(int(B), int(L), g is not None)
@@ -315,8 +347,8 @@ class DecoderSession(_SessionBase):
     """Streaming back half (export_decoder_forward, models.py:360-363): z chunk -> audio.
     `use_graph=True` replays a captured HIP graph per window shape (see GraphedDecoder)."""
 
-    def __init__(self, model, use_graph=False):
-        super().__init__(model)
+    def __init__(self, model, use_graph=False, is_onnx=True):
+        super().__init__(model, is_onnx)
         self._graphed = GraphedDecoder(model) if use_graph else None
 
     def get_inputs(self):
@@ -328,6 +360,10 @@ class DecoderSession(_SessionBase):
 
     def run(self, output_names, feeds, run_options=None):
         self._check(output_names)
+        with self._graph_arithmetic():
+            return self._run(feeds)
+
+    def _run(self, feeds):
         # (read by the decoder, which runs on the caller's stream in either mode -- not the encoder's side stream)
         z = self._dev(feeds["z"], torch.float32, consumer="decoder")
         sid = self._dev(feeds["sid"], torch.int64, consumer="decoder")
