@@ -22,7 +22,7 @@ def main():
     dev = torch.device("cuda", 0)
     rank, local_rank, world = sharding.env_world()
     assert world == 1 and rank == 0
-    # the product's own start-up: process group bound to the device (device_id), 120 s timeout, NCCL_DEBUG=WARN
+    # the product's own start-up: process group bound to the device (device_id), the default timeout, NCCL_DEBUG=WARN
     sharding.init_process_group(backend="nccl", force=True)
     assert dist.get_backend() == "nccl"
     mname, n_vocab, n_spk = "tiny", 40, 3

@@ -218,4 +218,16 @@ struct SmallConvScope {  // RAII: launches of up to `max_tiles` 64x64 tiles use 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// compute units of the current device (read once; 256 on MI355X): the host-side tile / strip schedules model rounds of
+// blocks per CU with it
+inline int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess &&
+           hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cus;
+}
+
 }  // namespace wetts

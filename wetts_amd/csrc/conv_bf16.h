@@ -84,6 +84,8 @@ struct ResStage2Params {
   int ktaps[RESSTAGE2_MAX_CHAINS], dil1[RESSTAGE2_MAX_CHAINS], dil2[RESSTAGE2_MAX_CHAINS];
   int nchain;
   int origin;     // widest c2 halo of the stage: column c of every chain <-> time n0 - origin + c
+  int h1max;      // widest c1 halo of the stage (shared staging: the lrelu(x) tile's halo)
+  int xrows;      // rows of the lrelu(x) LDS tile (whole staging passes)
   int T, B;
   float out_div;  // applied with the last chain (x = xs / num_kernels)
   float slope;

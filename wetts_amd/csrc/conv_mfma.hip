@@ -869,7 +869,7 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
     // columns per item: 64 x 128 (101 vs 84 on the big tile, 95 on 64 x 64); B = 64 in_layers: 64 x 128 / 128 x 128 (125 /
     // 124 vs 117) -- where the old rule (big tile from 384 blocks up) left 17-21 % on the table at B = 64.
     const int64_t n128 = nblk(128, 128);
-    constexpr int kCUs = 256;
+    const int kCUs = device_cus();  // (256 on MI355X; read from the device, so another part's count is modelled too)
     if (n128 >= 4 * kCUs) return launch_cfg<1, 4, 4, 1>(p, stream);
     // (a grid of fewer blocks than CUs leaves CUs idle and one wave per SIMD: never a candidate while another shape fills the
     // chip -- the FFN's 768 -> 192 at B = 64 is 192 tiles of 64 x 128: 67 TF/s against 70 on 384 tiles of 64 x 64)

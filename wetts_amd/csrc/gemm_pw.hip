@@ -299,18 +299,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------
-static int g_cus = 0;
-static int device_cus() {
-  if (g_cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-      g_cus = n;
-    else
-      g_cus = 256;
-  }
-  return g_cus;
-}
-
 bool pw_gemm_eligible(const PackedConv& pc, const ConvParams& p) {
   if (pc.ktaps != 1 || pc.up != 0 || pc.pad != 0) return false;
   if (p.in_act != IN_NONE || p.in_mask != nullptr || p.in_rev_base >= 0 || p.lens != nullptr) return false;

@@ -482,6 +482,7 @@ struct wetts_model {
   int conv_groups = 1;  // WETTS_TUNE conv_groups: independent single convs of a ResBlock1 step in one launch (0: one each)
   hipStream_t aux_stream[WETTS_MAX_RB_KERNELS] = {};
   hipEvent_t ev_fork = nullptr, ev_chain[WETTS_MAX_RB_KERNELS] = {};
+  bool fork_ok = false;  // every handle above exists (else: the serial grouped schedule)
 
   const float* T(const std::string& name) const {
     auto it = layout.index.find(name);
@@ -979,12 +980,15 @@ int32_t wetts_create(const wetts_config_t* cfg, const float* blob_dev, int64_t b
     }
     if (m->mrf_streams < 1) m->mrf_streams = 1;
     if (m->mrf_streams > cfg->n_resblock_kernels) m->mrf_streams = cfg->n_resblock_kernels;
-    (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
+    // the fork's handles; if any cannot be had the model keeps to the one-stream schedule (fork_ok = false): a null
+    // aux stream would be the legacy default stream -- illegal inside a graph capture, implicitly synchronising outside
+    m->fork_ok = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess && m->ev_fork;
     for (int j = 0; j < cfg->n_resblock_kernels; ++j) {
-      (void)hipEventCreateWithFlags(&m->ev_chain[j], hipEventDisableTiming);
-      if (j > 0)  // one per ResBlock chain: mrf_streams (big launches, opt-in) and small_fork (streaming windows) use them
-        (void)hipStreamCreateWithFlags(&m->aux_stream[j], hipStreamNonBlocking);
+      if (hipEventCreateWithFlags(&m->ev_chain[j], hipEventDisableTiming) != hipSuccess || !m->ev_chain[j]) m->fork_ok = false;
+      if (j > 0)  // one per ResBlock chain: the default f32 fork, mrf_streams and small_fork (streaming windows) use them
+        if (hipStreamCreateWithFlags(&m->aux_stream[j], hipStreamNonBlocking) != hipSuccess || !m->aux_stream[j]) m->fork_ok = false;
     }
+    (void)hipGetLastError();  // a failed creation must not surface as the next launch's error
   }
   if (r == WETTS_OK) {
     e = hipStreamSynchronize(s);
@@ -2008,7 +2012,7 @@ static int32_t run_hifigan(const wetts_model* m, const float* z, int64_t z_bs, i
     // chains concurrently when the stage's convs are launches of a few blocks (a streaming window): three
     // independent 10-25 us kernels then share the chip instead of queueing behind each other
     const bool small_stage = !lens && (int64_t)cdiv(ch, 64) * cdiv(len, 64) * B <= m->small_max_tiles;
-    const int nstreams = (c->resblock == 1 && ((m->small_fork && small_stage) || (ch <= m->mrf_fork_maxc && !m->dec_serial))) ? nk : m->mrf_streams;
+    const int nstreams = !m->fork_ok ? 1 : (c->resblock == 1 && ((m->small_fork && small_stage) || (ch <= m->mrf_fork_maxc && !m->dec_serial))) ? nk : m->mrf_streams;
     const bool forked = nstreams > 1;
     if (forked) WETTS_HIP_CHECK(hipEventRecord(m->ev_fork, s));
     // the chain kernel addresses one utterance's [C][T] plane with 32-bit byte offsets and buffer descriptors: a
@@ -2692,10 +2696,11 @@ int32_t wetts_dynamic_quant_conv1d(const float* x, const float* w, const float* 
 int32_t wetts_set_decoder_precision(const wetts_model_t* m, int32_t precision) {
   WETTS_REQUIRE(m != nullptr, "null model");
   const int unfused = (precision & WETTS_DECODER_UNFUSED) ? 1 : 0;
-  m->dec_serial = (precision & WETTS_DECODER_SERIAL) ? 1 : 0;
+  const int serial = (precision & WETTS_DECODER_SERIAL) ? 1 : 0;
   precision &= ~(WETTS_DECODER_UNFUSED | WETTS_DECODER_SERIAL);
   WETTS_REQUIRE(precision >= 0 && precision <= 3,
                 "precision must be 0 (f32), 1 (bf16), 2 (f16) or 3 (uint8 dynamic quantisation)");
+  m->dec_serial = serial;  // (only a validated request changes the model)
   m->dec_unfused = unfused;
   WETTS_REQUIRE(precision == 0 || m->cfg.vocoder_type == 0,
                 "the 16-bit decoder mode covers the HiFi-GAN generator only");

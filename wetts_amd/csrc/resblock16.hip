@@ -320,11 +320,22 @@ void resblock_pair16_kernel(const ResPairParams p) {
         }
       }
     }
+    // the running MRF sum of this m-block's outputs: ALL its pieces requested in one batch, from addresses clamped into
+    // the utterance (columns outside the stored range get some valid row's values; they are never stored), so the
+    // loads go out back to back instead of one load / wait / add round trip per piece (tools/isa_scan.py)
+    uint4 osum[NB][2];
+    if (p.accum) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        int t = (RB2 ? n0 - h2 : n0) + wcol + 32 * j;
+        t = t < 0 ? 0 : (t >= p.T ? p.T - 1 : t);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          osum[j][i] = *reinterpret_cast<const uint4*>(ob + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int col = wcol + 32 * j;
-      const int t = RB2 ? n0 - h2 + col : n0 + col;
-      const bool ok = (RB2 ? (col >= h2 && col < NTC - h2 && t >= 0) : col < NTO) && t < p.T;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const unsigned w4[4] = {rres[mi][j][i].x, rres[mi][j][i].y, rres[mi][j][i].z, rres[mi][j][i].w};
@@ -334,10 +345,8 @@ void resblock_pair16_kernel(const ResPairParams p) {
           v[2 * e] = RB2 ? acc[mi][j][8 * i + 2 * e] : lo16<F16>(w4[e]);
           v[2 * e + 1] = RB2 ? acc[mi][j][8 * i + 2 * e + 1] : hi16<F16>(w4[e]);
         }
-        if (p.accum && ok) {
-          const uint4 oo =
-              *reinterpret_cast<const uint4*>(ob + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half);
-          const unsigned o4[4] = {oo.x, oo.y, oo.z, oo.w};
+        if (p.accum) {
+          const unsigned o4[4] = {osum[j][i].x, osum[j][i].y, osum[j][i].z, osum[j][i].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             v[2 * e] += lo16<F16>(o4[e]);

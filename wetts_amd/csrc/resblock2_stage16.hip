@@ -16,24 +16,59 @@
 // contain the common output range [o, NTC - o).  Operation order and rounding points per output element are those
 // of the chain-by-chain launches, so the results are bit-identical to them
 // (tests/test_gpu_parity.py::test_fused_resblock_pair_bit_identical runs both).
+#include <type_traits>
+
 #include "common.h"
 #include "conv_bf16.h"
 #include "conv16_dev.h"
 
 namespace wetts {
 
-template <int C, bool F16, int NR, int OCC>
+// Round 6: what the SQ counters of this kernel said (profiles/r06_sq_counters_mrf16.txt: matrix pipe 26 % busy at C = 32,
+// 15 VALU + 6.6 SALU instructions per MFMA, 190 uniform branches in the epilogues) and what was done about it:
+//  * SHARED staging (C = 32): lrelu(x) is the same tile for every chain of the stage -- only the halo differs -- so it is
+//    staged ONCE with the widest c1 halo into its own LDS tile, and lrelu(t) of each chain goes to a second tile.  The
+//    per-chain re-staging (global load, unpack, leaky-relu, pack, ds_write: ~28 VALU per 16-byte piece, three times over)
+//    was a third of the kernel's vector work.  Two tiles of 512 columns do not fit twice into 160 KB, so the C = 32 tile is
+//    384 columns (three accumulator blocks per wave): 72 KB per block, two blocks per CU as before.
+//  * the raw x of a lane's own outputs (c1's accumulator init) is loaded once and kept in registers across the chains;
+//  * x is addressed through a buffer descriptor of the utterance's plane: rows before / behind the utterance read as
+//    zeros (lrelu(0) = 0: the convs' zero padding) without a bounds test, exec mask or branch per piece;
+//  * the `inside` select of lrelu(t) and the choice of the quotient are uniform per block and hoisted out of the
+//    per-element loops; bias adds, slope products and the quotient run on pairs (v_pk_add / mul / fma_f32).
+// Operation order and rounding points per output element are unchanged: bit-identical to the chain-by-chain launches.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+constexpr int kBufRsrcRaw = 0x00020000;  // gfx9 family raw buffer: 32-bit data format, no swizzle
+
+template <bool F16>
+__device__ __forceinline__ f32x2v unpack2(unsigned w) { return f32x2v{lo16<F16>(w), hi16<F16>(w)}; }
+// leaky-relu of a pair: one packed product, two v_max (max(x, slope x), see conv16_dev.h: lrelu_max)
+__device__ __forceinline__ f32x2v lrelu2v(f32x2v v, f32x2v slope2) {
+  const f32x2v m = v * slope2;
+  f32x2v r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r.x) : "v"(v.x), "v"(m.x));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r.y) : "v"(v.y), "v"(m.y));
+  return r;
+}
+template <bool F16>
+__device__ __forceinline__ unsigned lrelu_pk2(unsigned w, f32x2v slope2) {
+  const f32x2v r = lrelu2v(unpack2<F16>(w), slope2);
+  return pk2<F16>(r.x, r.y);
+}
+
+template <int C, bool F16, int NR, int OCC, int NB, bool SHARED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 void rb2_stage16_kernel(const ResStage2Params p) {
-  constexpr int WM = C / 32, WN = 4 / WM, NB = 4;
+  constexpr int WM = C / 32, WN = 4 / WM;
   constexpr int NTH = 256;
   constexpr int NTC = 32 * NB * WN;
   constexpr int CKB = C >= 64 ? 64 : 32;
   constexpr int NCH = C / CKB, KS = CKB / 16;
-  constexpr int SEG = C / 8;
+  constexpr int SEG = C / 8;      // 16-byte pieces per row
+  constexpr int RPP = NTH / SEG;  // rows per staging pass
   constexpr int RS = C * 2 + 16;
-  constexpr int MAXU = ((NTC + RESPAIR2_MAX_SPAN32) * SEG + NTH - 1) / NTH;
-  static_assert(NTH % SEG == 0, "piece index must not depend on the unit");
+  constexpr int MAXU = (NTC + RESPAIR2_MAX_SPAN32 + RPP - 1) / RPP;
+  static_assert(NTH % SEG == 0, "piece index must not depend on the pass");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
 
@@ -55,9 +90,61 @@ void rb2_stage16_kernel(const ResStage2Params p) {
   const int b = bid / p.ntiles;
   const int n0 = ntile * NTO;
   const unsigned short* xb = p.x + (int64_t)b * p.T * C;
+  // the utterance's [T][C] plane as a raw buffer: offsets outside it (rows before 0 / from T on) load zeros
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xb), 0, p.T * C * 2, kBufRsrcRaw);
   const int co_blk = wm * 32;
   const int wcol = wn * (32 * NB) + (lane & 31);
-  const unsigned char* bcol = smem_r + (size_t)wcol * RS + half * 16;
+  unsigned char* const xt = smem_r;                                       // lrelu(x)
+  unsigned char* const tt = SHARED ? smem_r + (size_t)p.xrows * RS : xt;  // lrelu(t) of the current chain
+  const f32x2v slope2 = {p.slope, p.slope};
+  // columns whose time lies outside the utterance exist only in its first / last tiles (block-uniform)
+  const bool edge = n0 - o < 0 || n0 - o + NTC > p.T;
+
+  auto load16 = [&](int byte_off) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsx, byte_off, 0, 0));
+  };
+
+  // raw x at this lane's columns: c1's accumulator init in every chain (requested first: the oldest loads in flight).
+  // SHARED (C = 32) keeps it in registers across the chains; the C = 64 tile has no room (it spills) and reloads it per
+  // chain, an L2 hit
+  uint4 rres[NB][2];
+  auto load_res = [&]() {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = n0 - o + wcol + 32 * j;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) rres[j][i] = load16((t * C + co_blk + 16 * i + 8 * half) * 2);
+    }
+  };
+  if (SHARED) load_res();
+
+  // ---- stage lrelu(x): rows r <-> time tx0 + r --------------------------------------------------------------------
+  auto stage_x = [&](int tx0, int rows) {
+    const int useg = tid % SEG, urow = tid / SEG;
+    const int voff = ((tx0 + urow) * C + useg * 8) * 2;
+    uint4 st[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i)
+      if (i * RPP < rows) st[i] = load16(voff + i * (RPP * C * 2));
+    unsigned char* dst = xt + (size_t)urow * RS + useg * 16;
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i)
+      if (i * RPP < rows) {  // (the tile is allocated in whole passes: no guard on the last pass's rows)
+        uint4 v = st[i];
+        v.x = lrelu_pk2<F16>(v.x, slope2); v.y = lrelu_pk2<F16>(v.y, slope2);
+        v.z = lrelu_pk2<F16>(v.z, slope2); v.w = lrelu_pk2<F16>(v.w, slope2);
+        *reinterpret_cast<uint4*>(dst + (size_t)i * (RPP * RS)) = v;
+      }
+  };
+  if (SHARED) {
+    stage_x(n0 - o - p.h1max, NTC + 2 * p.h1max);
+    // rows of the lrelu(t) tile no chain writes (the halo on both sides of its NTC columns) feed discarded columns
+    // only; zeroed once so that nothing uninitialised enters an MFMA
+    for (int r = tid; r < 2 * o * (RS / 16); r += NTH) {
+      const int row = r / (RS / 16), pc = r % (RS / 16);
+      *reinterpret_cast<uint4*>(tt + (size_t)(row < o ? row : NTC + row) * RS + pc * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
 
   uint4 sum[NB][2];  // the running MRF sum of this lane's outputs, packed 16 bit (rounded after every chain)
 #pragma unroll
@@ -68,8 +155,6 @@ void rb2_stage16_kernel(const ResStage2Params p) {
   for (int ch = 0; ch < p.nchain; ++ch) {
     const int ktaps = p.ktaps[ch], dil1 = p.dil1[ch], dil2 = p.dil2[ch];
     const int h1 = (ktaps - 1) / 2 * dil1, h2 = (ktaps - 1) / 2 * dil2;
-    const int W1 = NTC + 2 * (h1 > h2 ? h1 : h2);
-    const int tx0 = n0 - o - h1;  // time of LDS row 0 of the x tile
     const int G = NCH * ktaps;
     const uint4* abase1 = reinterpret_cast<const uint4*>(p.wpk1[ch]) + ((int64_t)wm * G * KS) * 64 + lane;
     const uint4* abase2 = reinterpret_cast<const uint4*>(p.wpk2[ch]) + ((int64_t)wm * G * KS) * 64 + lane;
@@ -83,46 +168,14 @@ void rb2_stage16_kernel(const ResStage2Params p) {
       for (int s = 0; s < KS; ++s) aa[NR - 1][s] = aa[0][s];
     };
     a_prologue(abase1);
+    if (!SHARED) load_res();
 
-    // raw x at c1's columns initialises c1's accumulators (requested first: the oldest load in flight)
-    uint4 rres[NB][2];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int t = n0 - o + wcol + 32 * j;
-      const bool ok = t >= 0 && t < p.T;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (ok) v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + co_blk + 16 * i + 8 * half);
-        rres[j][i] = v;
-      }
+    // ---- 1. lrelu(x) in LDS (SHARED: staged once above; else per chain with this chain's halo, L2 hits) ----------
+    if (!SHARED) {
+      if (ch > 0) __syncthreads();  // the previous chain's c2 has finished reading the tile
+      stage_x(n0 - o - h1, NTC + 2 * (h1 > h2 ? h1 : h2));
     }
-
-    // ---- 1. stage lrelu(x) (chains after the first: L2 hits) ---------------------------------------------
-    if (ch > 0) __syncthreads();  // the previous chain's c2 has finished reading the tile
-    {
-      const int useg = tid % SEG;
-      uint4 st[MAXU];
-#pragma unroll
-      for (int i = 0; i < MAXU; ++i) {
-        const int row = (tid + NTH * i) / SEG;
-        const int t = tx0 + row;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < W1 && t >= 0 && t < p.T) v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + useg * 8);
-        st[i] = v;
-      }
-#pragma unroll
-      for (int i = 0; i < MAXU; ++i) {
-        const int row = (tid + NTH * i) / SEG;
-        if (row < W1) {
-          uint4 v = st[i];
-          v.x = lrelu_pk<F16>(v.x, p.slope); v.y = lrelu_pk<F16>(v.y, p.slope);
-          v.z = lrelu_pk<F16>(v.z, p.slope); v.w = lrelu_pk<F16>(v.w, p.slope);
-          *reinterpret_cast<uint4*>(smem_r + (size_t)row * RS + useg * 16) = v;
-        }
-      }
-    }
-    __syncthreads();
+    if (!SHARED || ch == 0) __syncthreads();
 
     f32x16 acc[NB];
 #pragma unroll
@@ -137,7 +190,7 @@ void rb2_stage16_kernel(const ResStage2Params p) {
         }
       }
 
-    // one conv over the LDS tile (the loop of resblock16.hip at MB = 1: unconditional A prefetch NR - 1 groups
+    // one conv over an LDS tile (the loop of resblock16.hip at MB = 1: unconditional A prefetch NR - 1 groups
     // ahead, B fragments one k-step ahead)
     uint4 bq[2][NB];
     auto b_load = [&](uint4 (&dst)[NB], const unsigned char* bb, int s) {
@@ -155,9 +208,9 @@ void rb2_stage16_kernel(const ResStage2Params p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    auto conv_loop = [&](const uint4* abase, int dil, int row0) {
+    auto conv_loop = [&](const uint4* abase, int dil, const unsigned char* bcol) {
       int chunk = 0, tap = 0, g = 0;
-      auto bpos = [&](int tp, int cq) { return bcol + (size_t)(row0 + tp * dil) * RS + cq * (CKB * 2); };
+      auto bpos = [&](int tp, int cq) { return bcol + (size_t)(tp * dil) * RS + cq * (CKB * 2); };
       auto advance = [&](int& tp, int& cq) { if (++tp == ktaps) { tp = 0; ++cq; } };
       b_load(bq[0], bpos(0, 0), 0);
       for (; g + NR <= G; g += NR) {
@@ -191,41 +244,52 @@ void rb2_stage16_kernel(const ResStage2Params p) {
       }
     };
 
-    // ---- 2. c1: column c <-> time n0 - o + c reads x rows c + tap * dil1 (row 0 <-> time n0 - o - h1) ------
-    conv_loop(abase1, dil1, 0);
+    // ---- 2. c1: column c <-> time n0 - o + c reads the x tile's rows c + tap * dil1 (+ the halo this chain leaves unused)
+    conv_loop(abase1, dil1, xt + (size_t)(wcol + (SHARED ? p.h1max - h1 : 0)) * RS + half * 16);
     a_prologue(abase2);
 
-    // ---- 3. t = round16(c1 + b1) stays in the accumulators; lrelu(t) goes h2 rows down the tile ------------
+    // ---- 3. t = round16(c1 + b1) stays in the accumulators; lrelu(t) goes to the t tile, toff rows down --------------
+    const int toff = SHARED ? o : h2;
     {
-      float bia[16];
+      f32x2v bia[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bia[r] = p.bias1[ch][co_blk + 16 * (r >> 3) + 8 * half + (r & 7)];
-      __syncthreads();  // every wave has finished reading lrelu(x)
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const int col = wcol + 32 * j;
-        const int t = n0 - o + col;
-        const bool inside = t >= 0 && t < p.T;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          unsigned w[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const unsigned r16 = pk2<F16>(acc[j][8 * i + 2 * e] + bia[8 * i + 2 * e],
-                                          acc[j][8 * i + 2 * e + 1] + bia[8 * i + 2 * e + 1]);
-            acc[j][8 * i + 2 * e] = lo16<F16>(r16);
-            acc[j][8 * i + 2 * e + 1] = hi16<F16>(r16);
-            // lrelu_pk(r16) on the values just unpacked (same operations, two unpacks less)
-            w[e] = inside ? pk2<F16>(lrelu_max(acc[j][8 * i + 2 * e], p.slope), lrelu_max(acc[j][8 * i + 2 * e + 1], p.slope)) : 0u;
-          }
-          *reinterpret_cast<uint4*>(smem_r + (size_t)(col + h2) * RS + (co_blk + 16 * i + 8 * half) * 2) =
-              make_uint4(w[0], w[1], w[2], w[3]);
-        }
+      for (int r = 0; r < 8; ++r) {
+        const int cc = co_blk + 16 * (r >> 2) + 8 * half + 2 * (r & 3);
+        bia[r] = f32x2v{p.bias1[ch][cc], p.bias1[ch][cc + 1]};
       }
+      // the tile's readers are done: this chain's c1 (single tile) / the previous chain's c2 (shared staging)
+      if (!SHARED || ch > 0) __syncthreads();
+      auto mid = [&](auto edge_c) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int col = wcol + 32 * j;
+          const int t = n0 - o + col;
+          const bool inside = t >= 0 && t < p.T;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            unsigned w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const f32x2v a2 = f32x2v{acc[j][8 * i + 2 * e], acc[j][8 * i + 2 * e + 1]} + bia[4 * i + e];
+              const f32x2v t2 = unpack2<F16>(pk2<F16>(a2.x, a2.y));
+              acc[j][8 * i + 2 * e] = t2.x;
+              acc[j][8 * i + 2 * e + 1] = t2.y;
+              // lrelu_pk(r16) on the values just unpacked (same operations, two unpacks less)
+              const f32x2v l2 = lrelu2v(t2, slope2);
+              w[e] = pk2<F16>(l2.x, l2.y);
+              if (decltype(edge_c)::value) w[e] = inside ? w[e] : 0u;
+            }
+            *reinterpret_cast<uint4*>(tt + (size_t)(col + toff) * RS + (co_blk + 16 * i + 8 * half) * 2) =
+                make_uint4(w[0], w[1], w[2], w[3]);
+          }
+        }
+      };
+      if (edge) mid(std::true_type{});
+      else mid(std::false_type{});
       __syncthreads();
     }
 
-    // ---- 4. c2: accumulator = t (+ the running sum), rows c + tap * dil2 of the shifted tile ---------------
+    // ---- 4. c2: accumulator = t (+ the running sum), rows c + tap * dil2 of the t tile ------------------------------
     if (ch > 0) {
 #pragma unroll
       for (int j = 0; j < NB; ++j)
@@ -234,34 +298,50 @@ void rb2_stage16_kernel(const ResStage2Params p) {
           const unsigned o4[4] = {sum[j][i].x, sum[j][i].y, sum[j][i].z, sum[j][i].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            acc[j][8 * i + 2 * e] += lo16<F16>(o4[e]);
-            acc[j][8 * i + 2 * e + 1] += hi16<F16>(o4[e]);
+            const f32x2v s2 = f32x2v{acc[j][8 * i + 2 * e], acc[j][8 * i + 2 * e + 1]} + unpack2<F16>(o4[e]);
+            acc[j][8 * i + 2 * e] = s2.x;
+            acc[j][8 * i + 2 * e + 1] = s2.y;
           }
         }
     }
-    conv_loop(abase2, dil2, 0);
+    conv_loop(abase2, dil2, tt + (size_t)(wcol + toff - h2) * RS + half * 16);
 
     // ---- 5. + b2 (/ n on the last chain), round: the new running sum ---------------------------------------
     {
-      float bia[16];
+      f32x2v bia[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bia[r] = p.bias2[ch][co_blk + 16 * (r >> 3) + 8 * half + (r & 7)];
-      const bool dodiv = ch == p.nchain - 1 && p.out_div != 1.f;
-      const bool fastdiv = p.out_div == 3.f || p.out_div == 2.f;  // (num_kernels of every recipe: 3)
-      const float dinv = 1.f / p.out_div;
+      for (int r = 0; r < 8; ++r) {
+        const int cc = co_blk + 16 * (r >> 2) + 8 * half + 2 * (r & 3);
+        bia[r] = f32x2v{p.bias2[ch][cc], p.bias2[ch][cc + 1]};
+      }
+      auto fin_all = [&](auto fin) {
 #pragma unroll
-      for (int j = 0; j < NB; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          float v[8];
+          for (int i = 0; i < 2; ++i) {
+            unsigned w[4];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            v[e] = acc[j][8 * i + e] + bia[8 * i + e];
-            if (dodiv) v[e] = fastdiv ? div_small_const(v[e], p.out_div, dinv) : v[e] / p.out_div;
+            for (int e = 0; e < 4; ++e) {
+              const f32x2v v = fin(f32x2v{acc[j][8 * i + 2 * e], acc[j][8 * i + 2 * e + 1]} + bia[4 * i + e]);
+              w[e] = pk2<F16>(v.x, v.y);
+            }
+            sum[j][i] = make_uint4(w[0], w[1], w[2], w[3]);
           }
-          sum[j][i].x = pk2<F16>(v[0], v[1]); sum[j][i].y = pk2<F16>(v[2], v[3]);
-          sum[j][i].z = pk2<F16>(v[4], v[5]); sum[j][i].w = pk2<F16>(v[6], v[7]);
-        }
+      };
+      const float dv = p.out_div;
+      if (ch != p.nchain - 1 || dv == 1.f) {
+        fin_all([](f32x2v v) { return v; });
+      } else if (mrf_div_fast(dv)) {  // (num_kernels of every recipe: 3) common.h: div_small_const on a pair
+        const float dinv = 1.f / dv;
+        const f32x2v c2 = {dinv, dinv}, nd2 = {-dv, -dv};
+        fin_all([=](f32x2v v) {
+          const f32x2v q = v * c2;
+          const f32x2v r = __builtin_elementwise_fma(nd2, q, v);
+          return __builtin_elementwise_fma(r, c2, q);
+        });
+      } else {
+        fin_all([=](f32x2v v) { return f32x2v{v.x / dv, v.y / dv}; });
+      }
     }
   }
 
@@ -278,6 +358,12 @@ void rb2_stage16_kernel(const ResStage2Params p) {
   }
 }
 
+// the tile shapes: C = 32 -> 384 columns (three accumulator blocks per wave), lrelu(x) staged once for all chains into its
+// own LDS tile; C = 64 -> 256 columns, one tile restaged per chain (two tiles of 144-byte rows would leave one block per CU)
+static constexpr int stage16_nb(int C) { return C == 32 ? 3 : 4; }
+static constexpr bool stage16_shared(int C) { return C == 32; }
+static int stage16_ntc(int C) { return 32 * stage16_nb(C) * (4 / (C / 32)); }
+
 // valid output columns per block, or 0 when the stage is not covered (shapes, halos, waste above max_waste_pct)
 int resblock2_stage16_nto(const PackedConvB* const* c1, const PackedConvB* const* c2, int nchain, int max_waste_pct) {
   if (nchain < 1 || nchain > RESSTAGE2_MAX_CHAINS) return 0;
@@ -293,8 +379,8 @@ int resblock2_stage16_nto(const PackedConvB* const* c1, const PackedConvB* const
     if (2 * (h1 > h2 ? h1 : h2) > RESPAIR2_MAX_SPAN32) return 0;
     if (h2 > o) o = h2;
   }
-  const int NTC = 128 * (4 / (C / 32));
-  if (2 * o * 100 > max_waste_pct * NTC) return 0;
+  const int NTC = stage16_ntc(C);
+  if (2 * o >= NTC || 2 * o * 100 > max_waste_pct * NTC) return 0;
   return NTC - 2 * o;
 }
 
@@ -303,9 +389,10 @@ int32_t launch_resblock2_stage16(const PackedConvB* const* c1, const PackedConvB
   const int nto = resblock2_stage16_nto(c1, c2, nchain, 100);
   WETTS_REQUIRE(nto > 0, "ResBlock2 stage not supported by the fused kernel");
   const int C = c1[0]->Cin;
-  const int NTC = 128 * (4 / (C / 32)), RS = C * 2 + 16;
+  const int NTC = stage16_ntc(C), RS = C * 2 + 16;
+  const int RPP = 256 / (C / 8);
   p.nchain = nchain;
-  int wmax = 0;
+  int wmax = 0, h1max = 0;
   for (int j = 0; j < nchain; ++j) {
     p.wpk1[j] = c1[j]->wpk; p.bias1[j] = c1[j]->bias;
     p.wpk2[j] = c2[j]->wpk; p.bias2[j] = c2[j]->bias;
@@ -315,22 +402,45 @@ int32_t launch_resblock2_stage16(const PackedConvB* const* c1, const PackedConvB
     const int h1 = (p.ktaps[j] - 1) / 2 * p.dil1[j], h2 = (p.ktaps[j] - 1) / 2 * p.dil2[j];
     if (h1 > wmax) wmax = h1;
     if (h2 > wmax) wmax = h2;
+    if (h1 > h1max) h1max = h1;
   }
   p.origin = (NTC - nto) / 2;
+  p.h1max = h1max;
   p.ntiles = cdiv(p.T, nto);
   const int64_t nb = (int64_t)p.ntiles * p.B;
   if (nb <= 0) return WETTS_OK;
   WETTS_REQUIRE(nb < (1ll << 30), "resblock stage grid too large");
+  WETTS_REQUIRE((int64_t)p.T * C * 2 < (int64_t)INT32_MAX, "utterance plane too large for the stage kernel's 32-bit offsets");
   p.nblocks = (int)nb;
   const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);
-  const size_t lds = (size_t)(NTC + 2 * wmax) * RS;
+  // LDS: the lrelu(x) tile in whole staging passes of RPP rows (its stores carry no row guard); shared staging adds the
+  // lrelu(t) tile behind it: NTC columns + the widest c2 halo (= origin) on both sides
+  const bool shared = stage16_shared(C);
+  const int xneed = shared ? NTC + 2 * h1max : NTC + 2 * wmax;
+  p.xrows = (xneed + RPP - 1) / RPP * RPP;
+  const size_t lds = (size_t)(p.xrows + (shared ? NTC + 2 * p.origin : 0)) * RS;
+  WETTS_REQUIRE(lds <= 160 * 1024, "ResBlock2 stage tile exceeds the LDS");
   const bool f16 = c1[0]->f16 != 0;
+  auto go = [&](auto kern) -> int32_t {
+    if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: opt in once per device
+      static signed char state[4][64] = {};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      const int slot = (C == 32 ? 0 : 2) + (f16 ? 1 : 0);
+      if (dev >= 0 && dev < 64 && !state[slot][dev]) {
+        WETTS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        state[slot][dev] = 1;
+      }
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    return WETTS_OK;
+  };
   if (C == 32) {
-    if (f16) hipLaunchKernelGGL((rb2_stage16_kernel<32, true, 2, 2>), dim3(grid), dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL((rb2_stage16_kernel<32, false, 2, 2>), dim3(grid), dim3(256), lds, stream, p);
+    if (f16) WETTS_TRY(go(rb2_stage16_kernel<32, true, 2, 2, stage16_nb(32), stage16_shared(32)>));
+    else WETTS_TRY(go(rb2_stage16_kernel<32, false, 2, 2, stage16_nb(32), stage16_shared(32)>));
   } else {
-    if (f16) hipLaunchKernelGGL((rb2_stage16_kernel<64, true, 2, 2>), dim3(grid), dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL((rb2_stage16_kernel<64, false, 2, 2>), dim3(grid), dim3(256), lds, stream, p);
+    if (f16) WETTS_TRY(go(rb2_stage16_kernel<64, true, 2, 2, stage16_nb(64), stage16_shared(64)>));
+    else WETTS_TRY(go(rb2_stage16_kernel<64, false, 2, 2, stage16_nb(64), stage16_shared(64)>));
   }
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;

@@ -240,11 +240,19 @@ void resblock_pair32_kernel(const ResPair32Params p) {
   for (int j = 0; j < NB; ++j) {
     const int col = wcol + 32 * j;
     const int t = RB2 ? n0 - h2 + col : n0 + col;
-    const bool ok = (RB2 ? (col >= h2 && col < NTC - h2 && t >= 0) : col < NTO) && t < p.T;
+    // the running MRF sum: a column block's 16 rows requested in one batch from a column clamped into the utterance
+    // (columns outside the stored range are never stored), not one load / wait / add round trip per element
+    // (tools/isa_scan.py; the f32 conv kernel lost the same shape in round 5)
+    float os[16];
+    if (p.accum) {
+      const int tc = t < 0 ? 0 : (t >= p.T ? p.T - 1 : t);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) os[r] = ob[(int64_t)(co_blk + (r & 3) + 8 * (r >> 2) + 4 * half) * p.T + tc];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float v = RB2 ? acc[j][r] : rres[j][r];
-      if (p.accum && ok) v += ob[(int64_t)(co_blk + (r & 3) + 8 * (r >> 2) + 4 * half) * p.T + t];
+      if (p.accum) v += os[r];
       acc[j][r] = v;
     }
   }

@@ -18,7 +18,10 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-DEFAULT_TIMEOUT_S = 120.0  # process-group timeout (c10d's own default is 10-30 minutes: far too long for a bench)
+# process-group timeout (c10d's own default is 10-30 minutes: far too long for a bench).  It sits ABOVE the longest phase
+# deadline bench.py arms (setup: 300 s) so that PhaseMonitor -- which can still print the partial line -- fires first;
+# PhaseMonitor.enter clamps any longer request to this minus a margin
+DEFAULT_TIMEOUT_S = 420.0
 
 
 def describe_device(local_rank=None):
@@ -42,7 +45,7 @@ def init_process_group(backend=None, timeout_s=None, force=False):
     `nccl` (= RCCL): the process group is BOUND to this rank's current device (`device_id`) -- c10d otherwise guesses
     the device from the global rank ("can cause a hang if rank to GPU mapping is heterogeneous") and creates the
     communicator lazily inside the first collective; with `device_id` it is created here, eagerly, under `timeout_s`
-    (default 120 s; WETTS_DIST_TIMEOUT_S overrides).  NCCL_DEBUG defaults to WARN so that a failing rank explains
+    (default 420 s -- above every phase deadline of PhaseMonitor; WETTS_DIST_TIMEOUT_S overrides).  NCCL_DEBUG defaults to WARN so that a failing rank explains
     itself on stderr; every rank names its device there first.  `force`: also at world size 1 (the RCCL start-up test
     of a 1-GPU box)."""
     import datetime
@@ -92,7 +95,8 @@ class PhaseMonitor:
         self._lock = threading.Lock()
         self._stop = threading.Event()
         self._thr = None
-        self._sig_r = None
+        self._sig_r = self._sig_w = None
+        self._sig_prev, self._sig_prev_fd = None, -1
         if world > 1:
             self._watch_sigterm()
             self._thr = threading.Thread(target=self._watch, name="wetts-phase-monitor", daemon=True)
@@ -110,9 +114,9 @@ class PhaseMonitor:
             r, w = os.pipe()
             os.set_blocking(w, False)
             os.set_blocking(r, False)
-            signal.signal(signal.SIGTERM, lambda *_: None)
-            signal.set_wakeup_fd(w, warn_on_full_buffer=False)
-            self._sig_r = r
+            self._sig_prev = signal.signal(signal.SIGTERM, lambda *_: None)
+            self._sig_prev_fd = signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+            self._sig_r, self._sig_w = r, w
         except (OSError, ValueError):
             self._sig_r = None
 
@@ -127,6 +131,12 @@ class PhaseMonitor:
 
     def enter(self, phase, deadline_s):
         import time
+        # keep what the docstring promises: this monitor (which can still report) fires BEFORE c10d's own watchdog
+        # aborts a hung collective -- a phase may ask for more than the process-group timeout allows (bench.py's timed
+        # phase grows with --steps), so the deadline is clamped to that timeout minus a margin (non-zero ranks add 3 s)
+        pg = float(os.environ.get("WETTS_DIST_TIMEOUT_S", DEFAULT_TIMEOUT_S))
+        if self.world > 1 and not self.override:
+            deadline_s = min(float(deadline_s), max(5.0, pg - 10.0))
         with self._lock:
             self.phase = phase
             # (the reporting rank fires first: a non-zero rank that left earlier would only make the launcher tear rank 0 down)
@@ -147,7 +157,26 @@ class PhaseMonitor:
             return None
 
     def done(self):
+        """Stops the watcher and puts SIGTERM back the way it was found: from here on nobody reads the wake-up pipe, so
+        a handler left in place would swallow the launcher's (or a harness `timeout`'s) SIGTERM for the rest of the
+        process -- rank 0 still formats its line and may run the long CPU baseline after this."""
+        import signal
+        import threading
         self._stop.set()
+        if self._thr is not None and self._thr is not threading.current_thread():
+            self._thr.join(timeout=2.0)
+        if self._sig_r is not None and threading.current_thread() is threading.main_thread():
+            try:
+                signal.set_wakeup_fd(self._sig_prev_fd if self._sig_prev_fd is not None else -1)
+                signal.signal(signal.SIGTERM, self._sig_prev if self._sig_prev is not None else signal.SIG_DFL)
+            except (OSError, ValueError):
+                pass
+            for fd in (self._sig_r, self._sig_w):
+                try:
+                    os.close(fd)
+                except OSError:
+                    pass
+            self._sig_r = self._sig_w = None
 
     def expire_now(self, why):
         """The same exit path for a failure the main thread caught itself (an exception out of a collective)."""
