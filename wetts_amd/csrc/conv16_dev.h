@@ -66,6 +66,42 @@ __device__ __forceinline__ unsigned lrelu_pk(unsigned w, float slope) {
   const float a = lrelu_max(lo16<F16>(w), slope), c = lrelu_max(hi16<F16>(w), slope);
   return pk2<F16>(a, c);
 }
+// ---- pairs (round 6): the epilogues and the staging of the fused 16-bit kernels are VALU-bound (SQ counters: 7-15 vector
+// instructions per MFMA), and gfx950 executes v_pk_mul / add / fma_f32 on two f32 values per lane at the rate of one:
+// bias adds, slope products and the MRF quotient run on pairs.  Same IEEE operations per element, same results.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+template <bool F16>
+__device__ __forceinline__ f32x2v unpack2(unsigned w) { return f32x2v{lo16<F16>(w), hi16<F16>(w)}; }
+// leaky-relu of a pair: one packed product, two v_max (max(x, slope x), see lrelu_max)
+__device__ __forceinline__ f32x2v lrelu2v(f32x2v v, f32x2v slope2) {
+  const f32x2v m = v * slope2;
+  f32x2v r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r.x) : "v"(v.x), "v"(m.x));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r.y) : "v"(v.y), "v"(m.y));
+  return r;
+}
+template <bool F16>
+__device__ __forceinline__ unsigned lrelu_pk2(unsigned w, f32x2v slope2) {
+  const f32x2v r = lrelu2v(unpack2<F16>(w), slope2);
+  return pk2<F16>(r.x, r.y);
+}
+// common.h: div_small_const on a pair (c2 = {1/d, 1/d}, nd2 = {-d, -d})
+__device__ __forceinline__ f32x2v div_small_const2(f32x2v v, f32x2v nd2, f32x2v c2) {
+  const f32x2v q = v * c2;
+  const f32x2v r = __builtin_elementwise_fma(nd2, q, v);
+  return __builtin_elementwise_fma(r, c2, q);
+}
+// a [T][C] 16-bit plane as a raw buffer (gfx9 family descriptor: 32-bit data format, no swizzle): 16-byte loads at byte
+// offsets outside [0, bytes) -- rows before the utterance (negative offsets are huge unsigned ones) or behind it -- return
+// zeros, i.e. the convs' zero padding (lrelu(0) = 0) without a bounds test, exec mask or branch per piece
+constexpr int kBufRsrcRaw16 = 0x00020000;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const unsigned short* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(base), 0, bytes, kBufRsrcRaw16);
+}
+__device__ __forceinline__ uint4 plane_load16(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c) {
   if (F16)

@@ -45,6 +45,7 @@ struct ConvBParams {
   float* wn_skip;         // [B][T][H] f32
   const float* wn_mask;   // [B][T]
   int wn_H, wn_last, wn_first;
+  int lds_rows;  // rows of one LDS staging buffer (set by the launcher: whole staging passes)
   int tag;    // 1: MRF ResBlock launch (own kernel symbol for profiles, no code difference)
   int basic;  // 1: always conv_bf16_kernel (the decoder's UNFUSED diagnostic mode: the form the newer kernels are held to)
 };

@@ -15,6 +15,8 @@
 // decoders.py:63-82,157-170,205-214 (ups / ResBlock convs / conv_post).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "conv_bf16.h"
 #include "conv16_dev.h"
@@ -128,7 +130,7 @@ void conv_bf16_kernel(const ConvBParams p) {
   constexpr int SEG = CKB / 8;          // 16-byte pieces per staged row
   constexpr int KS = CKB / 16;          // MFMA k-steps per (chunk, tap) group
   constexpr int RS = CKB * 2 + 16;      // LDS row stride in bytes (padded)
-  constexpr int MAXU = ((NT + 128) * SEG + 255) / 256;
+  constexpr int MAXU = (NT + 128 + 256 / SEG - 1) / (256 / SEG);  // staging passes of 256 / SEG rows
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
 
@@ -148,47 +150,47 @@ void conv_bf16_kernel(const ConvBParams p) {
   const int n0 = ntile * NT;
   const int W = NT + p.span;
   unsigned char* buf0 = smem_b;
-  unsigned char* buf1 = smem_b + (size_t)W * RS;
+  unsigned char* buf1 = smem_b + (size_t)p.lds_rows * RS;
 
   const unsigned short* xb = p.x + (int64_t)b * p.x_bs;
 
-  // staging assignment (chunk independent): unit u = tid + 256*i -> (row, seg)
-  int urow[MAXU];
-  bool uok[MAXU];
-#pragma unroll
-  for (int i = 0; i < MAXU; ++i) {
-    const int u = tid + 256 * i;
-    const int row = u / SEG;
-    const int t = n0 + p.off_lo + row;
-    urow[i] = row;
-    uok[i] = (row < W) && (t >= 0) && (t < p.Tin);
-  }
-  const int useg = tid % SEG;  // 256 % SEG == 0, so the piece index does not depend on i
+  // staging (round 6): unit (row, piece) = (tid / SEG + RPP * i, tid % SEG), i = 0 .. passes - 1.  The item's [Tin][Cin]
+  // plane is addressed through a buffer descriptor (conv16_dev.h: plane_rsrc): rows before / behind it and -- offset
+  // forced negative -- pieces of a channel chunk's tail behind Cin load zeros without a bounds test or exec mask per piece;
+  // the LDS buffers are allocated in whole passes (p.lds_rows), so the stores carry no row guard either.  Before, every
+  // piece was `branch, load, s_waitcnt vmcnt(0), convert, ds_write`: one memory round trip per piece.
+  constexpr int RPP = 256 / SEG;
+  const __amdgpu_buffer_rsrc_t rsx = plane_rsrc(xb, p.Tin * p.Cin * 2);
+  const int useg = tid % SEG, urow = tid / SEG;  // 256 % SEG == 0, so the piece index does not depend on the pass
+  const int vrow = ((n0 + p.off_lo + urow) * p.Cin + useg * 8) * 2;
+  const int vpass = RPP * p.Cin * 2;
   uint4 st0[MAXU];
-  auto load_chunk = [&](int c, uint4* st) {
-    const int c0 = c * CKB + useg * 8;
+  auto load_chunk = [&](int c, uint4* st) __attribute__((always_inline)) {
+    // (c beyond the last chunk: every offset negative -> zeros, no memory traffic; keeps the issue pattern uniform)
+    const bool cok = c * CKB + useg * 8 < p.Cin && c < p.nchunks;
+    const int v0 = cok ? vrow + c * (CKB * 2) : -(1 << 30);
 #pragma unroll
-    for (int i = 0; i < MAXU; ++i) {
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (uok[i] && c0 < p.Cin)
-        v = *reinterpret_cast<const uint4*>(xb + (int64_t)(n0 + p.off_lo + urow[i]) * p.Cin + c0);
-      st[i] = v;
-    }
+    for (int i = 0; i < MAXU; ++i)
+      if (i * RPP < W) st[i] = plane_load16(rsx, cok ? v0 + i * vpass : v0);
   };
   const bool lrelu = p.in_act == IN_LRELU;
-  const float slope = p.in_slope;
-  auto store_chunk = [&](unsigned char* buf, const uint4* st) {
+  const f32x2v slope2 = {p.in_slope, p.in_slope};
+  auto store_chunk = [&](unsigned char* buf, const uint4* st) __attribute__((always_inline)) {
+    unsigned char* dst = buf + (size_t)urow * RS + useg * 16;
+    auto go = [&](auto lr) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < MAXU; ++i) {
-      if (urow[i] < W) {
-        uint4 v = st[i];
-        if (lrelu) {
-          v.x = lrelu_pk<F16>(v.x, slope); v.y = lrelu_pk<F16>(v.y, slope);
-          v.z = lrelu_pk<F16>(v.z, slope); v.w = lrelu_pk<F16>(v.w, slope);
+      for (int i = 0; i < MAXU; ++i)
+        if (i * RPP < W) {
+          uint4 v = st[i];
+          if (decltype(lr)::value) {
+            v.x = lrelu_pk2<F16>(v.x, slope2); v.y = lrelu_pk2<F16>(v.y, slope2);
+            v.z = lrelu_pk2<F16>(v.z, slope2); v.w = lrelu_pk2<F16>(v.w, slope2);
+          }
+          *reinterpret_cast<uint4*>(dst + (size_t)i * (RPP * RS)) = v;
         }
-        *reinterpret_cast<uint4*>(buf + (size_t)urow[i] * RS + useg * 16) = v;
-      }
-    }
+    };
+    if (lrelu) go(std::true_type{});
+    else go(std::false_type{});
   };
 
   f32x16 acc[NB];
@@ -282,38 +284,77 @@ void conv_bf16_kernel(const ConvBParams p) {
   store_chunk(buf0, st0);
   __syncthreads();
 
-  const int brow0 = wn * (32 * NB) + (lane & 31) - p.pad - p.off_lo;
-  int chunk = 0, tap = 0;
-  for (int g = 0; g < G; g += 2) {
+  // Main loop (round 6; the structure of resblock16.hip's conv loop).  Before, every MFMA was `ds_read_b128, s_waitcnt
+  // lgkmcnt(0), v_mfma` -- the LDS latency exposed once per MFMA -- and the A prefetch sat behind a uniform branch, which
+  // makes the compiler wait vmcnt(0) on the load it has just issued (a full L2 round trip per group).  Now: B fragments
+  // one k-step ahead in a second register set (pinned by sched_barriers), the A prefetch of group g + 1 unconditional
+  // with a clamped index, and the next chunk's staging loads issued at every chunk start (offsets forced out of range
+  // behind the last chunk: no traffic) instead of behind a per-group test.
+  const unsigned char* const bcol0 = buf0 + (size_t)(wn * (32 * NB) + (lane & 31) - p.pad - p.off_lo) * RS + half * 16;
+  const size_t bufd = (size_t)p.lds_rows * RS;  // buf1 - buf0
+  // ROLL (the 128-row tile with 64-channel chunks: acc 64 + A ring 32 + staging 32 registers leave no room for a second
+  // B set at three waves per SIMD): ONE B set, each fragment re-requested right behind the MFMA that consumed it -- it is
+  // needed again NB MFMAs later, which covers the LDS latency.  Otherwise: two B sets, a whole k-step ahead.
+  constexpr bool ROLL = CKB == 64 && WM == 4;
+  uint4 bq[ROLL ? 1 : 2][NB];
+  auto b_load = [&](uint4 (&dst)[NB], const unsigned char* bb, int s) __attribute__((always_inline)) {
 #pragma unroll
-    for (int par = 0; par < 2; ++par) {  // ping-pong A register sets, statically indexed
-      const int gg = g + par;
-      if (gg < G) {
-        if (gg + 1 < G) {
+    for (int j = 0; j < NB; ++j) dst[j] = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
+  };
+  auto mma_group = [&](const uint4 (&av)[KS], const unsigned char* cur, const unsigned char* nxt) __attribute__((always_inline)) {
 #pragma unroll
-          for (int s = 0; s < KS; ++s) aa[par ^ 1][s] = abase[((int64_t)(gg + 1) * KS + s) * 64];
+    for (int s = 0; s < KS; ++s) {
+      if (ROLL) {
+        const unsigned char* nb = s + 1 < KS ? cur + (s + 1) * 32 : nxt;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          acc[j] = mfma16<F16>(av[s], bq[0][j], acc[j]);
+          bq[0][j] = *reinterpret_cast<const uint4*>(nb + (size_t)(32 * j) * RS);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (tap == 0 && chunk + 1 < p.nchunks) load_chunk(chunk + 1, st0);
-        const unsigned char* cur = (chunk & 1) ? buf1 : buf0;
-        const unsigned char* bb = cur + (size_t)(brow0 + tap * p.dil) * RS + half * 16;
+      } else {
+        if (s + 1 < KS) b_load(bq[(s + 1) & 1], cur, s + 1);
+        else b_load(bq[(s + 1) & 1], nxt, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const uint4 av = aa[par][s];
-#pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            const uint4 bw = *reinterpret_cast<const uint4*>(bb + (size_t)(32 * j) * RS + s * 32);
-            acc[j] = mfma16<F16>(av, bw, acc[j]);
-          }
-        }
-        if (++tap == p.ktaps) {
-          tap = 0;
-          if (chunk + 1 < p.nchunks) store_chunk((chunk & 1) ? buf0 : buf1, st0);
-          __syncthreads();
-          ++chunk;
-        }
+        for (int j = 0; j < NB; ++j) acc[j] = mfma16<F16>(av[s], bq[s & 1][j], acc[j]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+  };
+  int chunk = 0, tap = 0;
+  b_load(bq[0], bcol0, 0);
+  load_chunk(1, st0);
+  auto group = [&](int gg, const uint4 (&av)[KS], uint4 (&an)[KS]) __attribute__((always_inline)) {
+    int gn = gg + 1;
+    gn = gn < G ? gn : G - 1;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) an[s] = abase[((int64_t)gn * KS + s) * 64];
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch at the top of its group
+    const unsigned char* cur = bcol0 + ((chunk & 1) ? bufd : 0) + (size_t)(tap * p.dil) * RS;
+    const bool last_tap = tap + 1 == p.ktaps;
+    // (the chunk's last group: the next tile is the other buffer, complete only behind the barrier -- a harmless
+    // re-read of this group's own position, and the real fragment is fetched after the barrier)
+    mma_group(av, cur, last_tap ? cur : cur + (size_t)p.dil * RS);
+    if (last_tap) {
+      tap = 0;
+      if (chunk + 1 < p.nchunks) {
+        store_chunk((chunk & 1) ? buf0 : buf1, st0);
+        __syncthreads();
+        ++chunk;
+        b_load(bq[0], bcol0 + ((chunk & 1) ? bufd : 0), 0);
+        load_chunk(chunk + 1, st0);  // in flight behind this chunk's MFMAs
+      }
+    } else {
+      ++tap;
+    }
+  };
+  int g = 0;
+  for (; g + 2 <= G; g += 2) {  // ping-pong A register sets, statically indexed
+    group(g, aa[0], aa[1]);
+    group(g + 1, aa[1], aa[0]);
   }
+  if (g < G) group(g, aa[0], aa[1]);
 
   // ---- epilogue: + bias, / div, round to 16 bit, channel-last stores ---------------------------
   if (!rows_ok) return;  // M is a multiple of 32 in every decoder conv; guard only
@@ -460,26 +501,31 @@ static int32_t launch_b(const ConvBParams& p, hipStream_t stream, bool f16) {
   WETTS_REQUIRE(blocks < (1ll << 31), "conv grid too large");
   // one staging buffer is enough when the whole reduction is a single channel chunk
   const int nbuf = p.nchunks > 1 ? 2 : 1;
-  size_t lds = (size_t)nbuf * (NT + p.span) * RS;
+  constexpr int RPP = 256 / (CKB / 8);  // a buffer = whole staging passes (the kernel's stores carry no row guard)
+  ConvBParams pl = p;
+  pl.lds_rows = (NT + p.span + RPP - 1) / RPP * RPP;
+  WETTS_REQUIRE((int64_t)p.Tin * p.Cin * 2 < (int64_t)INT32_MAX, "input plane too large for the 16-bit conv's 32-bit offsets");
+  size_t lds = (size_t)nbuf * pl.lds_rows * RS;
+  WETTS_REQUIRE(lds <= 64 * 1024, "16-bit conv tile exceeds the default dynamic LDS");
   const dim3 grid((unsigned)blocks), blk(256);
   if constexpr (NB == 4 && WM == 4 && WN == 1 && CKB == 64) {  // the shape of the flow's WN convs
     if (p.epi_mode == 1) {
-      if (f16) hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, 1>), grid, blk, lds, stream, p);
-      else hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, 1>), grid, blk, lds, stream, p);
+      if (f16) hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, 1>), grid, blk, lds, stream, pl);
+      else hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, 1>), grid, blk, lds, stream, pl);
       WETTS_LAUNCH_CHECK();
       return WETTS_OK;
     }
     if (p.epi_mode == 2) {
-      if (f16) hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, 2>), grid, blk, lds, stream, p);
-      else hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, 2>), grid, blk, lds, stream, p);
+      if (f16) hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, 2>), grid, blk, lds, stream, pl);
+      else hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, 2>), grid, blk, lds, stream, pl);
       WETTS_LAUNCH_CHECK();
       return WETTS_OK;
     }
   }
   if constexpr (NB == 4 && WM == 1 && WN == 4 && CKB == 32) {  // conv_post (k_conv_post_mfma16)
     if (p.epi_mode == 3) {
-      if (f16) hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, 3>), grid, blk, lds, stream, p);
-      else hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, 3>), grid, blk, lds, stream, p);
+      if (f16) hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, 3>), grid, blk, lds, stream, pl);
+      else hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, 3>), grid, blk, lds, stream, pl);
       WETTS_LAUNCH_CHECK();
       return WETTS_OK;
     }
@@ -487,16 +533,16 @@ static int32_t launch_b(const ConvBParams& p, hipStream_t stream, bool f16) {
   WETTS_REQUIRE(p.epi_mode == 0, "fused epilogue requested for a tile shape it is not instantiated for");
   if (p.tag) {
     if (f16)
-      hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, 0, true>), grid, blk, lds, stream, p);
+      hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true, 0, true>), grid, blk, lds, stream, pl);
     else
-      hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, 0, true>), grid, blk, lds, stream, p);
+      hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false, 0, true>), grid, blk, lds, stream, pl);
     WETTS_LAUNCH_CHECK();
     return WETTS_OK;
   }
   if (f16)
-    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true>), grid, blk, lds, stream, p);
+    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, true>), grid, blk, lds, stream, pl);
   else
-    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false>), grid, blk, lds, stream, p);
+    hipLaunchKernelGGL((conv_bf16_kernel<NB, WM, WN, CKB, false>), grid, blk, lds, stream, pl);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
 }

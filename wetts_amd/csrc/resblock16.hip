@@ -23,6 +23,8 @@
 
 #include <vector>
 
+#include <type_traits>
+
 #include "common.h"
 #include "conv_bf16.h"
 #include "conv16_dev.h"
@@ -56,8 +58,9 @@ void resblock_pair16_kernel(const ResPairParams p) {
   // widest halo the staging loop is sized for; the C = 32 ResBlock2 chain also takes v3's k = 7 block
   // (dilations 3 / 12: 72 columns, 14 % of the 512-column tile)
   constexpr int MAXSPAN = (RB2 && C == 32) ? RESPAIR2_MAX_SPAN32 : RESPAIR_MAX_SPAN;
-  constexpr int MAXU = ((NTC + MAXSPAN) * SEG + NTH - 1) / NTH;
-  static_assert(NTH % SEG == 0, "piece index must not depend on the unit");
+  constexpr int RPP = NTH / SEG;               // rows per staging pass
+  constexpr int MAXU = (NTC + MAXSPAN + RPP - 1) / RPP;
+  static_assert(NTH % SEG == 0, "piece index must not depend on the pass");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
 
@@ -85,6 +88,9 @@ void resblock_pair16_kernel(const ResPairParams p) {
   const int tx0 = n0 - h2 - h1;  // time of LDS row 0 of the x tile
 
   const unsigned short* xb = p.x + (int64_t)b * p.T * C;
+  // the utterance's plane as a raw buffer: rows outside it load zeros (conv16_dev.h: plane_rsrc)
+  const __amdgpu_buffer_rsrc_t rsx = plane_rsrc(xb, p.T * C * 2);
+  const f32x2v slope2 = {p.slope, p.slope};
   // ---- A streams -----------------------------------------------------------------------------
   const int G = NCH * p.ktaps;
   const uint4* abase1 = reinterpret_cast<const uint4*>(p.wpk1) + ((int64_t)(wm * MB) * G * KS) * 64 + lane;
@@ -115,41 +121,32 @@ void resblock_pair16_kernel(const ResPairParams p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int t = n0 - h2 + wcol + 32 * j;
-      const bool ok = t >= 0 && t < p.T;
 #pragma unroll
       for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          uint4 v = make_uint4(0u, 0u, 0u, 0u);
-          if (ok) v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half);
-          rres[mi][j][i] = v;
-        }
+        for (int i = 0; i < 2; ++i) rres[mi][j][i] = plane_load16(rsx, (t * C + co_blk + 32 * mi + 16 * i + 8 * half) * 2);
     }
   }
 
   // ---- 1. stage lrelu(x) ---------------------------------------------------------------------
+  // (the tile is allocated in whole passes of RPP rows: no row guard on the stores; rows outside the utterance arrive as
+  // zeros from the buffer loads, no bounds test per piece)
   {
-    const int useg = tid % SEG;
+    const int useg = tid % SEG, urow = tid / SEG;
+    const int voff = ((tx0 + urow) * C + useg * 8) * 2;
     uint4 st[MAXU];
 #pragma unroll
-    for (int i = 0; i < MAXU; ++i) {
-      const int row = (tid + NTH * i) / SEG;
-      const int t = tx0 + row;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (row < W1 && t >= 0 && t < p.T)
-        v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + useg * 8);
-      st[i] = v;
-    }
+    for (int i = 0; i < MAXU; ++i)
+      if (i * RPP < W1) st[i] = plane_load16(rsx, voff + i * (RPP * C * 2));
+    unsigned char* dst = smem_r + (size_t)urow * RS + useg * 16;
 #pragma unroll
-    for (int i = 0; i < MAXU; ++i) {
-      const int row = (tid + NTH * i) / SEG;
-      if (row < W1) {
+    for (int i = 0; i < MAXU; ++i)
+      if (i * RPP < W1) {
         uint4 v = st[i];
-        v.x = lrelu_pk<F16>(v.x, p.slope); v.y = lrelu_pk<F16>(v.y, p.slope);
-        v.z = lrelu_pk<F16>(v.z, p.slope); v.w = lrelu_pk<F16>(v.w, p.slope);
-        *reinterpret_cast<uint4*>(smem_r + (size_t)row * RS + useg * 16) = v;
+        v.x = lrelu_pk2<F16>(v.x, slope2); v.y = lrelu_pk2<F16>(v.y, slope2);
+        v.z = lrelu_pk2<F16>(v.z, slope2); v.w = lrelu_pk2<F16>(v.w, slope2);
+        *reinterpret_cast<uint4*>(dst + (size_t)i * (RPP * RS)) = v;
       }
-    }
   }
   __syncthreads();
 
@@ -249,56 +246,70 @@ void resblock_pair16_kernel(const ResPairParams p) {
   // c2's first A groups are requested now; they land during step 3.  (MB = 1 also requests the raw residual
   // here; with two m-blocks per wave its 64 registers on top of the 128 accumulators spill, so MB = 2 loads it
   // in step 4, when c1's accumulators are dead -- an L2 hit: the same rows were staged a moment ago.)
-  a_prologue(abase2);
+  if (!RB2) a_prologue(abase2);  // (RB2: after step 3 -- t1 keeps all accumulators live through it, the ring would spill)
   if (MB == 1) {
+    if (!RB2) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int col = wcol + 32 * j;
-      const int t = n0 + col;
-      const bool ok = !RB2 && col < NTO && t < p.T;
+      for (int j = 0; j < NB; ++j) {  // (columns from NTO on are never stored: whatever row they load is harmless)
+        const int t = n0 + wcol + 32 * j;
 #pragma unroll
-      for (int mi = 0; mi < MB; ++mi)
+        for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          uint4 v = make_uint4(0u, 0u, 0u, 0u);
-          if (ok) v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half);
-          rres[mi][j][i] = v;
-        }
+          for (int i = 0; i < 2; ++i) rres[mi][j][i] = plane_load16(rsx, (t * C + co_blk + 32 * mi + 16 * i + 8 * half) * 2);
+      }
     }
   }
 
   // ---- 3. ft = lrelu(round16(c1 + b1)) over the x tile ----------------------------------------
   {
-    float bia[MB][16];
+    f32x2v bia[MB][8];
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bia[mi][r] = p.bias1[co_blk + 32 * mi + 16 * (r >> 3) + 8 * half + (r & 7)];
+      for (int r = 0; r < 8; ++r) {
+        const int cc = co_blk + 32 * mi + 16 * (r >> 2) + 8 * half + 2 * (r & 3);
+        bia[mi][r] = f32x2v{p.bias1[cc], p.bias1[cc + 1]};
+      }
     __syncthreads();  // every wave has finished reading lrelu(x)
+    // columns whose time lies outside the utterance (zero padding of c2's input) exist only in its first / last tiles:
+    // a block-uniform choice, not a select per element
+    const bool edge = n0 - h2 < 0 || n0 - h2 + NTC > p.T;
+    auto mid = [&](auto edge_c) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int col = wcol + 32 * j;
-      const int t = n0 - h2 + col;
-      const bool inside = t >= 0 && t < p.T;
+      for (int j = 0; j < NB; ++j) {
+        const int col = wcol + 32 * j;
+        const int t = n0 - h2 + col;
+        const bool inside = t >= 0 && t < p.T;
 #pragma unroll
-      for (int mi = 0; mi < MB; ++mi)
+        for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          unsigned w[4];
+          for (int i = 0; i < 2; ++i) {
+            unsigned w[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const unsigned r16 = pk2<F16>(acc[mi][j][8 * i + 2 * e] + bia[mi][8 * i + 2 * e],
-                                          acc[mi][j][8 * i + 2 * e + 1] + bia[mi][8 * i + 2 * e + 1]);
-            if (RB2) {  // the rounded t1 is c2's residual: it stays in the accumulators
-              acc[mi][j][8 * i + 2 * e] = lo16<F16>(r16);
-              acc[mi][j][8 * i + 2 * e + 1] = hi16<F16>(r16);
+            for (int e = 0; e < 4; ++e) {
+              if (RB2) {
+                // the rounded t1 is c2's residual: it stays in the accumulators.  (Element by element here: with the 64
+                // accumulators live through this phase, the aligned register pairs of the packed form spill at C >= 64.)
+                const unsigned r16 = pk2<F16>(acc[mi][j][8 * i + 2 * e] + bia[mi][4 * i + e].x,
+                                              acc[mi][j][8 * i + 2 * e + 1] + bia[mi][4 * i + e].y);
+                acc[mi][j][8 * i + 2 * e] = lo16<F16>(r16);
+                acc[mi][j][8 * i + 2 * e + 1] = hi16<F16>(r16);
+                w[e] = pk2<F16>(lrelu_max(acc[mi][j][8 * i + 2 * e], p.slope), lrelu_max(acc[mi][j][8 * i + 2 * e + 1], p.slope));
+              } else {
+                const f32x2v a2 = f32x2v{acc[mi][j][8 * i + 2 * e], acc[mi][j][8 * i + 2 * e + 1]} + bia[mi][4 * i + e];
+                const f32x2v l2 = lrelu2v(unpack2<F16>(pk2<F16>(a2.x, a2.y)), slope2);
+                w[e] = pk2<F16>(l2.x, l2.y);
+              }
+              if (decltype(edge_c)::value) w[e] = inside ? w[e] : 0u;
             }
-            w[e] = inside ? lrelu_pk<F16>(r16, p.slope) : 0u;
+            *reinterpret_cast<uint4*>(smem_r + (size_t)(col + (RB2 ? h2 : 0)) * RS +
+                                      (co_blk + 32 * mi + 16 * i + 8 * half) * 2) = make_uint4(w[0], w[1], w[2], w[3]);
           }
-          *reinterpret_cast<uint4*>(smem_r + (size_t)(col + (RB2 ? h2 : 0)) * RS +
-                                    (co_blk + 32 * mi + 16 * i + 8 * half) * 2) = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-    }
+      }
+    };
+    if (edge) mid(std::true_type{});
+    else mid(std::false_type{});
+    if (RB2) a_prologue(abase2);
     __syncthreads();
   }
 
@@ -309,52 +320,50 @@ void resblock_pair16_kernel(const ResPairParams p) {
     if (MB == 2 && !RB2) {  // one m-block's residual at a time: 32 registers in flight, not 64
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int col = wcol + 32 * j;
-        const int t = n0 + col;
-        const bool ok = col < NTO && t < p.T;
+        const int t = n0 + wcol + 32 * j;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          uint4 v = make_uint4(0u, 0u, 0u, 0u);
-          if (ok) v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half);
-          rres[mi][j][i] = v;
-        }
+        for (int i = 0; i < 2; ++i) rres[mi][j][i] = plane_load16(rsx, (t * C + co_blk + 32 * mi + 16 * i + 8 * half) * 2);
       }
     }
-    // the running MRF sum of this m-block's outputs: ALL its pieces requested in one batch, from addresses clamped into
+    // the running MRF sum of this m-block's outputs, requested in batches (JB column blocks at a time: all four, or two
+    // where t1 occupies the accumulators as well -- RB2 -- and a batch of four would spill) from addresses clamped into
     // the utterance (columns outside the stored range get some valid row's values; they are never stored), so the
     // loads go out back to back instead of one load / wait / add round trip per piece (tools/isa_scan.py)
-    uint4 osum[NB][2];
-    if (p.accum) {
+    constexpr int JB = RB2 ? 2 : NB;
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        int t = (RB2 ? n0 - h2 : n0) + wcol + 32 * j;
-        t = t < 0 ? 0 : (t >= p.T ? p.T - 1 : t);
+    for (int j0 = 0; j0 < NB; j0 += JB) {
+      uint4 osum[JB][2];
+      if (p.accum) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          osum[j][i] = *reinterpret_cast<const uint4*>(ob + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half);
-      }
-    }
+        for (int jj = 0; jj < JB; ++jj) {
+          int t = (RB2 ? n0 - h2 : n0) + wcol + 32 * (j0 + jj);
+          t = t < 0 ? 0 : (t >= p.T ? p.T - 1 : t);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const unsigned w4[4] = {rres[mi][j][i].x, rres[mi][j][i].y, rres[mi][j][i].z, rres[mi][j][i].w};
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[2 * e] = RB2 ? acc[mi][j][8 * i + 2 * e] : lo16<F16>(w4[e]);
-          v[2 * e + 1] = RB2 ? acc[mi][j][8 * i + 2 * e + 1] : hi16<F16>(w4[e]);
+          for (int i = 0; i < 2; ++i)
+            osum[jj][i] = *reinterpret_cast<const uint4*>(ob + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half);
         }
-        if (p.accum) {
-          const unsigned o4[4] = {osum[j][i].x, osum[j][i].y, osum[j][i].z, osum[j][i].w};
+      }
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+        const int j = j0 + jj;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned w4[4] = {rres[mi][j][i].x, rres[mi][j][i].y, rres[mi][j][i].z, rres[mi][j][i].w};
+          f32x2v v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = RB2 ? f32x2v{acc[mi][j][8 * i + 2 * e], acc[mi][j][8 * i + 2 * e + 1]} : unpack2<F16>(w4[e]);
+          if (p.accum) {
+            const unsigned o4[4] = {osum[jj][i].x, osum[jj][i].y, osum[jj][i].z, osum[jj][i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += unpack2<F16>(o4[e]);
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[2 * e] += lo16<F16>(o4[e]);
-            v[2 * e + 1] += hi16<F16>(o4[e]);
+            acc[mi][j][8 * i + 2 * e] = v[e].x;
+            acc[mi][j][8 * i + 2 * e + 1] = v[e].y;
           }
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[mi][j][8 * i + e] = v[e];
       }
     }
     if (MB == 2) __builtin_amdgcn_sched_barrier(0);
@@ -362,11 +371,14 @@ void resblock_pair16_kernel(const ResPairParams p) {
   conv_loop(abase2, dil2);
 
   // ---- 5. epilogue -----------------------------------------------------------------------------
-  float bia[MB][16];
+  f32x2v bia[MB][8];
 #pragma unroll
   for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bia[mi][r] = p.bias2[co_blk + 32 * mi + 16 * (r >> 3) + 8 * half + (r & 7)];
+    for (int r = 0; r < 8; ++r) {
+      const int cc = co_blk + 32 * mi + 16 * (r >> 2) + 8 * half + 2 * (r & 3);
+      bia[mi][r] = f32x2v{p.bias2[cc], p.bias2[cc + 1]};
+    }
   auto store_all = [&](auto fin) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -378,20 +390,25 @@ void resblock_pair16_kernel(const ResPairParams p) {
       for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          float v[8];
+          unsigned w[4];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fin(acc[mi][j][8 * i + e] + bia[mi][8 * i + e]);
-          uint4 o;
-          o.x = pk2<F16>(v[0], v[1]); o.y = pk2<F16>(v[2], v[3]);
-          o.z = pk2<F16>(v[4], v[5]); o.w = pk2<F16>(v[6], v[7]);
-          *reinterpret_cast<uint4*>(ob + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half) = o;
+          for (int e = 0; e < 4; ++e) {
+            const f32x2v v = fin(f32x2v{acc[mi][j][8 * i + 2 * e], acc[mi][j][8 * i + 2 * e + 1]} + bia[mi][4 * i + e]);
+            w[e] = pk2<F16>(v.x, v.y);
+          }
+          *reinterpret_cast<uint4*>(ob + (int64_t)t * C + co_blk + 32 * mi + 16 * i + 8 * half) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
   };
   const float dv = p.out_div, dinv = 1.f / p.out_div;  // the MRF mean (common.h: mrf_div), uniform choice
-  if (dv == 1.f) store_all([](float v) { return v; });
-  else if (mrf_div_fast(dv)) store_all([=](float v) { return div_small_const(v, dv, dinv); });
-  else store_all([=](float v) { return v / dv; });
+  if (dv == 1.f) {
+    store_all([](f32x2v v) { return v; });
+  } else if (mrf_div_fast(dv)) {
+    const f32x2v c2 = {dinv, dinv}, nd2 = {-dv, -dv};
+    store_all([=](f32x2v v) { return div_small_const2(v, nd2, c2); });
+  } else {
+    store_all([=](f32x2v v) { return f32x2v{v.x / dv, v.y / dv}; });
+  }
 }
 
 template <int C, int NR, int OCC, bool RB2, int MB>
@@ -408,7 +425,10 @@ static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream
   WETTS_REQUIRE(nb < (1ll << 30), "resblock grid too large");
   p.nblocks = (int)nb;
   const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);
-  const size_t lds = (size_t)(NTC + 2 * (h1 > h2 ? h1 : h2)) * RS;
+  WETTS_REQUIRE((int64_t)p.T * C * 2 < (int64_t)INT32_MAX, "utterance plane too large for the pair kernel's 32-bit offsets");
+  constexpr int RPP = NTH / (C / 8);  // the tile in whole staging passes (the kernel's stores carry no row guard)
+  const size_t lds = (size_t)((NTC + 2 * (h1 > h2 ? h1 : h2) + RPP - 1) / RPP * RPP) * RS;
+  WETTS_REQUIRE(lds <= 64 * 1024, "pair tile exceeds the default dynamic LDS");
   if (f16)
     hipLaunchKernelGGL((resblock_pair16_kernel<C, true, NR, OCC, RB2, MB>), dim3(grid), dim3(NTH), lds, stream, p);
   else

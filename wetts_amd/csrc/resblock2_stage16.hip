@@ -37,25 +37,6 @@ namespace wetts {
 //  * the `inside` select of lrelu(t) and the choice of the quotient are uniform per block and hoisted out of the
 //    per-element loops; bias adds, slope products and the quotient run on pairs (v_pk_add / mul / fma_f32).
 // Operation order and rounding points per output element are unchanged: bit-identical to the chain-by-chain launches.
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-constexpr int kBufRsrcRaw = 0x00020000;  // gfx9 family raw buffer: 32-bit data format, no swizzle
-
-template <bool F16>
-__device__ __forceinline__ f32x2v unpack2(unsigned w) { return f32x2v{lo16<F16>(w), hi16<F16>(w)}; }
-// leaky-relu of a pair: one packed product, two v_max (max(x, slope x), see conv16_dev.h: lrelu_max)
-__device__ __forceinline__ f32x2v lrelu2v(f32x2v v, f32x2v slope2) {
-  const f32x2v m = v * slope2;
-  f32x2v r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r.x) : "v"(v.x), "v"(m.x));
-  asm("v_max_f32 %0, %1, %2" : "=v"(r.y) : "v"(v.y), "v"(m.y));
-  return r;
-}
-template <bool F16>
-__device__ __forceinline__ unsigned lrelu_pk2(unsigned w, f32x2v slope2) {
-  const f32x2v r = lrelu2v(unpack2<F16>(w), slope2);
-  return pk2<F16>(r.x, r.y);
-}
-
 template <int C, bool F16, int NR, int OCC, int NB, bool SHARED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 void rb2_stage16_kernel(const ResStage2Params p) {
@@ -91,7 +72,7 @@ void rb2_stage16_kernel(const ResStage2Params p) {
   const int n0 = ntile * NTO;
   const unsigned short* xb = p.x + (int64_t)b * p.T * C;
   // the utterance's [T][C] plane as a raw buffer: offsets outside it (rows before 0 / from T on) load zeros
-  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xb), 0, p.T * C * 2, kBufRsrcRaw);
+  const __amdgpu_buffer_rsrc_t rsx = plane_rsrc(xb, p.T * C * 2);
   const int co_blk = wm * 32;
   const int wcol = wn * (32 * NB) + (lane & 31);
   unsigned char* const xt = smem_r;                                       // lrelu(x)
@@ -100,9 +81,7 @@ void rb2_stage16_kernel(const ResStage2Params p) {
   // columns whose time lies outside the utterance exist only in its first / last tiles (block-uniform)
   const bool edge = n0 - o < 0 || n0 - o + NTC > p.T;
 
-  auto load16 = [&](int byte_off) {
-    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsx, byte_off, 0, 0));
-  };
+  auto load16 = [&](int byte_off) { return plane_load16(rsx, byte_off); };
 
   // raw x at this lane's columns: c1's accumulator init in every chain (requested first: the oldest loads in flight).
   // SHARED (C = 32) keeps it in registers across the chains; the C = 64 tile has no room (it spills) and reloads it per
@@ -334,11 +313,7 @@ void rb2_stage16_kernel(const ResStage2Params p) {
       } else if (mrf_div_fast(dv)) {  // (num_kernels of every recipe: 3) common.h: div_small_const on a pair
         const float dinv = 1.f / dv;
         const f32x2v c2 = {dinv, dinv}, nd2 = {-dv, -dv};
-        fin_all([=](f32x2v v) {
-          const f32x2v q = v * c2;
-          const f32x2v r = __builtin_elementwise_fma(nd2, q, v);
-          return __builtin_elementwise_fma(r, c2, q);
-        });
+        fin_all([=](f32x2v v) { return div_small_const2(v, nd2, c2); });
       } else {
         fin_all([=](f32x2v v) { return f32x2v{v.x / dv, v.y / dv}; });
       }

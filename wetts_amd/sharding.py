@@ -24,6 +24,33 @@ def env_world():
 DEFAULT_TIMEOUT_S = 420.0
 
 
+DIAG_PATH = os.path.join("gpurun_out", "scale_diag.json")
+
+
+def diag(event, **fields):
+    """Appends one JSON line to gpurun_out/scale_diag.json (relative to the working directory -- the repo root on the GPU
+    box, the directory the driver pulls back): what every rank of a multi-GPU run says on stderr -- which device it bound,
+    which phase failed -- plus rank 0's result or partial line, in ONE file that survives the run.  The first N > 1 run is
+    the driver's and nobody can rehearse it; its post-mortem should not depend on captured stderr.  One small O_APPEND
+    write per event (atomic between the ranks of a node); never raises."""
+    import json
+    import time
+    try:
+        if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+            return
+        os.makedirs(os.path.dirname(DIAG_PATH), exist_ok=True)
+        line = json.dumps(dict(event=event, rank=int(os.environ.get("RANK", "0")),
+                               world=int(os.environ.get("WORLD_SIZE", "1")), pid=os.getpid(),
+                               t=round(time.time(), 3), **fields)) + "\n"
+        fd = os.open(DIAG_PATH, os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
+        try:
+            os.write(fd, line.encode())
+        finally:
+            os.close(fd)
+    except Exception:
+        pass
+
+
 def describe_device(local_rank=None):
     """One line naming the HIP device this rank is bound to (index, name, PCI address where torch exposes it): what a
     failed multi-GPU start-up needs on stderr to tell WHICH GPU did not come up."""
@@ -66,6 +93,7 @@ def init_process_group(backend=None, timeout_s=None, force=False):
         sys.stderr.write(f"[wetts rank {rank}/{world}] {backend} on {describe_device()} "
                          f"(timeout {timeout_s:.0f} s, NCCL_DEBUG={os.environ['NCCL_DEBUG']})\n")
         sys.stderr.flush()
+        diag("init_process_group", backend=backend, device=describe_device(), timeout_s=timeout_s)
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return rank, local_rank, world
@@ -188,6 +216,7 @@ class PhaseMonitor:
         sys.stderr.write(f"[wetts rank {self.rank}/{self.world}] {why} in phase '{phase}' on {describe_device()}; "
                          f"ranks that reached it: {seen if seen is not None else 'unknown'} of {self.world}\n")
         sys.stderr.flush()
+        diag("phase_failed", phase=phase, why=why, ranks_seen=seen, device=describe_device())
         try:
             if self.on_expire is not None:
                 self.on_expire(phase, seen, why)
