@@ -437,7 +437,7 @@ class HipBackend:
         for _ in range(n):
             for hb in pinned:
                 # (net.upload: on the stream that reads the ids -- the encoder's side stream when calls are pipelined)
-                xd2, ld2, sd2 = (net.upload(t) if hasattr(net, "upload") else t.to(dev, non_blocking=True) for t in hb)
+                xd2, ld2, sd2 = (net.upload(t, non_blocking=True) if hasattr(net, "upload") else t.to(dev, non_blocking=True) for t in hb)
                 o, _, y_mask, _ = net.infer(xd2, ld2, sid=sd2, **infer_kw)
                 if not pipelined:
                     _ = o.cpu()

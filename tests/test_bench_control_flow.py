@@ -24,13 +24,24 @@ def _run(extra_env=None, args=(), gpus=2, batch=8):
     return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
 
 
-def test_bench_two_ranks_control_flow_and_reductions():
+def _diag(path):
+    return [json.loads(l) for l in open(path).read().splitlines() if l.strip()]
+
+
+def test_bench_two_ranks_control_flow_and_reductions(tmp_path):
     sys.path.insert(0, ROOT)
     import bench
     from tests import bench_stub
     from wetts_amd import batching
-    p = _run()
+    diag = tmp_path / "scale_diag.json"
+    p = _run({"WETTS_SCALE_DIAG": str(diag)})
     assert p.returncode == 0, p.stderr[-3000:]
+    # gpurun_out/scale_diag.json (here: the tmp path): every rank's start-up line and rank 0's result, one JSON line each
+    ev = _diag(diag)
+    assert sorted(e["rank"] for e in ev if e["event"] == "init_process_group") == [0, 1]
+    assert all("device" in e and e["world"] == 2 for e in ev if e["event"] == "init_process_group")
+    res = [e for e in ev if e["event"] == "result"]
+    assert len(res) == 1 and res[0]["rank"] == 0 and res[0]["n_gpus"] == 2 and len(res[0]["rank_ms"]) == 2
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout  # exactly ONE JSON line, from rank 0
     # ... and nothing else on stdout: the banners Gloo prints from C++ ("[Gloo] Rank 0 is connected ...") go to stderr
@@ -142,10 +153,19 @@ def test_bench_eight_ranks_one_hangs_after_the_rendezvous_partial_line_not_a_han
     with code 4, and the launcher comes back in seconds."""
     import time
     t0 = time.time()
+    diag = os.path.join(ROOT, "gpurun_out", "scale_diag_test_hang.json")
+    if os.path.exists(diag):
+        os.remove(diag)
     p = _run({"WETTS_STUB_HANG_RANK": "5", "WETTS_STUB_HANG_AT": "load", "WETTS_BENCH_PHASE_DEADLINE_S": "15",
-              "WETTS_DIST_TIMEOUT_S": "60"}, gpus=8, batch=2)
+              "WETTS_DIST_TIMEOUT_S": "60", "WETTS_SCALE_DIAG": diag}, gpus=8, batch=2)
     assert p.returncode != 0
     d = _partial(p)
+    ev = _diag(diag)  # the post-mortem file: 8 ranks bound a device, rank 0 said which phase failed and who was there
+    assert sorted(e["rank"] for e in ev if e["event"] == "init_process_group") == list(range(8))
+    failed = [e for e in ev if e["event"] == "phase_failed" and e["rank"] == 0]
+    assert failed and failed[0]["phase"] == "timed" and failed[0]["ranks_seen"] == 7
+    assert [e for e in ev if e["event"] == "partial_line"]
+    os.remove(diag)
     assert d["n_gpus"] == 8 and d["ranks_seen"] == 7 and d["failed_phase"] == "timed"
     assert "deadline" in d["error"] or "SIGTERM" in d["error"]
     assert time.time() - t0 < 180  # (the stub's rank would sleep for an hour; c10d's own default timeout is 10+ minutes)
@@ -168,6 +188,32 @@ def test_bench_two_ranks_one_crashes_partial_line_on_the_launchers_sigterm():
     d = _partial(p)
     assert d["ranks_seen"] <= 2 and ("SIGTERM" in d["error"] or "Error" in d["error"] or "deadline" in d["error"])
     assert "this rank dies while loading its weights" in p.stderr
+
+
+def test_scale_line_names_the_same_workload_as_the_single_gpu_line():
+    """The driver computes scaling efficiency from its N = 1 / 2 / 4 / 8 runs of `bench.py --gpus N` and checks the N = 1
+    one against BENCH: weak scaling, per-GPU work fixed, so `config.workload` -- which names the preset, the model, the
+    per-GPU batch, the precision and the BASELINE.json label -- must be the SAME string at every N for the default
+    invocation (only `global_batch` and `parallelism` carry N), and `value_excludes` says what `value` leaves out."""
+    lines = {}
+    for n in (1, 2):
+        env = dict(os.environ)
+        env.pop("WORLD_SIZE", None)
+        env.pop("RANK", None)
+        env.update(WETTS_BENCH_TEST_BACKEND="tests.bench_stub:StubBackend", WETTS_DIST_BACKEND="gloo",
+                   PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""), OMP_NUM_THREADS="1",
+                   WETTS_SCALE_DIAG=os.devnull)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+               "--presteps-s", "0.02", "--no-cpu-baseline"]
+        p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines[n] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    a, b = lines[1], lines[2]
+    assert a["config"]["workload"] == b["config"]["workload"] and "BASELINE.json configs[1]" in a["config"]["workload"]
+    assert "not a BASELINE" not in a["config"]["workload"]
+    assert a["metric"] == b["metric"] and a["unit"] == b["unit"] and a["scaling"] == b["scaling"] == "weak"
+    assert (a["n_gpus"], b["n_gpus"]) == (1, 2) and b["config"]["global_batch"] == 2 * a["config"]["global_batch"]
+    assert "H2D" in a["value_excludes"] and "pcie_inclusive_pipelined_samples_per_s" in a["value_excludes"]
 
 
 def test_bench_refuses_a_corrupted_broadcast():

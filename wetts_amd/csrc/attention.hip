@@ -435,14 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NKS <= 24 ?
   }
 }
 
-static int attn_flash_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("WETTS_ATTN_FLASH");  // 0: scores / softmax / P.V as separate kernels
-    v = e ? atoi(e) : 1;
-  }
-  return v;
-}
+static int attn_flash_enabled() { return 1; }  // (the A/B against separate scores / softmax / P.V kernels is settled: profiles/r01_ab_attn_flash.txt)
 
 int64_t attn_score_elems(int window, int dk, int B, int n_heads, int T) {
   const bool mfma_path = window < 0 || T >= 64;
@@ -662,14 +655,8 @@ __global__ __launch_bounds__(1024) void attn_small_kernel(
   }
 }
 
-static int attn_small_max_t() {  // WETTS_ATTN_SMALL=0 keeps the multi-kernel paths (A/B switch)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("WETTS_ATTN_SMALL");
-    v = e ? atoi(e) : 128;
-  }
-  return v;
-}
+// longest sequence the one-launch kernel covers (longer ones take the multi-kernel paths)
+static int attn_small_max_t() { return 128; }
 
 int32_t k_rel_attention(const float* q, const float* k, const float* v, int64_t qkv_batch_stride,
                         const float* mask, const float* emb_rel_k, const float* emb_rel_v,

@@ -839,9 +839,8 @@ int32_t launch_conv(const PackedConv& pc, ConvParams p, hipStream_t stream) {
   }
   // 1x1 convs with a plain input: the LDS-DMA GEMM with strip scheduling (gemm_pw.hip)
   {
-    static const int pw_on = [] { const char* e = getenv("WETTS_PW_GEMM"); return e ? atoi(e) : 1; }();  // A/B switch
     const int v = conv_variant();
-    if (pw_on && (v == 0 || (v >= 7 && v <= 9)) && pw_gemm_eligible(pc, p)) return launch_pw_gemm(pc, p, stream, v);
+    if ((v == 0 || (v >= 7 && v <= 9)) && pw_gemm_eligible(pc, p)) return launch_pw_gemm(pc, p, stream, v);
   }
   // tile selection: fill the chip first, then maximise per-wave register reuse
   const int64_t cols = (int64_t)p.N * p.B;

@@ -267,12 +267,10 @@ template <int KT, int SCH, int MAXKG>
 static int32_t launch_small_cfg(const ConvParams& p, hipStream_t stream, int force_kg = 0) {
   const int64_t blocks = (int64_t)cdiv(p.M, 32) * cdiv(p.N, 32) * p.B;
   const int NS = p.nchunks / SCH;
-  // WETTS_SMALL_KG8_NS / WETTS_SMALL_KG16_NS (experiment): stages from which 8 / 16 waves are used.  8 waves from 8 stages
-  // (round 5; was 16): the flow's in_layers (12 stages) and the C = 128 window convs get the 8-wave split -- B = 1
-  // encoder call 1.491 -> 1.455 ms, first window 1.054 -> 1.025, first chunk 2.54 -> 2.48 ms same box
-  // (profiles/r05_small_launch_knobs.txt)
-  static const int ns8 = getenv("WETTS_SMALL_KG8_NS") ? atoi(getenv("WETTS_SMALL_KG8_NS")) : 8;
-  static const int ns16 = getenv("WETTS_SMALL_KG16_NS") ? atoi(getenv("WETTS_SMALL_KG16_NS")) : 32;
+  // stages from which 8 / 16 waves are used.  8 waves from 8 stages (round 5; was 16): the flow's in_layers (12 stages)
+  // and the C = 128 window convs get the 8-wave split -- B = 1 encoder call 1.491 -> 1.455 ms, first window 1.054 ->
+  // 1.025, first chunk 2.54 -> 2.48 ms same box (profiles/r05_small_launch_knobs.txt; the sweep's switches are gone)
+  constexpr int ns8 = 8, ns16 = 32;
   int kg = 4;
   if (NS >= ns8 && blocks * 2 <= 512) kg = 8;
   if (NS >= ns16 && blocks * 4 <= 512) kg = 16;
@@ -303,11 +301,8 @@ int32_t launch_conv_small(const ConvParams& p, hipStream_t stream, bool* taken) 
     case 1: {
       // 1x1 convs of launches with at most 256 blocks: one-chunk stages over 8 waves instead of four-chunk stages
       // over 4 (of which one idles at 12 chunks): a wave's chain is 1-2 short stages instead of one long one --
-      // B = 1 encoder call 1.64 -> 1.51 ms (profiles/r03_small_1x1_ab.txt).  WETTS_SMALL_1X1: 0 = the four-chunk
-      // form, 1 / 2 / 3 = one-chunk stages over 4 / 8 / 16 waves.
-      static const int mode = getenv("WETTS_SMALL_1X1") ? atoi(getenv("WETTS_SMALL_1X1")) : 2;
-      if (mode > 0 && blocks_of(p) * 4 <= 1024)
-        return launch_small_cfg<1, 1, 16>(p, stream, mode == 1 ? 4 : mode == 2 ? 8 : 16);
+      // B = 1 encoder call 1.64 -> 1.51 ms (profiles/r03_small_1x1_ab.txt: 8 waves beat 4 and 16).
+      if (blocks_of(p) * 4 <= 1024) return launch_small_cfg<1, 1, 16>(p, stream, 8);
       return sch4 ? launch_small_cfg<1, 4, 8>(p, stream) : launch_small_cfg<1, 1, 16>(p, stream);
     }
     case 2: return launch_small_cfg<2, 1, 16>(p, stream);

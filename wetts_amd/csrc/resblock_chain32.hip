@@ -399,17 +399,11 @@ static void chain_geometry(int ktaps, const int* dil, int npairs, int* S, int* M
 // CU's LDS, else 4.  Measured (profiles/r05_chain_narrow_tiles_ab.txt, C = 32): k = 3 whole chain 97.7 -> 98.6 TF/s,
 // k = 7 as three pairs 113.0 -> 116.8 (and ahead of the whole chain's 112.3, which the 15 % halo bound now rules out by
 // itself), k = 11 pairs 124.2 -> 125.8; headline 61.14 -> 60.9 ms/step same box.  C = 64 loses 1 % (its halo share
-// doubles twice as fast) and keeps 4.  WETTS_CHAIN_NB3=0 is the A/B switch (2: two blocks per wave, four resident
-// blocks -- measured too, no better than 3).
-static int g_chain_nb3 = -1;
+// doubles twice as fast) and keeps 4.  (Two blocks per wave, four resident blocks: measured too, no better than 3 --
+// profiles/r05_chain_narrow_tiles_ab.txt; the A/B switch is gone.)
 static int chain_nb(int C, int Mmin) {
-  if (g_chain_nb3 < 0) {
-    const char* e = getenv("WETTS_CHAIN_NB3");
-    g_chain_nb3 = e ? atoi(e) : 3;
-  }
-  if (!g_chain_nb3 || C > 32) return 4;
-  // (the switch's value 2 asks for two blocks per wave = FOUR resident blocks: measurement only)
-  const int want = g_chain_nb3 == 2 ? 2 : 3, blocks = want == 2 ? 4 : 3;
+  if (C > 32) return 4;
+  const int want = 3, blocks = 3;
   const int ntc = 32 * want * (4 / (C / 32));
   const int wp = (ntc + 2 * Mmin + 4 + 3) & ~3;
   return blocks * (int64_t)C * wp * 4 <= 160 * 1024 ? want : 4;

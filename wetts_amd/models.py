@@ -183,28 +183,30 @@ class SynthesizerTrn:
         return self
 
     def _new_enc_stream(self):
-        """The side stream of overlap mode.  WETTS_ENC_STREAM_PRIORITY (measurement switch) asks for a stream priority
-        (torch convention: lower = higher priority)."""
-        pr = os.environ.get("WETTS_ENC_STREAM_PRIORITY")
-        if pr is not None:
-            return torch.cuda.Stream(device=self.device, priority=int(pr))
+        """The side stream of overlap mode (stream priorities were measured in round 5: not a lever)."""
         return torch.cuda.Stream(device=self.device)
 
-    def upload(self, t, dtype=None, consumer="encoder"):
+    def upload(self, t, dtype=None, consumer="encoder", non_blocking=False):
         """Host tensor / array -> device tensor on the stream that will read it.  `consumer="encoder"` (ids, lengths,
         speaker ids: what infer() / infer_encoder() read): the caller's stream, or in overlap mode the encoder's side
         stream, whose work is NOT ordered behind the caller's stream (see set_overlap).  `consumer="decoder"` (a z chunk
         for export_decoder_forward / hifigan): always the caller's stream, where the decoder runs in either mode.
-        A pinned source is copied without blocking the host (the copy is stream-ordered in front of its reader).  The
-        wetts_amd hosts (sessions, batching, CLI) put their inputs on the device through this."""
+        `non_blocking=True` (opt-in, pinned sources only): the call returns before the copy has finished -- the copy is
+        stream-ordered in front of its reader, but the CALLER must not refill the pinned buffer until that stream has
+        passed it (a serving loop that reuses one staging buffer would otherwise overwrite ids still in flight); the
+        default waits for the copy, like `tensor.to(device)` of a pageable source.  The wetts_amd hosts (sessions,
+        batching, CLI) put their inputs on the device through this."""
         t = torch.as_tensor(t)
-        nb = bool(t.device.type == "cpu" and t.is_pinned())
+        nb = bool(non_blocking and t.device.type == "cpu" and t.is_pinned())
         if consumer != "encoder" or not (self.overlap and self.device.type == "cuda"):
             return t.to(device=self.device, dtype=dtype, non_blocking=nb)
         if self._enc_stream is None:
             self._enc_stream = self._new_enc_stream()
         with torch.cuda.stream(self._enc_stream):
-            return t.to(device=self.device, dtype=dtype, non_blocking=nb)
+            out = t.to(device=self.device, dtype=dtype, non_blocking=nb)
+        if not nb and t.device.type == "cpu" and t.is_pinned():
+            self._enc_stream.synchronize()  # (a pinned source is copied asynchronously on a non-default stream)
+        return out
 
     def blob_layout(self):
         return checkpoint.blob_layout(self.cfg)

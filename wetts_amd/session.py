@@ -147,10 +147,13 @@ class EncoderSession(_SessionBase):
 
     def run(self, output_names, feeds, run_options=None):
         self._check(output_names)
-        x = self._dev(feeds["input"], torch.int64)
-        xl = self._dev(feeds["input_lengths"], torch.int64)
+        # (the graphed path copies its inputs into graph-owned buffers on the CALLER's stream, so they are uploaded there
+        # too; the plain path reads them on the encoder's side stream in overlap mode)
+        where = "decoder" if self._graphed is not None else "encoder"
+        x = self._dev(feeds["input"], torch.int64, consumer=where)
+        xl = self._dev(feeds["input_lengths"], torch.int64, consumer=where)
         scales = np.asarray(feeds["scales"], dtype=np.float32)
-        sid = self._dev(feeds["sid"], torch.int64)
+        sid = self._dev(feeds["sid"], torch.int64, consumer=where)
         if self._graphed is not None:
             # export_encoder_forward (models.py:346-358): row 0 of `scales`, z * y_mask, time-major
             st = self._graphed.encode(x, xl, sid, float(scales[0][0]), float(scales[0][1]), float(scales[0][2]))

@@ -24,7 +24,7 @@ def env_world():
 DEFAULT_TIMEOUT_S = 420.0
 
 
-DIAG_PATH = os.path.join("gpurun_out", "scale_diag.json")
+DIAG_PATH = os.path.join("gpurun_out", "scale_diag.json")  # (WETTS_SCALE_DIAG: another path -- the tests' tmp dir)
 
 
 def diag(event, **fields):
@@ -38,11 +38,12 @@ def diag(event, **fields):
     try:
         if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
             return
-        os.makedirs(os.path.dirname(DIAG_PATH), exist_ok=True)
+        path = os.environ.get("WETTS_SCALE_DIAG", DIAG_PATH)
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         line = json.dumps(dict(event=event, rank=int(os.environ.get("RANK", "0")),
                                world=int(os.environ.get("WORLD_SIZE", "1")), pid=os.getpid(),
                                t=round(time.time(), 3), **fields)) + "\n"
-        fd = os.open(DIAG_PATH, os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
+        fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
         try:
             os.write(fd, line.encode())
         finally:
