@@ -564,6 +564,35 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, int bid) {
         const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         bia[i][r] = (p.bias && row < p.M) ? p.bias[row >> sh] : 0.f;
       }
+    // Stride >= 4 with the padding and the output length multiples of 4 (k = 16 / stride 8: every first and second stage):
+    // a lane's four consecutive accumulator rows are four consecutive PHASES of one output channel, i.e. four consecutive
+    // samples t0 .. t0 + 3 with t0 a multiple of 4 -- one aligned 16-byte store instead of four scalar ones, valid or
+    // invalid as a whole (round 6: 650 -> 633 us and 596 -> 530 us for the two k = 16 stages of the headline).
+    if (sh >= 2 && (p.up_pad & 3) == 0 && (Tout & 3) == 0 && (p.M & 3) == 0) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = wrow0 + i * 32 + 8 * q + 4 * half;  // rows row .. row + 3: phases ph .. ph + 3 of channel co
+          const int co = row >> sh, ph = row & um;
+          const unsigned rowoff = (unsigned)co * ocs4;
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const int col = wcol0 + 32 * j + (lane & 31);
+            const int t = (col << sh) + ph - p.up_pad;
+            if (row < p.M && col < N && t >= 0 && t < Tout) {
+              f32x4v v;
+              v.x = acc[i][j][4 * q] + bia[i][4 * q];
+              v.y = acc[i][j][4 * q + 1] + bia[i][4 * q + 1];
+              v.z = acc[i][j][4 * q + 2] + bia[i][4 * q + 2];
+              v.w = acc[i][j][4 * q + 3] + bia[i][4 * q + 3];
+              *reinterpret_cast<f32x4v*>(obase + (rowoff + (unsigned)t * 4u)) = v;
+            }
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
 #pragma unroll

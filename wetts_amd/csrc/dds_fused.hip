@@ -52,23 +52,21 @@ __global__ __launch_bounds__(NW * 16) void dds_fused_kernel(const DdsFusedParams
       const int c = cg + kDdsCG * j;
       xv[j] = (inside && c < C) ? xg[(int64_t)c * T + t] : 0.f;
     }
-    const int np = 27 * C;
-    constexpr int NPV = (27 * kDdsCG * kDdsPer + NTHR - 1) / NTHR;
-    float pv[NPV];
+    // (round 6) one thread per channel fetches that channel's 27 parameters through UNIFORM base pointers, all 27
+    // loads issued back to back.  Before, a thread derived (layer, k, c) from a flat index and picked its source
+    // pointer per lane out of the argument arrays: a pointer fetch and a dependent value fetch, one after the other,
+    // for each of its ~10 parameters -- the runs of serialised round trips tools/isa_scan.py flagged, and most of the
+    // 52 us this launch took at B = 1.
+    float pv[27];
+    if (tid < C) {
 #pragma unroll
-    for (int u = 0; u < NPV; ++u) {
-      const int e = tid + NTHR * u;
-      const int ec = e < np ? e : 0;
-      const int layer = ec / (9 * C), k = (ec / C) % 9, c = ec % C;
-      const float* src = k < 3 ? p.sep_w[layer] + c * 3 + k
-                       : k == 3 ? p.sep_b[layer] + c
-                       : k == 4 ? p.n1g[layer] + c
-                       : k == 5 ? p.n1b[layer] + c
-                       : k == 6 ? p.n2g[layer] + c
-                       : k == 7 ? p.n2b[layer] + c
-                                : (p.bias[layer] ? p.bias[layer] + c : p.sep_b[layer] + c);
-      pv[u] = *src;
-      if (k == 8 && !p.bias[layer]) pv[u] = 0.f;
+      for (int layer = 0; layer < 3; ++layer)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const float* src = k < 3 ? p.sep_w[layer] : k == 3 ? p.sep_b[layer] : k == 4 ? p.n1g[layer]
+                           : k == 5 ? p.n1b[layer] : k == 6 ? p.n2g[layer] : k == 7 ? p.n2b[layer] : p.bias[layer];
+          pv[layer * 9 + k] = src ? src[k < 3 ? tid * 3 + k : tid] : 0.f;
+        }
     }
     const float mv = inside ? p.mask[(int64_t)b * T + t] : 0.f;
 #pragma unroll
@@ -76,10 +74,9 @@ __global__ __launch_bounds__(NW * 16) void dds_fused_kernel(const DdsFusedParams
       const int c = cg + kDdsCG * j;
       if (c < C) xs[c * kDdsW + col] = xv[j];
     }
+    if (tid < C) {
 #pragma unroll
-    for (int u = 0; u < NPV; ++u) {
-      const int e = tid + NTHR * u;
-      if (e < np) prm[e] = pv[u];
+      for (int q = 0; q < 27; ++q) prm[q * C + tid] = pv[q];
     }
     if (cg == 0) mk[col] = mv;
   }
