@@ -507,8 +507,9 @@ def hifigan_16bit_sim(W, cfg, z, g, dtype=torch.bfloat16):
 def hifigan_bf16sim(W, cfg, z, g):
     """Numerics spec of the bf16 decoder mode (wetts_set_decoder_precision(m, 1)): same graph as
     `hifigan`, with conv weights and every inter-conv activation rounded to bfloat16, f32
-    accumulation, f32 bias / residual / running-sum adds before the single rounding per output."""
-    x = conv1d(W, "dec.conv_pre", z, padding=3)
+    accumulation, f32 bias / residual / running-sum adds before the single rounding per output.  conv_pre is a conv of
+    the mode like the others (round 6): 16-bit input z, 16-bit weights, f32 bias + speaker conditioning, one rounding."""
+    x = F.conv1d(_q(z), _q(W["dec.conv_pre.weight"]), W["dec.conv_pre.bias"], padding=3)
     if g is not None:
         x = x + conv1d(W, "dec.cond", g)
     x = _q(x)

@@ -104,6 +104,9 @@ int32_t launch_conv_bf16(const PackedConvB& pc, ConvBParams p, hipStream_t strea
 int resblock_pair16_ntc(int C);
 int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, int f16,
                        hipStream_t s);
+// ... with batch / channel strides and an optional row mask [B][>= T]: out = round16(x * mask)
+int32_t k_cf32_to_cl16_strided(const float* x, int64_t x_bs, int64_t x_cs, const float* mask, int64_t mask_stride,
+                               unsigned short* out, int B, int C, int T, int f16, hipStream_t s);
 // ---- 16-bit WaveNet layers of the flow (wn16.hip), channel-last like the 16-bit decoder ----------
 // acts[row][c] = tanh(xin[row][c]) * sigmoid(xin[row][H + c])   (commons.py:98-105), rows = B*T
 int32_t k_gate_cl16(const unsigned short* xin, unsigned short* acts, int64_t rows, int H, int f16,

@@ -578,10 +578,11 @@ int32_t launch_conv_bf16(const PackedConvB& pc, ConvBParams p, hipStream_t strea
 // ------------------------------------------------------------------------------------------
 // layout / precision boundaries of the bf16 decoder
 // ------------------------------------------------------------------------------------------
-// f32 channel-first [B,C,T] -> bf16 channel-last [B,T,C]
+// f32 channel-first [B,C,T] (batch / channel strides x_bs / x_cs, optional row mask [B][>= T]) -> 16-bit channel-last
+// [B,T,C]: (x * mask) rounded once
 template <bool F16>
-__global__ void cf32_to_cl16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
-                                    int B, int C, int T) {
+__global__ void cf32_to_cl16_kernel(const float* __restrict__ x, int64_t x_bs, int64_t x_cs, const float* __restrict__ mask,
+                                    int64_t mask_stride, unsigned short* __restrict__ out, int B, int C, int T) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, c8, t) with t fastest
   const int C8 = C / 8;
   int64_t total = (int64_t)B * C8 * T;
@@ -589,28 +590,34 @@ __global__ void cf32_to_cl16_kernel(const float* __restrict__ x, unsigned short*
   int t = (int)(idx % T);
   int c8 = (int)((idx / T) % C8);
   int b = (int)(idx / ((int64_t)T * C8));
-  const float* xp = x + ((int64_t)b * C + c8 * 8) * T + t;
+  const float* xp = x + (int64_t)b * x_bs + (int64_t)(c8 * 8) * x_cs + t;
+  const float mk = mask ? mask[(int64_t)b * mask_stride + t] : 1.f;
   uint4 o;
-  o.x = pk2<F16>(xp[0], xp[(int64_t)T]);
-  o.y = pk2<F16>(xp[2 * (int64_t)T], xp[3 * (int64_t)T]);
-  o.z = pk2<F16>(xp[4 * (int64_t)T], xp[5 * (int64_t)T]);
-  o.w = pk2<F16>(xp[6 * (int64_t)T], xp[7 * (int64_t)T]);
+  o.x = pk2<F16>(xp[0] * mk, xp[x_cs] * mk);
+  o.y = pk2<F16>(xp[2 * x_cs] * mk, xp[3 * x_cs] * mk);
+  o.z = pk2<F16>(xp[4 * x_cs] * mk, xp[5 * x_cs] * mk);
+  o.w = pk2<F16>(xp[6 * x_cs] * mk, xp[7 * x_cs] * mk);
   *reinterpret_cast<uint4*>(out + ((int64_t)b * T + t) * C + c8 * 8) = o;
 }
 
-int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, int f16,
-                       hipStream_t s) {
+int32_t k_cf32_to_cl16_strided(const float* x, int64_t x_bs, int64_t x_cs, const float* mask, int64_t mask_stride,
+                               unsigned short* out, int B, int C, int T, int f16, hipStream_t s) {
   WETTS_REQUIRE(C % 8 == 0, "channel count must be a multiple of 8");
   int64_t n = (int64_t)B * (C / 8) * T;
   if (n == 0) return WETTS_OK;
   if (f16)
     hipLaunchKernelGGL(cf32_to_cl16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                       x, out, B, C, T);
+                       x, x_bs, x_cs, mask, mask_stride, out, B, C, T);
   else
     hipLaunchKernelGGL(cf32_to_cl16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       s, x, out, B, C, T);
+                       s, x, x_bs, x_cs, mask, mask_stride, out, B, C, T);
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
+}
+
+int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, int f16,
+                       hipStream_t s) {
+  return k_cf32_to_cl16_strided(x, (int64_t)C * T, T, nullptr, 0, out, B, C, T, f16, s);
 }
 
 // conv_post on channel-last bf16: lrelu(0.01) -> Conv1d(C,1,k) -> tanh -> f32 audio [B,T]

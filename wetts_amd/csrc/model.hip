@@ -457,6 +457,7 @@ struct wetts_model {
   // which 16-bit type the flow / decoder copies currently hold (0 = none); set only after EVERY layer is packed
   mutable int flow_packed_prec = 0, dec_packed_prec = 0;
   mutable std::vector<PackedConvB> b_ups;
+  mutable PackedConvB b_pre;  // conv_pre of the 16-bit decoder (round 6: on the 16-bit kernel like every other conv of the mode)
   mutable std::vector<std::vector<PackedConvB>> b_c1, b_c2;  // per resblock
   // device status word the stage calls OR their WETTS_STATUS_* bits into (wetts_set_status_word)
   mutable int32_t* status_word = nullptr;
@@ -2213,6 +2214,7 @@ static void free_decoder_bf16(const wetts_model* m) {
   for (auto& v : m->b_c1) for (auto& pc : v) free_packed_bf16(&pc);
   for (auto& v : m->b_c2) for (auto& pc : v) free_packed_bf16(&pc);
   free_packed_bf16(&m->b_post);
+  free_packed_bf16(&m->b_pre);
   m->b_ups.clear();
   m->b_c1.clear();
   m->b_c2.clear();
@@ -2226,6 +2228,8 @@ static int32_t pack_decoder_bf16_layers(const wetts_model* m, int f16, hipStream
   m->b_c1.assign(c->n_upsamples * nk, std::vector<PackedConvB>(nd));
   m->b_c2.assign(c->n_upsamples * nk, std::vector<PackedConvB>(c->resblock == 1 ? nd : 0));
   int ch = c->upsample_initial_channel;
+  WETTS_TRY(pack_conv_weight_bf16(m->T("dec.conv_pre.weight"), m->T("dec.conv_pre.bias"), ch, c->inter_channels, 7, 1, 3,
+                                  0, 0, f16, s, &m->b_pre));
   for (int i = 0; i < c->n_upsamples; ++i) {
     const int u = c->upsample_rates[i], uk = c->upsample_kernel_sizes[i];
     WETTS_TRY(pack_conv_weight_bf16(m->T(S("dec.ups.%d.weight", i)), m->T(S("dec.ups.%d.bias", i)),
@@ -2294,8 +2298,10 @@ static ConvBParams convb_io(const unsigned short* x, int Cin, int T, unsigned sh
   return p;
 }
 
-// Generator.forward with bf16 channel-last activations between the convs (f32 accumulate):
-// conv_pre (+cond) runs on the f32 kernel, its output is rounded to bf16; conv_post + tanh are f32.
+// Generator.forward with 16-bit channel-last activations between the convs (f32 accumulate).  conv_pre too (round 6):
+// (z * y_mask) is rounded to 16 bit channel-last and conv_pre (+ cond as a per-utterance bias) runs on the 16-bit kernel
+// -- it was the one conv of the mode left on the f32 kernel, 0.41 ms of the 8.5 ms configs[2] step for a conv that is
+// 60 us at 16 bit; conv_post's tanh is f32.
 static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_bs, int64_t z_cs,
                                 const float* y_mask, int64_t mask_stride, const float* g, int B,
                                 int L, float* audio, void* workspace, int64_t workspace_bytes,
@@ -2305,7 +2311,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
   WETTS_TRY(pack_decoder_bf16(m, s));
   const int64_t mx = dec_max_elems(c, B, L);
   Bump ws(workspace, workspace_bytes);
-  float* pre = ws.take<float>((int64_t)B * C0 * L);
+  unsigned short* z16 = ws.take<unsigned short>((int64_t)B * I * L);
   unsigned short* bx = ws.take<unsigned short>(mx);
   unsigned short* bt = ws.take<unsigned short>(mx);
   unsigned short* bs = ws.take<unsigned short>(mx);
@@ -2319,20 +2325,16 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
     return WETTS_E_WORKSPACE;
   }
   {
-    ConvParams p = conv_io(z, I, L, pre, C0, B);
-    p.x_bs = z_bs;
-    p.x_cs = z_cs;
-    if (y_mask) {
-      p.in_mask = y_mask;
-      p.in_mask_stride = mask_stride;
-    }
+    const int f16 = m->dec_precision == 2 ? 1 : 0;
+    WETTS_TRY(k_cf32_to_cl16_strided(z, z_bs, z_cs, y_mask, mask_stride, z16, B, I, L, f16, s));
+    ConvBParams p = convb_io(z16, I, L, bx, C0, L, B);
+    p.in_act = IN_NONE;
     if (has_g(c) && g) {
       WETTS_TRY(k_cond_linear(g, m->dec_cond_w, m->dec_cond_b, B, C0, c->gin_channels, cond, s));
       p.bias_b = cond;
       p.bias_b_stride = C0;
     }
-    WETTS_TRY(launch_conv(m->conv_pre, p, s));
-    WETTS_TRY(k_cf32_to_cl16(pre, bx, B, C0, L, m->dec_precision == 2 ? 1 : 0, s));
+    WETTS_TRY(launch_conv_bf16(m->b_pre, p, s));
   }
   int ch = C0, len = L;
   unsigned short* x = bx;
