@@ -1,7 +1,7 @@
 #!/bin/bash
-# One GPU-box pass (round 5): parity tests, rocprofv3 kernel stats + HBM counters for every benched line (f32 headline,
+# One GPU-box pass (round 6): parity tests, rocprofv3 kernel stats + HBM counters for every benched line (f32 headline,
 # 16-bit decoder, configs[2], configs[4], Vocos, VITS2 + Vocos, uint8), the bench lines, streaming, MAS.
-# Outputs -> gpurun_out/ ; `python tools/summarize_profiles.py r05` copies the judged summaries into profiles/.
+# Outputs -> gpurun_out/ ; `python tools/summarize_profiles.py r06` copies the judged summaries into profiles/.
 # SKIP_TESTS=1 skips the pytest pass (it is also run by tools/gpu_tests.sh).
 mkdir -p gpurun_out
 R=/root/repo
@@ -35,7 +35,7 @@ prof vocos --model vocos
 prof vits2vocos --model vits2_vocos_v1
 prof uint8 --decoder-dtype uint8
 cd $R
-python tools/summarize_profiles.py r05 > gpurun_out/traffic_summary.txt 2>&1  # bench.py reads the newest profiles/r*_hbm_traffic.json
+python tools/summarize_profiles.py r06 > gpurun_out/traffic_summary.txt 2>&1  # bench.py reads the newest profiles/r*_hbm_traffic.json
 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err
 cut -c1-420 gpurun_out/bench.json
 python bench.py --gpus 2 --steps 2 --warmup 1 > gpurun_out/bench_gpus2_refused.json 2> gpurun_out/bench_gpus2_refused.err; echo "gpus2 exit=$?" | tee -a gpurun_out/bench_gpus2_refused.err
@@ -52,6 +52,15 @@ python bench.py --stream --model v1 > gpurun_out/stream_v1.json 2>/dev/null
 python bench.py --stream --model vits2_vocos_v1 --stream-cpu > gpurun_out/stream_vits2_vocos.json 2>/dev/null
 python bench.py --mas > gpurun_out/mas.json 2>/dev/null
 (export TMPDIR=/tmp; timeout 300 rocprofv3 --kernel-trace -d /tmp/b1 -o b1 --output-format csv -- python tools/trace_b1.py --reps 5 > gpurun_out/b1_run.txt 2>&1; python tools/trace_b1.py --summarize /tmp/b1 > gpurun_out/b1_summary.txt 2>&1)
+# SQ counters per kernel symbol: matrix-pipe busy share, wave-cycle split, instruction mix per MFMA (three passes each)
+bash tools/gpu_sq_counters.sh mrf > gpurun_out/sq_f32.log 2>&1
+{ echo "f32 headline, one-stream schedule (bench.py --decoder-serial), per kernel symbol; VALU counts include the MFMAs themselves"; python tools/sq_table.py mrf "conv_mfma|resblock_chain32"; } > gpurun_out/sq_table_mrf.txt 2>&1
+bash tools/gpu_sq_counters.sh mrf16_cfg2 "re:." --config multilingual > gpurun_out/sq_cfg2.log 2>&1
+{ echo "configs[2] (bench.py --config multilingual), per kernel symbol; VALU counts include the MFMAs themselves"; python tools/sq_table.py mrf16_cfg2 | head -24; } > gpurun_out/sq_table_mrf16_cfg2.txt 2>&1
+bash tools/gpu_sq_counters.sh mrf16_stress48k "re:." --config stress48k > gpurun_out/sq_s48.log 2>&1
+{ echo "configs[4] (bench.py --config stress48k), per kernel symbol; VALU counts include the MFMAs themselves"; python tools/sq_table.py mrf16_stress48k | head -20; } > gpurun_out/sq_table_mrf16_stress48k.txt 2>&1
+find gpurun_out -name "*counter_collection.csv" -path "*pmc_sq_*" -delete 2>/dev/null
+python tools/summarize_profiles.py r06 > gpurun_out/traffic_summary2.txt 2>&1
 WETTS_BENCH_B=16 WETTS_XSHAPES=512:1536:1:760,1536:512:1:760,192:384:1:760,192:384:5:760,512:1026:1:760 python tools/bench_conv.py 6,0 > gpurun_out/pw_gemm_microbench.txt 2>&1
 WETTS_BENCH_ITERS=10 python tools/bench_conv.py 0 2>&1 | grep -v amdgpu.ids > gpurun_out/conv_microbench.txt
 for f in gpurun_out/bench_*.json gpurun_out/bench.json; do echo $f; python -c "

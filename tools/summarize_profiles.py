@@ -10,7 +10,7 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = "gpurun_out"
 import os
 for a, b in [("prof_stats_baker/r_kernel_stats.csv", "kernel_stats.csv"), ("bench.json",) * 2,
@@ -31,7 +31,10 @@ for a, b in [("prof_stats_baker/r_kernel_stats.csv", "kernel_stats.csv"), ("benc
              ("bench_cfg3_aishell3.json",) * 2, ("bench_cfg3_aishell3_padded.json",) * 2,
              ("bench_cfg4_stress48k_f16.json",) * 2,
              ("bench_gpus2_refused.err",) * 2, ("bench_2rank_dryrun.json",) * 2, ("pytest_gpu.log",) * 2,
-             ("b1_summary.txt", "b1_anatomy.txt"), ("stream_v1_bf16.json",) * 2]:
+             ("b1_summary.txt", "b1_anatomy.txt"), ("stream_v1_bf16.json",) * 2,
+             # SQ counters per kernel symbol (tools/gpu_sq_counters.sh + tools/sq_table.py): f32 MRF class, 16-bit classes
+             ("sq_table_mrf.txt", "sq_counters_mrf.txt"), ("sq_table_mrf16_cfg2.txt", "sq_counters_mrf16_cfg2.txt"),
+             ("sq_table_mrf16_stress48k.txt", "sq_counters_mrf16_stress48k.txt")]:
     # gpurun_out/ accumulates over rounds (every call merges into it): only what THIS pass wrote is copied -- files not
     # older than the pass's library-digest stamp
     fresh_after = os.path.getmtime(f"{src}/lib_digest.txt") - 5 if os.path.exists(f"{src}/lib_digest.txt") else 0
