@@ -40,23 +40,31 @@ def test_infer_matches_reference(name):
 @pytest.mark.parametrize("name", util.STRIDED_CASES)
 def test_infer_matches_reference_at_the_benched_batch(name):
     """BASELINE configs[1] / [2] / [4] at their benched batch (the sub-sampled fixtures v1_b16x128, v3_b64x128,
-    stress48k_b16x128): the oracle against the live reference's durations, alignment and the strided z / audio views
-    (~20-40 s of CPU each)."""
+    stress48k_b16x128): the oracle against the live reference's durations, alignment and the strided z / audio views.
+    configs[1] decodes in full (~25 s of CPU); the two others -- whose decoders are pinned by their small-batch goldens --
+    run every stage up to z in full and the decoder on the first 96 frames (audio compared over the first 48, in front of
+    the cut's receptive field), which keeps the CPU tier to minutes."""
     case = util.load_case(name)
     cfg, _, W, _ = util.case_model(case)
     ns, ls, nsw = [float(v) for v in case["scales"]]
     torch.set_num_threads(8)
+    full = name == "v1_b16x128"
     st = vo.infer(W, util.cfg_dict(cfg), util.t(case["x"]), util.t(case["x_lengths"]), util.t(case["sid"]),
                   noise_scale=ns, length_scale=ls, noise_scale_w=nsw, eps_w=util.t(case["eps_w"]),
-                  eps_z=util.t(case["eps_z"]), return_stages=True)
+                  eps_z=util.t(case["eps_z"]), return_stages=True, max_len=None if full else 96)
     sa, sz = (int(v) for v in case["sub_strides"])
     w_err = float(np.abs(np.exp(st["logw"].numpy()) - np.exp(case["logw"])).max()) * ls
     assert float(case["ceil_margin"]) > 10 * w_err
     assert np.array_equal(st["y_mask"].numpy(), case["y_mask"])
     assert np.array_equal(st["attn"].numpy().astype(np.uint8), case["attn"])
     assert util.rel_rms(st["z"].numpy()[..., ::sz], case["z_sub"]) < 5e-5
-    assert util.rms(st["o"].numpy()[..., ::sa] - case["audio_sub"]) < 2e-5
-    assert abs(float(st["o"].double().pow(2).sum()) / float(case["audio_sqsum"]) - 1.0) < 1e-5
+    if full:
+        assert util.rms(st["o"].numpy()[..., ::sa] - case["audio_sub"]) < 2e-5
+        assert abs(float(st["o"].double().pow(2).sum()) / float(case["audio_sqsum"]) - 1.0) < 1e-5
+    else:
+        hop = int(case["audio_shape"][-1]) // int(case["z_shape"][-1])
+        n = 48 * hop // sa  # strided samples of the first 48 frames
+        assert util.rms(st["o"].numpy()[..., ::sa][..., :n] - case["audio_sub"][..., :n]) < 2e-5
 
 
 def test_onnx_stft_head_is_0375_of_torch_istft_in_the_interior_and_differs_at_the_edges():
