@@ -78,6 +78,11 @@ def parse_args():
                     help="f32 decoder: the three ResBlock chains of a stage on ONE stream (WETTS_DECODER_SERIAL; the "
                          "form whose kernel trace has non-overlapping per-kernel durations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--live-traffic", default="auto", choices=["auto", "0", "1"],
+                    help="refresh roofline.traffic by running the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of "
+                         "this same command as child processes after the timed region (+ ~1 min).  auto: on for a "
+                         "single-GPU run on a real device that is not itself being profiled; the committed "
+                         "profiles/rNN_hbm_traffic.json figure is the fallback and stays in the line beside it")
     ap.add_argument("--cpu-fixture", type=int, default=16,
                     help="also time the oracle on the first N utterances of the batch as ONE padded call (SURVEY 8d's "
                          "fixture) at the sweep's best thread count; 0 = skip")
@@ -763,10 +768,9 @@ def _bench(args, rank, local_rank, world, mon):
         except OSError:
             return None
 
-    def pmc_traffic(key):
+    def committed_traffic(key):
         """Committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command (profiles/): (bytes per launch,
-        file, digest of the library sources the counter pass ran on).  The driver cannot refresh it, so the line says
-        whether it is current (`traffic_current`: that digest == the digest of the library that just ran)."""
+        file, digest of the library sources the counter pass ran on)."""
         try:
             import glob
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
@@ -778,10 +782,64 @@ def _bench(args, rank, local_rank, world, mon):
             pass
         return None, None, None
 
+    traffic_memo = {}
+    live_note = {}
+
+    def live_wanted():
+        if args.live_traffic == "0" or world != 1 or be.label or not torch.cuda.is_available():
+            return False
+        if args.live_traffic == "1":
+            return True
+        # auto: never inside a profiler run (tools/gpu_round.sh profiles this script; rocprofv3 preloads its tool library)
+        return not any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) and \
+            "rocprofiler" not in os.environ.get("LD_PRELOAD", "")
+
+    def pmc_traffic(key):
+        """HBM bytes per launch of the dominant class from the PMC counters: (bytes, source, digest of the library the
+        counter pass ran on).  LIVE when possible -- the two `rocprofv3 --pmc` passes of this same command (one step each)
+        run as child processes right here, so the figure belongs to the library and the box of THIS line; else the
+        committed summary under profiles/ (`traffic_current` then says whether it was taken on the library that just ran)."""
+        if key in traffic_memo:
+            return traffic_memo[key]
+        res = committed_traffic(key)
+        if live_wanted() and key != "none":
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            try:
+                import pmc_traffic as pt
+                cls = "mrf16" if key.startswith("mrf16_") else "pw" if key.startswith("pw_") else key
+                keep, skip = [], False
+                for a in sys.argv[1:]:  # this command, one timed step, no CPU baseline, no nested refresh
+                    if skip:
+                        skip = False
+                        continue
+                    if a in ("--steps", "--warmup", "--presteps-s", "--live-traffic", "--cpu-sample", "--cpu-fixture"):
+                        skip = True
+                        continue
+                    if a.startswith(("--steps=", "--warmup=", "--presteps-s=", "--live-traffic=")) or a == "--no-cpu-baseline":
+                        continue
+                    keep.append(a)
+                child = [os.path.abspath(__file__)] + keep + ["--steps", "1", "--warmup", "1", "--presteps-s", "0.3",
+                                                              "--no-cpu-baseline", "--live-traffic", "0"]
+                t_l = time.perf_counter()
+                b_l, n_l = pt.live(child, cls, budget_s=240.0, log=lambda m: sys.stderr.write(m + "\n"))
+                if b_l is not None:
+                    live_note.update(committed={"traffic": res[0], "source": res[1], "head": res[2]},
+                                     launches_in_counter_pass=n_l, seconds=round(time.perf_counter() - t_l, 1))
+                    res = (b_l, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, run by bench.py "
+                                "after the timed region", lib_digest())
+                else:
+                    live_note.update(error=str(n_l))
+            except Exception as e:  # a measurement aid must never cost the line
+                live_note.update(error=f"{type(e).__name__}: {e}")
+        traffic_memo[key] = res
+        return res
+
     def stamp_traffic(roof, src, dig):
         roof["traffic_source"] = src
         roof["traffic_head"] = dig  # sources digest (wetts_amd/lib/build.sha256) of the library the PMC pass ran on
         roof["traffic_current"] = bool(dig) and dig == lib_digest()
+        if live_note:
+            roof["traffic_live"] = dict(live_note)
 
     # algorithmic bytes of the class at the granularity it was launched with (wetts_read_mrf_bytes), over the timed
     # steps; a ragged decode computes lens[b] of the dense rows the library counted

@@ -235,3 +235,38 @@ def test_bench_cpu_baseline_is_n1_only_unless_asked(tmp_path):
     finally:
         sys.argv = old
     assert a.cpu_baseline_multi and a.cpu_sample == 1 and abs(a.length_scale - 0.92) < 1e-9
+
+
+def test_pmc_traffic_class_sums_and_the_stub_line_never_spawns_a_profiler(tmp_path):
+    """tools/pmc_traffic.py (shared by tools/summarize_profiles.py and bench.py --live-traffic): HBM bytes per launch of a
+    kernel class = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 summed over the class's dispatches / its launches, with the uint8
+    convention of counting one launch per Conv node; and a line produced on the device-free stub (or under --live-traffic 0)
+    carries no `traffic_live`: the refresh is for real single-GPU runs only."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic as pt
+    rows = ["Kernel_Name,Counter_Name,Counter_Value"]
+    mrf = "void wetts::conv_mfma_kernel<1, 4, 4, 1, 1, true, true>(wetts::ConvParams)"
+    other = "void wetts::conv_mfma_kernel<1, 4, 4, 1, 3, false, true>(wetts::ConvParams)"
+    for v in (100, 300):
+        rows.append(f'"{mrf}",FETCH_SIZE,{v}')
+    rows.append(f'"{other}",FETCH_SIZE,999')
+    f = tmp_path / "fetch_counter_collection.csv"
+    f.write_text("\n".join(rows))
+    w = tmp_path / "write_counter_collection.csv"
+    w.write_text("\n".join(["Kernel_Name,Counter_Name,Counter_Value", f'"{mrf}",WRITE_SIZE,50', f'"{mrf}",WRITE_SIZE,150']))
+    b, n, fb, wb = pt.class_traffic(pt.agg(str(f), "FETCH_SIZE"), pt.agg(str(w), "WRITE_SIZE"), pt.is_mrf)
+    assert n == 2 and b == (2 * 400 + 200) * 1024 / 2 and fb == 400 * 1024 / 2 and wb == 200 * 1024 / 2
+    assert pt.is_mrf16("void wetts::rb2_stage16_kernel<32, false, 2, 2, 3, true>(x)") and not pt.is_mrf(other)
+    assert pt.is_pw("void wetts::pw_gemm_kernel<16, 4, true>(x)") and not pt.is_pw("void wetts::pw_gemm_kernel<16, 4, false>(x)")
+    val, why = pt.live(["-c", "pass"], "no-such-class")
+    assert val is None and "class" in why or "rocprofv3" in why
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.update(WETTS_BENCH_TEST_BACKEND="tests.bench_stub:StubBackend", PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--phonemes", "16",
+           "--presteps-s", "0.02", "--no-cpu-baseline", "--live-traffic", "1"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert "traffic_live" not in d["roofline"]

@@ -18,15 +18,15 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
 prof() {  # $1 = tag, rest = bench flags: kernel stats + the two HBM counter passes (separate runs, as the guide prescribes)
   tag=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats_$tag -o r -- python $R/bench.py "$@" --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_stats_$tag.log 2>&1
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch_$tag -o r -- python $R/bench.py "$@" --steps 1 --warmup 1 --presteps-s 0.3 --no-cpu-baseline > $R/gpurun_out/pmc_fetch_$tag.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write_$tag -o r -- python $R/bench.py "$@" --steps 1 --warmup 1 --presteps-s 0.3 --no-cpu-baseline > $R/gpurun_out/pmc_write_$tag.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats_$tag -o r -- python $R/bench.py "$@" --steps 5 --warmup 1 --no-cpu-baseline --live-traffic 0 > $R/gpurun_out/prof_stats_$tag.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch_$tag -o r -- python $R/bench.py "$@" --steps 1 --warmup 1 --presteps-s 0.3 --no-cpu-baseline --live-traffic 0 > $R/gpurun_out/pmc_fetch_$tag.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write_$tag -o r -- python $R/bench.py "$@" --steps 1 --warmup 1 --presteps-s 0.3 --no-cpu-baseline --live-traffic 0 > $R/gpurun_out/pmc_write_$tag.log 2>&1
   # keep the merged-back scratch small: the per-dispatch traces are not needed once the stats / counter CSVs exist
   find $R/gpurun_out/prof_stats_$tag $R/gpurun_out/pmc_fetch_$tag $R/gpurun_out/pmc_write_$tag -name "*kernel_trace.csv" -delete 2>/dev/null
 }
 prof baker
 # the same line with the stage's chains on ONE stream: per-kernel durations of this trace do not overlap (kernel quality)
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats_baker_serial -o r -- python $R/bench.py --decoder-serial --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_stats_baker_serial.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats_baker_serial -o r -- python $R/bench.py --decoder-serial --steps 5 --warmup 1 --no-cpu-baseline --live-traffic 0 > $R/gpurun_out/prof_stats_baker_serial.log 2>&1
 find $R/gpurun_out/prof_stats_baker_serial -name "*kernel_trace.csv" -delete 2>/dev/null
 prof bf16 --decoder-dtype bf16
 prof cfg2 --config multilingual
@@ -39,15 +39,15 @@ python tools/summarize_profiles.py r06 > gpurun_out/traffic_summary.txt 2>&1  # 
 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err
 cut -c1-420 gpurun_out/bench.json
 python bench.py --gpus 2 --steps 2 --warmup 1 > gpurun_out/bench_gpus2_refused.json 2> gpurun_out/bench_gpus2_refused.err; echo "gpus2 exit=$?" | tee -a gpurun_out/bench_gpus2_refused.err
-WETTS_BENCH_SINGLE_DEVICE=1 WETTS_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_2rank_dryrun.json 2> gpurun_out/bench_2rank_dryrun.err; echo "dryrun exit=$?"
-python bench.py --decoder-serial --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_serial.json 2>/dev/null
+WETTS_BENCH_SINGLE_DEVICE=1 WETTS_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --live-traffic 0 > gpurun_out/bench_2rank_dryrun.json 2> gpurun_out/bench_2rank_dryrun.err; echo "dryrun exit=$?"
+python bench.py --decoder-serial --steps 20 --warmup 3 --no-cpu-baseline --live-traffic 0 > gpurun_out/bench_serial.json 2>/dev/null
 for dt in bf16 f16 uint8; do python bench.py --steps 10 --warmup 3 --no-cpu-baseline --decoder-dtype $dt > gpurun_out/bench_$dt.json 2>/dev/null; done
-python bench.py --config multilingual --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_cfg2_multilingual_bf16.json 2>/dev/null
-python bench.py --config multilingual --decoder-dtype f32 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_cfg2_multilingual_f32.json 2>/dev/null
-python bench.py --config aishell3 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_cfg3_aishell3.json 2>/dev/null
-python bench.py --config stress48k --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_cfg4_stress48k_f16.json 2>/dev/null
-python bench.py --model vocos --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_vocos.json 2>/dev/null
-python bench.py --model vits2_vocos_v1 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_vits2_vocos.json 2>/dev/null
+python bench.py --config multilingual --steps 10 --warmup 3 --no-cpu-baseline --live-traffic 0 > gpurun_out/bench_cfg2_multilingual_bf16.json 2>/dev/null
+python bench.py --config multilingual --decoder-dtype f32 --steps 10 --warmup 3 --no-cpu-baseline --live-traffic 0 > gpurun_out/bench_cfg2_multilingual_f32.json 2>/dev/null
+python bench.py --config aishell3 --steps 5 --warmup 2 --no-cpu-baseline --live-traffic 0 > gpurun_out/bench_cfg3_aishell3.json 2>/dev/null
+python bench.py --config stress48k --steps 10 --warmup 3 --no-cpu-baseline --live-traffic 0 > gpurun_out/bench_cfg4_stress48k_f16.json 2>/dev/null
+python bench.py --model vocos --steps 10 --warmup 3 --no-cpu-baseline --live-traffic 0 > gpurun_out/bench_vocos.json 2>/dev/null
+python bench.py --model vits2_vocos_v1 --steps 10 --warmup 3 --no-cpu-baseline --live-traffic 0 > gpurun_out/bench_vits2_vocos.json 2>/dev/null
 python bench.py --stream --model v1 > gpurun_out/stream_v1.json 2>/dev/null
 python bench.py --stream --model vits2_vocos_v1 --stream-cpu > gpurun_out/stream_vits2_vocos.json 2>/dev/null
 python bench.py --mas > gpurun_out/mas.json 2>/dev/null

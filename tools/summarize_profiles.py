@@ -42,28 +42,8 @@ for a, b in [("prof_stats_baker/r_kernel_stats.csv", "kernel_stats.csv"), ("benc
         shutil.copy(f"{src}/{a}", f"profiles/{tag}_{b}")
 
 
-def agg(path, ctr):
-    d = collections.defaultdict(list)
-    if not os.path.exists(path):
-        return d
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == ctr:
-            d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return d
-
-
-def is_mrf(k):
-    """The MRF ResBlock class by kernel symbol: f32 -- conv_mfma_kernel instantiations with the MRF flag, the
-    grouped launches, the chain / pair kernels; 16 bit -- the fused pair kernels and the MRF-tagged single convs."""
-    mm = re.search(r"conv_mfma_kernel<\d+, \d+, \d+, \d+, \d+, (true|false)", k)
-    if mm and mm.group(1) == "true":
-        return True
-    if "conv_mfma_group_kernel" in k or "resblock_pair32_kernel" in k or "resblock_chain32_kernel" in k:
-        return True
-    if "resblock_pair16_kernel" in k or "conv16_mb2_kernel" in k or "resblock1_chain16_kernel" in k:
-        return True
-    mm = re.search(r"conv_bf16_kernel<\d+, \d+, \d+, \d+, (true|false), \d+, (true|false)", k)
-    return bool(mm and mm.group(2) == "true")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_traffic import agg, is_mrf, is_pw, is_u8, is_mrf16 as _mrf16  # noqa: E402  (shared with bench.py --live-traffic)
 
 
 out = {"note": "per kernel name; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch "
@@ -71,18 +51,6 @@ out = {"note": "per kernel name; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per 
                "uncalibrated, so read this as an upper bound on reads).  Class keys: dominant_conv_mfma = the f32 "
                "headline's MRF class, mrf16_<config> = the 16-bit MRF class of bench.py --config <config> "
                "(baker = --decoder-dtype bf16)"}
-def is_pw(k):  # the tagged launches: the ConvNeXt GEMMs bench.py times for the Vocos models
-    return "pw_gemm_kernel" in k and ", true>" in k
-
-
-def is_u8(k):
-    return "qconv_i8_kernel" in k or "qquantize" in k or "qminmax" in k or "qrange" in k
-
-
-def _mrf16(k):
-    return is_mrf(k) or "rb2_stage16_kernel" in k
-
-
 # key in the JSON -> (sub-directory tag of the three rocprofv3 passes, kernel-class predicate,
 #                     launches of the class counted as: kernels (None) or this kernel-name substring only)
 CLASSES = (("dominant_conv_mfma", "baker", is_mrf, None), ("mrf16_baker", "bf16", _mrf16, None),
