@@ -696,3 +696,31 @@ def test_streamed_vocos_decode_matches_the_references_client_on_the_exported_mod
         err = util.rms(got - want)
         print("streamed Vocos (exported arithmetic)", block, pad, "abs rms vs the reference client", err)
         assert err < 1e-4
+
+
+def test_istft_mode_through_the_c_abi_and_the_native_infer_entry():
+    """wetts_set_istft_mode / wetts_get_istft_mode on a live handle: the config's is_onnx is the mode at create, an
+    invalid mode is refused without changing anything, a HiFi-GAN model takes the call without effect, and
+    wetts_infer -- the native hosts' entry -- follows the handle's mode (its audio equals the Python composition's in
+    either mode, and the two modes differ)."""
+    from wetts_amd import _lib
+    lib = _lib.load()
+    net, case, cfg, sd, W = _model("tiny_vocos_onnx_b2")
+    assert lib.wetts_get_istft_mode(net._handle) == 1 and net.is_onnx
+    assert lib.wetts_set_istft_mode(net._handle, 7) != 0 and "istft mode" in _lib.last_error()
+    assert lib.wetts_get_istft_mode(net._handle) == 1
+    z = torch.from_numpy((case["z"] * case["y_mask"])).cuda()
+    g = torch.nn.functional.embedding(util.t(case["sid"]), W["emb_g.weight"]).cuda()
+    a_onnx = net.hifigan(z, g).cpu().numpy()
+    assert util.rms(a_onnx - case["audio"]) < 1e-4
+    net.set_is_onnx(False)
+    assert lib.wetts_get_istft_mode(net._handle) == 0
+    a_torch = net.hifigan(z, g).cpu().numpy()
+    ref = util.load_case("tiny_vocos_b2")  # same weights, inputs and noise: the torch.istft head's golden
+    assert util.rms(a_torch - ref["audio"]) < 1e-4 and util.rms(a_torch - a_onnx) > 1e-3
+    hnet, *_ = _model("tiny_sdp_b3")  # HiFi-GAN: the flag exists and does nothing
+    zz = torch.randn(1, hnet.inter_channels, 9, device="cuda")
+    gg = torch.zeros(1, hnet.gin_channels, device="cuda")
+    before = hnet.hifigan(zz, gg).cpu().numpy()
+    hnet.set_is_onnx(True)
+    assert np.array_equal(hnet.hifigan(zz, gg).cpu().numpy(), before)
