@@ -29,19 +29,19 @@ namespace wetts {
 //  * SHARED staging (C = 32): lrelu(x) is the same tile for every chain of the stage -- only the halo differs -- so it is
 //    staged ONCE with the widest c1 halo into its own LDS tile, and lrelu(t) of each chain goes to a second tile.  The
 //    per-chain re-staging (global load, unpack, leaky-relu, pack, ds_write: ~28 VALU per 16-byte piece, three times over)
-//    was a third of the kernel's vector work.  Two tiles of 512 columns do not fit twice into 160 KB, so the C = 32 tile is
-//    384 columns (three accumulator blocks per wave): 72 KB per block, two blocks per CU as before.
+//    was a third of the kernel's vector work.  The block is eight waves wide (768 columns at C = 32, 384 at C = 64: see
+//    stage16_nb below), one per CU.
 //  * the raw x of a lane's own outputs (c1's accumulator init) is loaded once and kept in registers across the chains;
 //  * x is addressed through a buffer descriptor of the utterance's plane: rows before / behind the utterance read as
 //    zeros (lrelu(0) = 0: the convs' zero padding) without a bounds test, exec mask or branch per piece;
 //  * the `inside` select of lrelu(t) and the choice of the quotient are uniform per block and hoisted out of the
 //    per-element loops; bias adds, slope products and the quotient run on pairs (v_pk_add / mul / fma_f32).
 // Operation order and rounding points per output element are unchanged: bit-identical to the chain-by-chain launches.
-template <int C, bool F16, int NR, int OCC, int NB, bool SHARED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
+template <int C, bool F16, int NR, int OCC, int NB, bool SHARED, int NW = 4>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 void rb2_stage16_kernel(const ResStage2Params p) {
-  constexpr int WM = C / 32, WN = 4 / WM;
-  constexpr int NTH = 256;
+  constexpr int WM = C / 32, WN = NW / WM;
+  constexpr int NTH = 64 * NW;
   constexpr int NTC = 32 * NB * WN;
   constexpr int CKB = C >= 64 ? 64 : 32;
   constexpr int NCH = C / CKB, KS = CKB / 16;
@@ -333,11 +333,17 @@ void rb2_stage16_kernel(const ResStage2Params p) {
   }
 }
 
-// the tile shapes: C = 32 -> 384 columns (three accumulator blocks per wave), lrelu(x) staged once for all chains into its
-// own LDS tile; C = 64 -> 256 columns, one tile restaged per chain (two tiles of 144-byte rows would leave one block per CU)
-static constexpr int stage16_nb(int C) { return C == 32 ? 3 : 4; }
-static constexpr bool stage16_shared(int C) { return C == 32; }
-static int stage16_ntc(int C) { return 32 * stage16_nb(C) * (4 / (C / 32)); }
+// The tile shapes (round 6, measured on configs[2], same box): EIGHT waves per block, three accumulator blocks per wave,
+// lrelu(x) staged once for all chains into its own LDS tile -- C = 32: 768 columns (139 KB of LDS), C = 64: 384 columns
+// (130 KB): one block of eight waves per CU instead of two of four.  The halo the common origin costs drops from 72 of 384
+// (512 before the shared staging) columns to 72 of 768 at C = 32 and from 72 of 256 to 72 of 384 at C = 64, and the step went
+// 8.61 -> 8.19 (C = 32 on eight waves) -> 7.69 (C = 64 too, one restaged tile of 512 columns) -> 7.55 ms (C = 64 with the shared
+// staging); the kernels' own durations moved less (C = 32 1.55 -> 1.56 ms, C = 64 1.37 -> 1.26) than the step -- a CU's one
+// big block leaves the neighbouring call's encoder stages (bench.py pipelines calls) more room than two did.
+static constexpr int stage16_nb(int C) { return 3; }
+static constexpr bool stage16_shared(int C) { return true; }
+static constexpr int stage16_nw(int C) { return 8; }  // waves per block
+static int stage16_ntc(int C) { return 32 * stage16_nb(C) * (stage16_nw(C) / (C / 32)); }
 
 // valid output columns per block, or 0 when the stage is not covered (shapes, halos, waste above max_waste_pct)
 int resblock2_stage16_nto(const PackedConvB* const* c1, const PackedConvB* const* c2, int nchain, int max_waste_pct) {
@@ -365,7 +371,7 @@ int32_t launch_resblock2_stage16(const PackedConvB* const* c1, const PackedConvB
   WETTS_REQUIRE(nto > 0, "ResBlock2 stage not supported by the fused kernel");
   const int C = c1[0]->Cin;
   const int NTC = stage16_ntc(C), RS = C * 2 + 16;
-  const int RPP = 256 / (C / 8);
+  const int RPP = 64 * stage16_nw(C) / (C / 8);
   p.nchain = nchain;
   int wmax = 0, h1max = 0;
   for (int j = 0; j < nchain; ++j) {
@@ -407,15 +413,15 @@ int32_t launch_resblock2_stage16(const PackedConvB* const* c1, const PackedConvB
         state[slot][dev] = 1;
       }
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * stage16_nw(C)), lds, stream, p);
     return WETTS_OK;
   };
   if (C == 32) {
-    if (f16) WETTS_TRY(go(rb2_stage16_kernel<32, true, 2, 2, stage16_nb(32), stage16_shared(32)>));
-    else WETTS_TRY(go(rb2_stage16_kernel<32, false, 2, 2, stage16_nb(32), stage16_shared(32)>));
+    if (f16) WETTS_TRY(go(rb2_stage16_kernel<32, true, 2, 2, stage16_nb(32), stage16_shared(32), stage16_nw(32)>));
+    else WETTS_TRY(go(rb2_stage16_kernel<32, false, 2, 2, stage16_nb(32), stage16_shared(32), stage16_nw(32)>));
   } else {
-    if (f16) WETTS_TRY(go(rb2_stage16_kernel<64, true, 2, 2, stage16_nb(64), stage16_shared(64)>));
-    else WETTS_TRY(go(rb2_stage16_kernel<64, false, 2, 2, stage16_nb(64), stage16_shared(64)>));
+    if (f16) WETTS_TRY(go(rb2_stage16_kernel<64, true, 2, 2, stage16_nb(64), stage16_shared(64), stage16_nw(64)>));
+    else WETTS_TRY(go(rb2_stage16_kernel<64, false, 2, 2, stage16_nb(64), stage16_shared(64), stage16_nw(64)>));
   }
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
