@@ -101,7 +101,7 @@ int32_t pack_conv_weight_bf16(const float* w_dev, const float* bias_dev, int Cou
                               PackedConvB* out, int gate_h = 0);
 void free_packed_bf16(PackedConvB* pc);
 int32_t launch_conv_bf16(const PackedConvB& pc, ConvBParams p, hipStream_t stream);
-int resblock_pair16_ntc(int C);
+int resblock_pair16_ntc(int C, bool rb2 = false);
 int32_t k_cf32_to_cl16(const float* x, unsigned short* out, int B, int C, int T, int f16,
                        hipStream_t s);
 // ... with batch / channel strides and an optional row mask [B][>= T]: out = round16(x * mask)

@@ -2389,7 +2389,7 @@ static int32_t run_hifigan_bf16(const wetts_model* m, const float* z, int64_t z_
         if (c->resblock == 2 && nd == 2 && d == 0 && !m->dec_unfused &&
             resblock2_chain16_supported(m->b_c1[n][0], m->b_c1[n][1],
                                         ch <= 32 ? m->fuse2_waste_pct : (m->fuse2_waste_pct + 1) / 2) &&
-            cdiv(len, pair_nto(ch, 1) - (m->b_c1[n][1].ktaps - 1) * m->b_c1[n][1].dil) * B >=
+            cdiv(len, resblock_pair16_ntc(ch, true) - (m->b_c1[n][1].ktaps - 1) * m->b_c1[n][1].dil) * B >=
                 m->fuse_min_blocks) {
           // a whole ResBlock2 in one launch (see resblock16.hip, RB2)
           ResPairParams pp;

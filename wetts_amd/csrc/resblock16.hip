@@ -44,11 +44,16 @@ namespace wetts {
 // issue, not the matrix pipe, sets the pace.  A wave now owns 64 rows x 128 columns (8 accumulators), a block is
 // two waves (C = 128: 2 x 1, C = 64: 1 x 2) on the same 128 / 256-column tile as before, so the LDS tile, the
 // column -> time mapping, the K order of every accumulator and therefore the results are unchanged.
+// Waves per block (MB = 1).  ResBlock1 pairs: 4 (three blocks per CU, three waves per SIMD).  ResBlock2 chains: 8, one block
+// per CU (round 6; configs[2] 7.50 -> 7.38 ms/step same box) -- its c2 halo ((k - 1) / 2 * dilation, up to 36 columns a
+// side) is then amortised over twice the columns.  Eight waves for the ResBlock1 pairs measured WORSE (configs[4] 13.75 ->
+// 15.09 ms/step, v1 bf16 11.13 -> 11.94): their halo is 1-5 columns, and two waves per SIMD instead of three is all it buys.
+constexpr int pair16_waves(bool rb2) { return rb2 ? 8 : 4; }
 template <int C, bool F16, int NR, int OCC, bool RB2, int MB>
-__global__ __launch_bounds__(64 * (C / (32 * MB)) * (MB == 2 ? (C == 128 ? 1 : 2) : 4 / (C / 32)))
+__global__ __launch_bounds__(64 * (C / (32 * MB)) * (MB == 2 ? (C == 128 ? 1 : 2) : pair16_waves(RB2) / (C / 32)))
 __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 void resblock_pair16_kernel(const ResPairParams p) {
-  constexpr int WM = C / (32 * MB), WN = MB == 2 ? (C == 128 ? 1 : 2) : 4 / (C / 32), NB = 4;
+  constexpr int WM = C / (32 * MB), WN = MB == 2 ? (C == 128 ? 1 : 2) : pair16_waves(RB2) / (C / 32), NB = 4;
   constexpr int NTH = 64 * WM * WN;            // threads per block
   constexpr int NTC = 32 * NB * WN;            // columns computed per conv
   constexpr int CKB = C >= 64 ? 64 : 32;       // K chunk of the packed weights (pack_bf16_kernel)
@@ -413,7 +418,7 @@ void resblock_pair16_kernel(const ResPairParams p) {
 
 template <int C, int NR, int OCC, bool RB2, int MB>
 static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream) {
-  constexpr int WM = C / (32 * MB), WN = MB == 2 ? (C == 128 ? 1 : 2) : 4 / (C / 32);
+  constexpr int WM = C / (32 * MB), WN = MB == 2 ? (C == 128 ? 1 : 2) : pair16_waves(RB2) / (C / 32);
   constexpr int NTC = 128 * WN, RS = C * 2 + 16, NTH = 64 * WM * WN;
   ResPairParams p = p0;
   const int h2 = (p.ktaps - 1) / 2 * (RB2 ? p.dil2 : 1), h1 = (p.ktaps - 1) / 2 * p.dil;
@@ -428,7 +433,12 @@ static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream
   WETTS_REQUIRE((int64_t)p.T * C * 2 < (int64_t)INT32_MAX, "utterance plane too large for the pair kernel's 32-bit offsets");
   constexpr int RPP = NTH / (C / 8);  // the tile in whole staging passes (the kernel's stores carry no row guard)
   const size_t lds = (size_t)((NTC + 2 * (h1 > h2 ? h1 : h2) + RPP - 1) / RPP * RPP) * RS;
-  WETTS_REQUIRE(lds <= 64 * 1024, "pair tile exceeds the default dynamic LDS");
+  WETTS_REQUIRE(lds <= 160 * 1024, "pair tile exceeds the LDS");
+  if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: opt in once per device and instantiation
+    static signed char st16[2][64] = {};
+    if (f16) WETTS_REQUIRE(lds_opt_in((const void*)resblock_pair16_kernel<C, true, NR, OCC, RB2, MB>, st16[1]), "LDS opt-in refused");
+    else WETTS_REQUIRE(lds_opt_in((const void*)resblock_pair16_kernel<C, false, NR, OCC, RB2, MB>, st16[0]), "LDS opt-in refused");
+  }
   if (f16)
     hipLaunchKernelGGL((resblock_pair16_kernel<C, true, NR, OCC, RB2, MB>), dim3(grid), dim3(NTH), lds, stream, p);
   else
@@ -438,8 +448,8 @@ static int32_t launch_pair(const ResPairParams& p0, bool f16, hipStream_t stream
 }
 
 // output columns a block of the pair kernel computes per conv (the decoder's tile arithmetic, model.hip)
-int resblock_pair16_ntc(int C) {
-  return 128 * (4 / (C / 32));
+int resblock_pair16_ntc(int C, bool rb2) {
+  return 128 * (pair16_waves(rb2) / (C / 32));
 }
 
 bool resblock_pair16_supported(const PackedConvB& c1, const PackedConvB& c2) {
@@ -478,7 +488,7 @@ bool resblock2_chain16_supported(const PackedConvB& c1, const PackedConvB& c2, i
   if (c1.pad != (c1.ktaps - 1) / 2 * c1.dil || c2.pad != (c2.ktaps - 1) / 2 * c2.dil) return false;
   if ((c1.ktaps - 1) * (c1.dil > c2.dil ? c1.dil : c2.dil) > (C == 32 ? RESPAIR2_MAX_SPAN32 : RESPAIR_MAX_SPAN))
     return false;
-  const int NTC = resblock_pair16_ntc(C);
+  const int NTC = resblock_pair16_ntc(C, true);
   return (c2.ktaps - 1) * c2.dil * 100 <= max_waste_pct * NTC;
 }
 
@@ -493,9 +503,9 @@ int32_t launch_resblock2_chain16(const PackedConvB& c1, const PackedConvB& c2, R
   p.dil2 = c2.dil;
   const bool h = c1.f16 != 0;
   switch (c1.Cin) {
-    case 32: return launch_pair<32, 2, 3, true, 1>(p, h, stream);
-    case 64: return launch_pair<64, 2, 3, true, 1>(p, h, stream);
-    default: return launch_pair<128, 2, 3, true, 1>(p, h, stream);
+    case 32: return launch_pair<32, 2, 2, true, 1>(p, h, stream);
+    case 64: return launch_pair<64, 2, 2, true, 1>(p, h, stream);
+    default: return launch_pair<128, 2, 2, true, 1>(p, h, stream);
   }
 }
 
