@@ -101,9 +101,19 @@ def live(argv, key, budget_s=200.0, log=None):
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "r", "--",
                    sys.executable] + list(argv)
             env = dict(os.environ, TMPDIR="/tmp")
+            # own session: a pass that overruns is killed as a GROUP (rocprofv3 and the python under it), so that no
+            # grandchild keeps the GPU busy behind the bench's back
+            import signal
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                 start_new_session=True)
             try:
-                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=left)
+                p.wait(timeout=left)
             except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                p.wait()
                 return None, f"{ctr} pass timed out"
             if log:
                 log(f"[live traffic] {ctr} pass: exit {p.returncode}, {time.time() - t0:.0f} s")
