@@ -47,13 +47,15 @@ if xs:
     for it in xs.split(","):
         ci, co, k, L = (int(v) for v in it.split(":"))
         row = f"{ci:4d}->{co:4d} k={k:2d} L={L:6d}          "
+        first = None
         for v in variants:
             ms, cs = C.c_double(), C.c_double()
             rc = lib.wetts_bench_conv(ci, co, k, 1, B, L, extra, v, 20, C.byref(ms), C.byref(cs))
             if rc != 0:
                 row += f"  ERR {_lib.last_error()}"
                 continue
-            row += f"  {ms.value:7.4f} {2.0 * ci * co * k * L * B / (ms.value * 1e-3) / 1e12:6.1f}  "
+            first = cs.value if first is None else first
+            row += f"  {ms.value:7.4f} {2.0 * ci * co * k * L * B / (ms.value * 1e-3) / 1e12:6.1f} {'=' if cs.value == first else '!='}"
         print(row, flush=True)
     sys.exit(0)
 print(f"{'shape':34s}" + "".join(f"  v{v:#06x}: ms TF/s GB/s  " for v in variants))
