@@ -195,11 +195,22 @@ __global__ void qpack_weight_kernel(const float* __restrict__ w, const QuantWeig
 }
 
 // The integer contraction + dequantising epilogue.  Block = 4 waves; wave w owns m-block
-// (mtile*WM + w / WN) and NB 32-column blocks; B operands come straight from the channel-last int8
-// image (16 consecutive channels of one frame = one aligned 16-byte piece per lane), A operands from
-// the packed weights: no LDS, L1 / L2 carry the tap and tile overlap.
+// (mtile*WM + w % mw) and NB 32-column blocks of column group w / mw.
+//
+// Round 6 rebuild (the first version read every B operand of every tap straight from global memory, kept a three-step
+// operand ring in 60 registers -- 240 in all, two waves per SIMD -- and started each column block's residual /
+// running-sum loads only when the block's turn came: a wave lived 43 us, nearly all of it waiting, and the launches of
+// the C <= 128 stages moved 1.75 TB/s).  Now:
+//   * the block's int8 tile -- [columns + (k - 1) dilation frames][Cp channels], a contiguous piece of the
+//     channel-last image -- and the per-frame channel sums of those frames are staged in LDS once; the taps are
+//     ds_read_b128 at shifted rows (row stride Cp + 16 bytes: conflict-free), the zero-point window sums LDS reads;
+//   * A fragments in a ring six steps deep (24 registers: a step is NB MFMAs of 32 cycles, an L2 round trip is 10+);
+//   * the epilogue's f32 operands (residual, running sum) of column block j + 1 are requested before block j is
+//     finished, those of block 0 before the contraction starts: the loads of a wave are in flight all the time.
+// Integer accumulation is exact in any order, and the f32 expression per element is unchanged: bit-identical output.
 template <int NB>
-__global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void qconv_i8_kernel(const QConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NT = 32 * NB;  // columns per wave
@@ -207,7 +218,8 @@ __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
   // 2 for M = 64, 1 for M <= 32 (four column groups) -- no wave of a narrow conv sits idle
   const int mw = p.M > 64 ? 4 : (p.M > 32 ? 2 : 1);
   const int cgw = 4 / mw;
-  const int ntiles = (p.T + NT * cgw - 1) / (NT * cgw);
+  const int NTB = NT * cgw;    // columns per block
+  const int ntiles = (p.T + NTB - 1) / NTB;
   const int mtiles = (p.M + 32 * mw - 1) / (32 * mw);
   int bid = blockIdx.x;
   const int ntile = bid % ntiles;
@@ -216,9 +228,9 @@ __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
   const int b = bid / mtiles;
   const int mt32 = mtile * mw + wave % mw;
   const int row0 = mt32 * 32;
-  if (row0 >= p.M) return;
-  const int n0 = (ntile * cgw + wave / mw) * NT;
-  if (n0 >= p.T) return;
+  const int nb0 = ntile * NTB;
+  const int n0 = nb0 + (wave / mw) * NT;
+  const bool active = row0 < p.M && n0 < p.T;
   const int khalf = lane >> 5, l31 = lane & 31;
   float sx;
   int zx;
@@ -227,7 +239,74 @@ __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
   const unsigned padw = (unsigned)padv * 0x01010101u;
   const int CG = p.Cp / 32;
   const signed char* xb = p.xs + (int64_t)b * p.T * p.Cp;
+  const int* csb = p.colsum + (int64_t)b * p.T;
   const uint4* ab = reinterpret_cast<const uint4*>(p.wpk) + ((int64_t)mt32 * p.ktaps * CG) * 64 + lane;
+  const int nsteps = p.ktaps * CG;  // steps = (tap, channel group) pairs, tap-major: the packed order
+
+  // ---- A ring: requested first, lands behind the staging --------------------------------------------------------
+  constexpr int RD = 6;
+  uint4 a_r[RD];
+#pragma unroll
+  for (int u = 0; u < RD; ++u) a_r[u] = ab[(int64_t)(u < nsteps ? u : nsteps - 1) * 64];
+
+  // ---- the tile: frames r0 .. r0 + R - 1 of the int8 image (padding frames hold the quantised zero) -------------
+  const int span = (p.ktaps - 1) * p.dil;
+  const int R = NTB + span;
+  const int RS = p.Cp + 16;
+  const int r0 = nb0 - p.pad;
+  unsigned char* xt = smem_q;
+  int* cs_l = reinterpret_cast<int*>(smem_q + (((size_t)R * RS + 15) & ~(size_t)15));
+  {
+    const int SEG = p.Cp >> 4, total = R * SEG;
+    const uint4 pad4 = make_uint4(padw, padw, padw, padw);
+    for (int base = 0; base < total; base += 4 * 256) {
+      uint4 v[4];
+      int off[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 256 + tid;
+        const int row = i / SEG, seg = i - row * SEG;
+        const int t = r0 + row;
+        const bool ok = i < total && t >= 0 && t < p.T;
+        off[u] = i < total ? row * RS + seg * 16 : -1;
+        v[u] = *reinterpret_cast<const uint4*>(xb + (int64_t)(ok ? t : 0) * p.Cp + (ok ? seg : 0) * 16);
+        if (!ok) v[u] = pad4;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (off[u] >= 0) *reinterpret_cast<uint4*>(xt + off[u]) = v[u];
+    }
+    for (int i = tid; i < R; i += 256) {
+      const int t = r0 + i;
+      cs_l[i] = (t >= 0 && t < p.T) ? csb[t] : p.Cp * (zx - 128);
+    }
+  }
+
+  // ---- the epilogue's f32 operands: this lane's 16 rows of column block j (zeros where absent) ------------------
+  float* ob = p.out + (int64_t)b * p.o_bs;
+  const float* rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
+  const bool has_ops = rb != nullptr || p.accum;
+  float rv[2][16], pv[2][16];
+  // (addresses: a uniform row base -- scalar registers -- plus ONE 32-bit lane offset per tensor; per-row 64-bit lane
+  // addresses cost 64 registers and the kernel spilled)
+  const int lane_o = 4 * khalf * (int)p.o_cs + l31, lane_r = 4 * khalf * (int)p.r_cs + l31;
+  auto load_ops = [&](int j, float (&rvj)[16], float (&pvj)[16]) __attribute__((always_inline)) {
+    const int t = n0 + 32 * j + l31;
+    const bool okt = active && t < p.T;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rowu = row0 + (r & 3) + 8 * (r >> 2);  // uniform; this lane's row is rowu + 4 * khalf
+      const bool okr = okt && rowu + 4 * khalf < p.M;
+      rvj[r] = 0.f;
+      pvj[r] = 0.f;
+      if (rb && okr) rvj[r] = (rb + (int64_t)rowu * p.r_cs + (n0 + 32 * j))[lane_r];
+      if (p.accum && okr) pvj[r] = (ob + (int64_t)rowu * p.o_cs + (n0 + 32 * j))[lane_o];
+    }
+  };
+  if (has_ops) load_ops(0, rv[0], pv[0]);
+
+  __syncthreads();
+  if (!active) return;
 
   i32x16 acc[NB];
 #pragma unroll
@@ -235,44 +314,42 @@ __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0;
 
-  // steps = (tap, channel group) pairs; the operands of step i + 1 are requested before the MFMAs of step i
-  // (every load unconditional: out-of-range frames read frame 0 and are replaced by the padding value afterwards)
-  const int nsteps = p.ktaps * CG;
-  auto load_step = [&](int step, uint4& av, uint4 (&bv)[NB], unsigned& okm) {
-    const int st = step < nsteps ? step : nsteps - 1;
-    const int tap = st / CG, cg = st - tap * CG;
-    av = ab[((int64_t)tap * CG + cg) * 64];
-    okm = 0u;
+  // ---- the contraction: B fragments from the tile, one step ahead -----------------------------------------------
+  {
+    const unsigned char* bbase = xt + (size_t)((n0 - nb0) + l31) * RS + 16 * khalf;
+    // ONE B set, each fragment re-requested right behind the MFMA that consumed it: it is needed again NB MFMAs later,
+    // which covers the LDS latency (a second set would be 16 more registers: the kernel then spills at two waves per SIMD)
+    uint4 bq[NB];
+    const int tap_bytes = p.dil * RS;
+    int cgn = 0, boffn = 0;  // channel group / byte offset of the step whose fragments are requested next
+    auto advance = [&]() __attribute__((always_inline)) {
+      if (++cgn == CG) { cgn = 0; boffn += tap_bytes - (CG - 1) * 32; }
+      else boffn += 32;
+    };
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int tj = n0 + 32 * j + l31 + tap * p.dil - p.pad;
-      const bool ok = tj >= 0 && tj < p.T;
-      okm |= ok ? (1u << j) : 0u;
-      bv[j] = *reinterpret_cast<const uint4*>(xb + (int64_t)(ok ? tj : 0) * p.Cp + cg * 32 + 16 * khalf);
-    }
-  };
-  // a ring three steps deep (two in flight behind the one being consumed): a step is four MFMAs, far less than an
-  // L2 round trip, so one step of prefetch distance left the loop waiting on memory.  Loads are unconditional
-  // (clamped step index), so the waits carry exact counts; only the MFMAs sit under the (uniform) tail test.
-  constexpr int RD = 3;
-  uint4 a_r[RD], b_r[RD][NB];
-  unsigned ok_r[RD];
+    for (int j = 0; j < NB; ++j) bq[j] = *reinterpret_cast<const uint4*>(bbase + (size_t)(32 * j) * RS);
+    advance();
+    for (int step = 0; step < nsteps; step += RD) {
 #pragma unroll
-  for (int u = 0; u < RD; ++u) load_step(u, a_r[u], b_r[u], ok_r[u]);
-  for (int step = 0; step < nsteps; step += RD) {
+      for (int u = 0; u < RD; ++u) {
+        if (step + u < nsteps) {
+          const i32x4 a = {(int)a_r[u].x, (int)a_r[u].y, (int)a_r[u].z, (int)a_r[u].w};
+          const bool more = step + u + 1 < nsteps;
+          const unsigned char* nb = bbase + (more ? boffn : 0);
 #pragma unroll
-    for (int u = 0; u < RD; ++u) {
-      if (step + u < nsteps) {
-        const i32x4 a = {(int)a_r[u].x, (int)a_r[u].y, (int)a_r[u].z, (int)a_r[u].w};
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          const uint4 bv = (ok_r[u] >> j) & 1u ? b_r[u][j] : make_uint4(padw, padw, padw, padw);
-          const i32x4 bq = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
-          acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq, acc[j], 0, 0, 0);
+          for (int j = 0; j < NB; ++j) {
+            const uint4 bv = bq[j];
+            const i32x4 bqv = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+            acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bqv, acc[j], 0, 0, 0);
+            bq[j] = *reinterpret_cast<const uint4*>(nb + (size_t)(32 * j) * RS);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (more) advance();
         }
+        const int sn = step + u + RD;
+        a_r[u] = ab[(int64_t)(sn < nsteps ? sn : nsteps - 1) * 64];  // unconditional (clamped): exact wait counts
+        __builtin_amdgcn_sched_barrier(0);
       }
-      load_step(step + u + RD, a_r[u], b_r[u], ok_r[u]);
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -282,44 +359,31 @@ __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
   const int cx = 128 - zx, cw = 128 - zw;
   const int K = p.Cp * p.ktaps;
   const float sprod = sx * sw;  // Mul(x_scale, w_scale) of the quantised graph, in f32
-  const int* csb = p.colsum + (int64_t)b * p.T;
-  float* ob = p.out + (int64_t)b * p.o_bs;
-  const float* rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
   const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
   const bool dodiv = p.out_div != 1.f;
   float omn = INFINITY, omx = -INFINITY;  // range of what this wave writes (for the conv that consumes it)
   // per-row constants of this lane's 16 rows: zero-point correction, bias (+ per-utterance bias)
   int rcorr[16];
-  float rbias[16], rbb[16];
+  float rbias[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
     const bool okr = row < p.M;
     rcorr[r] = okr ? cx * p.rowsum[row] : 0;
     rbias[r] = (okr && p.bias) ? p.bias[row] : 0.f;
-    rbb[r] = (okr && bb) ? bb[row] : 0.f;
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
+    // the next column block's operands first: in flight behind this block's arithmetic and stores
+    if (has_ops && j + 1 < NB) load_ops(j + 1, rv[(j + 1) & 1], pv[(j + 1) & 1]);
     const int t = n0 + 32 * j + l31;
     if (t >= p.T) continue;
-    int cs = 0;  // sum over the receptive field of the per-frame channel sums (padding = Cp * (zx-128))
-    for (int tap = 0; tap < p.ktaps; ++tap) {
-      const int tt = t + tap * p.dil - p.pad;
-      cs += (tt >= 0 && tt < p.T) ? csb[tt] : p.Cp * (zx - 128);
+    int cs = 0;  // sum over the receptive field of the per-frame channel sums (padding frames = Cp * (zx-128), staged)
+    {
+      const int* cp = cs_l + (n0 - nb0) + 32 * j + l31;
+      for (int tap = 0; tap < p.ktaps; ++tap) cs += cp[tap * p.dil];
     }
     const int base = cw * cs + K * cx * cw;
-    // all of this column's residual / running-sum operands are requested BEFORE the first store: the stores go
-    // through a plain float* the loads might alias, so left to itself every load waits behind the previous store --
-    // 16 dependent memory round trips per column block instead of one
-    float rv[16], pv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-      const bool okr = row < p.M;
-      rv[r] = (rb && okr) ? rb[(int64_t)row * p.r_cs + t] : 0.f;
-      pv[r] = (p.accum && okr) ? ob[(int64_t)row * p.o_cs + t] : 0.f;
-    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
@@ -330,11 +394,11 @@ __global__ __launch_bounds__(256) void qconv_i8_kernel(const QConvParams p) {
       float v = (float)a * sprod;
       asm volatile("" : "+v"(v));
       v += rbias[r];
-      if (bb) v += rbb[r];  // the graph adds cond(g) to the finished conv_pre output
-      if (rb) v += rv[r];
-      if (p.accum) v += pv[r];
+      if (bb) v += bb[row];  // the graph adds cond(g) to the finished conv_pre output
+      if (rb) v += rv[j & 1][r];
+      if (p.accum) v += pv[j & 1][r];
       if (dodiv) v = v / p.out_div;
-      ob[(int64_t)row * p.o_cs + t] = v;
+      (ob + (int64_t)(row - 4 * khalf) * p.o_cs + (n0 + 32 * j))[lane_o] = v;
       omn = fminf(omn, v);
       omx = fmaxf(omx, v);
     }
@@ -524,7 +588,15 @@ int32_t launch_qconv(const PackedQConv& pc, QConvIO io, void* scratch, int64_t s
     hipLaunchKernelGGL(qpartial_reset_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, s, partial, (int)blocks);
     WETTS_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL((qconv_i8_kernel<NB>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+  const int R = 32 * NB * (4 / mw) + (pc.ktaps - 1) * pc.dil;
+  const size_t lds = (((size_t)R * (pc.Cp + 16) + 15) & ~(size_t)15) + (size_t)R * sizeof(int);
+  WETTS_REQUIRE(lds <= 160 * 1024, "qconv: tile of %zu bytes exceeds the LDS (Cp %d, k %d, dilation %d)", lds, pc.Cp, pc.ktaps, pc.dil);
+  static signed char opt_in[64] = {};
+  if (lds > 64 * 1024 && !lds_opt_in(reinterpret_cast<const void*>(&qconv_i8_kernel<NB>), opt_in)) {
+    set_error("qconv_i8_kernel: the device refused the %zu-byte dynamic LDS opt-in", lds);
+    return WETTS_E_HIP;
+  }
+  hipLaunchKernelGGL((qconv_i8_kernel<NB>), dim3((unsigned)blocks), dim3(256), lds, s, p);
   WETTS_LAUNCH_CHECK();
   if (io.out_stats) {
     hipLaunchKernelGGL(qrange_reduce_kernel, dim3(1), dim3(1024), 0, s, partial, (int)blocks, io.out_stats);
