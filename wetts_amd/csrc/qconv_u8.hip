@@ -94,6 +94,35 @@ __global__ __launch_bounds__(256) void qminmax_kernel(const float* __restrict__ 
   }
 }
 
+// the same range over a CONTIGUOUS unmasked tensor (every decoder tensor a range pass is run on: the upsamplers' outputs):
+// 16-byte loads, four in flight per thread, no index arithmetic.  (The general kernel does two 64-bit divisions per
+// element: 280 us for the 400 MB tensors of the last stages, 0.9 TB/s.)  act is monotone non-decreasing, so
+// min / max commute with it exactly: it is applied to the two results.
+__global__ __launch_bounds__(256) void qminmax_flat_kernel(const float4* __restrict__ x, int64_t n4, int act, float slope,
+                                                           QuantStats* st) {
+  float mn = INFINITY, mx = -INFINITY;
+  auto fold = [&](const float4& v) {
+    mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+    mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+  };
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a = x[i], b = x[i + stride], c = x[i + 2 * stride], d = x[i + 3 * stride];
+    fold(a); fold(b); fold(c); fold(d);
+  }
+  for (; i < n4; i += stride) fold(x[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, off, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0 && mn <= mx) {
+    atomicMin(&st->min_ord, f2ord(q_act(mn, act, slope)));
+    atomicMax(&st->max_ord, f2ord(q_act(mx, act, slope)));
+  }
+}
+
 // x [B][C][T] f32 -> xs [B][T][Cp] int8 (x_q - 128, channel-last, channels padded to Cp with a real
 // zero) and colsum[b][t] = sum_c xs (over the Cp channels).  A thread takes one frame x 32 channels: 32 loads in
 // flight (each coalesced along t across the lanes), one 32-byte store, and the frame's channel sum without an
@@ -286,21 +315,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
   float* ob = p.out + (int64_t)b * p.o_bs;
   const float* rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
   const bool has_ops = rb != nullptr || p.accum;
-  float rv[2][16], pv[2][16];
-  // (addresses: a uniform row base -- scalar registers -- plus ONE 32-bit lane offset per tensor; per-row 64-bit lane
-  // addresses cost 64 registers and the kernel spilled)
+  // The epilogue walks this lane's 16 rows in four quarters of four rows, and within a row the NB column blocks back to
+  // back: a wave then touches 128 * NB contiguous bytes of a row within a few instructions (one DRAM page visit) instead
+  // of coming back to the row NB times, a column block apart each.  Operands of quarter q + 1 are requested before
+  // quarter q is finished, those of quarter 0 before the contraction starts.
+  float rv[2][4][NB], pv[2][4][NB];
   const int lane_o = 4 * khalf * (int)p.o_cs + l31, lane_r = 4 * khalf * (int)p.r_cs + l31;
-  auto load_ops = [&](int j, float (&rvj)[16], float (&pvj)[16]) __attribute__((always_inline)) {
-    const int t = n0 + 32 * j + l31;
-    const bool okt = active && t < p.T;
+  auto load_ops = [&](int q, float (&rvq)[4][NB], float (&pvq)[4][NB]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rowu = row0 + (r & 3) + 8 * (r >> 2);  // uniform; this lane's row is rowu + 4 * khalf
-      const bool okr = okt && rowu + 4 * khalf < p.M;
-      rvj[r] = 0.f;
-      pvj[r] = 0.f;
-      if (rb && okr) rvj[r] = (rb + (int64_t)rowu * p.r_cs + (n0 + 32 * j))[lane_r];
-      if (p.accum && okr) pvj[r] = (ob + (int64_t)rowu * p.o_cs + (n0 + 32 * j))[lane_o];
+    for (int i = 0; i < 4; ++i) {
+      const int rowu = row0 + i + 8 * q;  // uniform; this lane's row is rowu + 4 * khalf
+      const bool okr = active && rowu + 4 * khalf < p.M;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const bool ok = okr && n0 + 32 * j + l31 < p.T;
+        rvq[i][j] = 0.f;
+        pvq[i][j] = 0.f;
+        if (rb && ok) rvq[i][j] = (rb + (int64_t)rowu * p.r_cs + (n0 + 32 * j))[lane_r];
+        if (p.accum && ok) pvq[i][j] = (ob + (int64_t)rowu * p.o_cs + (n0 + 32 * j))[lane_o];
+      }
     }
   };
   if (has_ops) load_ops(0, rv[0], pv[0]);
@@ -372,35 +405,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
     rcorr[r] = okr ? cx * p.rowsum[row] : 0;
     rbias[r] = (okr && p.bias) ? p.bias[row] : 0.f;
   }
+  int base[NB];  // zero-point terms of this lane's NB columns: window sum of the per-frame channel sums (staged; padding
+  // frames hold Cp * (zx - 128))
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    // the next column block's operands first: in flight behind this block's arithmetic and stores
-    if (has_ops && j + 1 < NB) load_ops(j + 1, rv[(j + 1) & 1], pv[(j + 1) & 1]);
-    const int t = n0 + 32 * j + l31;
-    if (t >= p.T) continue;
-    int cs = 0;  // sum over the receptive field of the per-frame channel sums (padding frames = Cp * (zx-128), staged)
-    {
-      const int* cp = cs_l + (n0 - nb0) + 32 * j + l31;
-      for (int tap = 0; tap < p.ktaps; ++tap) cs += cp[tap * p.dil];
-    }
-    const int base = cw * cs + K * cx * cw;
+    const int* cp = cs_l + (n0 - nb0) + 32 * j + l31;
+    int cs = 0;
+    for (int tap = 0; tap < p.ktaps; ++tap) cs += cp[tap * p.dil];
+    base[j] = cw * cs + K * cx * cw;
+  }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+  for (int q = 0; q < 4; ++q) {
+    if (has_ops && q + 1 < 4) load_ops(q + 1, rv[(q + 1) & 1], pv[(q + 1) & 1]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * q + i;  // accumulator register: rows (r & 3) + 8 * (r >> 2) + 4 * khalf
+      const int row = row0 + i + 8 * q + 4 * khalf;
       if (row >= p.M) continue;
-      const int a = acc[j][r] + base + rcorr[r];
-      // (the empty asm pins the rounded product: HIP contracts a * b + c -- also through __fmul_rn / __fadd_rn --
-      // into v_fma_f32, one rounding instead of the graph's two)
-      float v = (float)a * sprod;
-      asm volatile("" : "+v"(v));
-      v += rbias[r];
-      if (bb) v += bb[row];  // the graph adds cond(g) to the finished conv_pre output
-      if (rb) v += rv[j & 1][r];
-      if (p.accum) v += pv[j & 1][r];
-      if (dodiv) v = v / p.out_div;
-      (ob + (int64_t)(row - 4 * khalf) * p.o_cs + (n0 + 32 * j))[lane_o] = v;
-      omn = fminf(omn, v);
-      omx = fmaxf(omx, v);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (n0 + 32 * j + l31 >= p.T) continue;
+        const int a = acc[j][r] + base[j] + rcorr[r];
+        // (the empty asm pins the rounded product: HIP contracts a * b + c -- also through __fmul_rn / __fadd_rn --
+        // into v_fma_f32, one rounding instead of the graph's two)
+        float v = (float)a * sprod;
+        asm volatile("" : "+v"(v));
+        v += rbias[r];
+        if (bb) v += bb[row];  // the graph adds cond(g) to the finished conv_pre output
+        if (rb) v += rv[q & 1][i][j];
+        if (p.accum) v += pv[q & 1][i][j];
+        if (dodiv) v = v / p.out_div;
+        (ob + (int64_t)(row - 4 * khalf) * p.o_cs + (n0 + 32 * j))[lane_o] = v;
+        omn = fminf(omn, v);
+        omx = fmaxf(omx, v);
+      }
     }
   }
   if (p.out_partial) {
@@ -523,14 +561,27 @@ int32_t k_qstats_reset(QuantStats* slots, int n, hipStream_t s) {
   return WETTS_OK;
 }
 
-int32_t k_qminmax(const float* x, int B, int C, int T, QuantStats* slot, hipStream_t s) {
+// range of act(x * mask) over [B][C][T] into a reset slot: the flat kernel for contiguous unmasked tensors
+static int32_t launch_qminmax(const float* x, int64_t x_bs, int64_t x_cs, const float* mask, int64_t mask_stride, int B,
+                              int C, int T, int act, float slope, QuantStats* slot, hipStream_t s) {
   const int64_t nx = (int64_t)B * C * T;
   if (nx <= 0) return WETTS_OK;
-  const int gridm = (int)((nx + 255) / 256 < 4096 ? (nx + 255) / 256 : 4096);
-  hipLaunchKernelGGL(qminmax_kernel, dim3(gridm), dim3(256), 0, s, x, (int64_t)C * T, (int64_t)T,
-                     (const float*)nullptr, (int64_t)0, B, C, T, 0, 0.f, slot);
+  if (!mask && x_cs == T && x_bs == (int64_t)C * T && (nx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const int64_t n4 = nx >> 2;
+    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(qminmax_flat_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(x), n4, act, slope,
+                       slot);
+  } else {
+    const int gridm = (int)((nx + 255) / 256 < 4096 ? (nx + 255) / 256 : 4096);
+    hipLaunchKernelGGL(qminmax_kernel, dim3(gridm), dim3(256), 0, s, x, x_bs, x_cs, mask, mask_stride, B, C, T, act, slope,
+                       slot);
+  }
   WETTS_LAUNCH_CHECK();
   return WETTS_OK;
+}
+
+int32_t k_qminmax(const float* x, int B, int C, int T, QuantStats* slot, hipStream_t s) {
+  return launch_qminmax(x, (int64_t)C * T, (int64_t)T, nullptr, 0, B, C, T, 0, 0.f, slot, s);
 }
 
 int32_t launch_qconv(const PackedQConv& pc, QConvIO io, void* scratch, int64_t scratch_bytes,
@@ -554,11 +605,7 @@ int32_t launch_qconv(const PackedQConv& pc, QConvIO io, void* scratch, int64_t s
   const bool have_range = io.in_stats != nullptr && io.mask == nullptr;
   const QuantStats* st = have_range ? io.in_stats : own;
   if (!have_range) {  // one more pass over the tensor: range of act(x * mask)
-    const int64_t nx = (int64_t)B * pc.Cin * T;
-    const int gridm = (int)((nx + 255) / 256 < 4096 ? (nx + 255) / 256 : 4096);
-    hipLaunchKernelGGL(qminmax_kernel, dim3(gridm), dim3(256), 0, s, io.x, io.x_bs, io.x_cs, io.mask,
-                       io.mask_stride, B, pc.Cin, T, io.in_act, io.in_slope, own);
-    WETTS_LAUNCH_CHECK();
+    WETTS_TRY(launch_qminmax(io.x, io.x_bs, io.x_cs, io.mask, io.mask_stride, B, pc.Cin, T, io.in_act, io.in_slope, own, s));
   }
   const int64_t nq = (int64_t)B * (pc.Cp / 32) * T;
   hipLaunchKernelGGL(qquantize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, io.x, io.x_bs,
@@ -577,6 +624,8 @@ int32_t launch_qconv(const PackedQConv& pc, QConvIO io, void* scratch, int64_t s
   p.in_act = have_range ? io.in_act : 0;  // the stats of the range pass already are those of act(x)
   p.in_slope = io.in_slope;
   p.out_stats = io.out_stats;
+  // (NB = 2 -- 159 registers, three waves per SIMD -- measured 3 % slower: what counts is the length of the contiguous run a
+  // wave moves per row, not the number of waves)
   constexpr int NB = 4;
   const int mw = pc.Cout > 64 ? 4 : (pc.Cout > 32 ? 2 : 1);  // as in the kernel
   const int64_t blocks = (int64_t)cdiv(T, 32 * NB * (4 / mw)) * cdiv(pc.Cout, 32 * mw) * B;
