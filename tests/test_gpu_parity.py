@@ -443,7 +443,12 @@ def test_flow_16bit_mode_matches_its_numerics_spec(name, dtype):
 
 @pytest.mark.parametrize("B,Cin,Cout,k,dil,T", [(2, 32, 32, 3, 1, 300), (3, 192, 64, 7, 1, 77),
                                                 (1, 64, 64, 11, 5, 1000), (2, 256, 1, 1, 1, 1),
-                                                (2, 40, 96, 5, 3, 129), (1, 32, 1, 7, 1, 513)])
+                                                (2, 40, 96, 5, 3, 129), (1, 32, 1, 7, 1, 513),
+                                                # round 6 (LDS-tile conv, flat range pass): an odd element count (the
+                                                # general range kernel), the widest tile (k = 11 at dilation 5, C = 128),
+                                                # two m-tiles of rows (C = 256), a tile wider than the sequence
+                                                (1, 33, 32, 3, 2, 131), (1, 128, 128, 11, 5, 700),
+                                                (1, 256, 256, 7, 3, 333), (2, 32, 32, 11, 5, 40)])
 def test_dynamic_quant_conv1d_is_bit_exact_to_its_restatement(B, Cin, Cout, k, dil, T):
     """The uint8 dynamic-quantisation conv (qconv_u8.hip, v_mfma_i32_32x32x32_i8) against the exact-integer
     restatement of DynamicQuantizeLinear -> ConvInteger -> scale + bias (oracle.dynamic_quant_conv1d):
