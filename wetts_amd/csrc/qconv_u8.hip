@@ -233,12 +233,16 @@ __global__ void qpack_weight_kernel(const float* __restrict__ w, const QuantWeig
 //   * the block's int8 tile -- [columns + (k - 1) dilation frames][Cp channels], a contiguous piece of the
 //     channel-last image -- and the per-frame channel sums of those frames are staged in LDS once; the taps are
 //     ds_read_b128 at shifted rows (row stride Cp + 16 bytes: conflict-free), the zero-point window sums LDS reads;
-//   * A fragments in a ring six steps deep (24 registers: a step is NB MFMAs of 32 cycles, an L2 round trip is 10+);
+//   * A fragments in a ring four steps deep (a step is NB MFMAs of 32 cycles, an L2 round trip is 10+);
 //   * the epilogue's f32 operands (residual, running sum) of column block j + 1 are requested before block j is
 //     finished, those of block 0 before the contraction starts: the loads of a wave are in flight all the time.
+//   * 166 registers -- THREE waves per SIMD: the per-row constants of the epilogue are fetched per row quarter instead of
+//     sixteen of each being held across the contraction, the A ring is four deep.  The waves of this kernel wait on memory
+//     for 55 % of their cycles (SQ counters), and the third resident block is worth 12 % of the uint8 step (33.6 -> 29.4
+//     ms, same box; a fourth wave for the convs without a residual measured nothing more).
 // Integer accumulation is exact in any order, and the f32 expression per element is unchanged: bit-identical output.
 template <int NB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void qconv_i8_kernel(const QConvParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void qconv_i8_kernel(const QConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
   const int nsteps = p.ktaps * CG;  // steps = (tap, channel group) pairs, tap-major: the packed order
 
   // ---- A ring: requested first, lands behind the staging --------------------------------------------------------
-  constexpr int RD = 6;
+  constexpr int RD = 4;
   uint4 a_r[RD];
 #pragma unroll
   for (int u = 0; u < RD; ++u) a_r[u] = ab[(int64_t)(u < nsteps ? u : nsteps - 1) * 64];
@@ -395,16 +399,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
   const float* bb = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_stride : nullptr;
   const bool dodiv = p.out_div != 1.f;
   float omn = INFINITY, omx = -INFINITY;  // range of what this wave writes (for the conv that consumes it)
-  // per-row constants of this lane's 16 rows: zero-point correction, bias (+ per-utterance bias)
-  int rcorr[16];
-  float rbias[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-    const bool okr = row < p.M;
-    rcorr[r] = okr ? cx * p.rowsum[row] : 0;
-    rbias[r] = (okr && p.bias) ? p.bias[row] : 0.f;
-  }
   int base[NB];  // zero-point terms of this lane's NB columns: window sum of the per-frame channel sums (staged; padding
   // frames hold Cp * (zx - 128))
 #pragma unroll
@@ -417,6 +411,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if (has_ops && q + 1 < 4) load_ops(q + 1, rv[(q + 1) & 1], pv[(q + 1) & 1]);
+    // the quarter's per-row constants (zero-point correction, bias): loaded here, four at a time -- sixteen of each
+    // held across the contraction cost the third wave per SIMD
+    int rcq[4];
+    float rbq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + i + 8 * q + 4 * khalf;
+      const bool okr = row < p.M;
+      rcq[i] = okr ? cx * p.rowsum[row] : 0;
+      rbq[i] = (okr && p.bias) ? p.bias[row] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * q + i;  // accumulator register: rows (r & 3) + 8 * (r >> 2) + 4 * khalf
@@ -425,12 +430,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         if (n0 + 32 * j + l31 >= p.T) continue;
-        const int a = acc[j][r] + base[j] + rcorr[r];
+        const int a = acc[j][r] + base[j] + rcq[i];
         // (the empty asm pins the rounded product: HIP contracts a * b + c -- also through __fmul_rn / __fadd_rn --
         // into v_fma_f32, one rounding instead of the graph's two)
         float v = (float)a * sprod;
         asm volatile("" : "+v"(v));
-        v += rbias[r];
+        v += rbq[i];
         if (bb) v += bb[row];  // the graph adds cond(g) to the finished conv_pre output
         if (rb) v += rv[q & 1][i][j];
         if (p.accum) v += pv[q & 1][i][j];
