@@ -448,7 +448,9 @@ def test_flow_16bit_mode_matches_its_numerics_spec(name, dtype):
                                                 # general range kernel), the widest tile (k = 11 at dilation 5, C = 128),
                                                 # two m-tiles of rows (C = 256), a tile wider than the sequence
                                                 (1, 33, 32, 3, 2, 131), (1, 128, 128, 11, 5, 700),
-                                                (1, 256, 256, 7, 3, 333), (2, 32, 32, 11, 5, 40)])
+                                                (1, 256, 256, 7, 3, 333), (2, 32, 32, 11, 5, 40),
+                                                # a tile above the default 64 KB of dynamic LDS (the opt-in path)
+                                                (1, 512, 128, 3, 1, 200)])
 def test_dynamic_quant_conv1d_is_bit_exact_to_its_restatement(B, Cin, Cout, k, dil, T):
     """The uint8 dynamic-quantisation conv (qconv_u8.hip, v_mfma_i32_32x32x32_i8) against the exact-integer
     restatement of DynamicQuantizeLinear -> ConvInteger -> scale + bias (oracle.dynamic_quant_conv1d):
