@@ -84,6 +84,10 @@ def test_pointwise_gemm_and_16bit_kernels_keep_their_occupancy(table):
             assert v["VGPRs"] <= 192 and v["ScratchSize"] == 0, (k, v)
         if "rb2_stage16_kernel<" in k:  # two blocks of four waves per CU
             assert v["VGPRs"] <= 256 and v["ScratchSize"] == 0, (k, v)
+        # the uint8 conv: its waves wait on memory, and the third one per SIMD was worth 12 % of the uint8 step (round 6,
+        # profiles/r06_ab_uint8.txt: 188 -> 166 registers)
+        if "qconv_i8_kernel<" in k:
+            assert v["VGPRs"] <= 168 and v["ScratchSize"] == 0, (k, v)
 
 
 def test_no_serialised_load_round_trips_in_the_kernels_fixed_for_them():
